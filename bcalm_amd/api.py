@@ -1,0 +1,176 @@
+"""ctypes binding of libcdbg.so (include/cdbg.h) -- the host-side Python mirror.
+
+Plain pointers and sizes only; torch is not involved.  `load()` opens the HIP build
+(bcalm_amd/_build/libcdbg.so); there is no CPU fallback: without the library or
+without a HIP device every entry point raises.  (tests/ may pass `path=` to bind the
+kernel-logic simulator built by tests/hostsim/build.sh; nothing in this package does.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "_build", "libcdbg.so")
+
+
+class CdbgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcdbg error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("k", C.c_int), ("abundance_min", C.c_int), ("minimizer_size", C.c_int),
+                ("log2_partitions", C.c_int), ("device_id", C.c_int), ("world_size", C.c_int),
+                ("rank", C.c_int), ("all_abundance_counts", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "input_bytes", "n_records", "n_member_kmers", "n_occurrences", "n_distinct", "n_solid",
+        "n_solid_travellers", "n_pieces", "n_glue_open_ends", "n_glue_joined", "n_unitigs",
+        "unitig_bases", "n_big_partitions", "n_cycles")] + [
+        ("minimizer_size", C.c_int), ("log2_partitions", C.c_int), ("kmer_words", C.c_int)] + [
+        (n, C.c_float) for n in ("ms_scan_hist", "ms_scan_emit", "ms_count", "ms_compact", "ms_glue", "ms_total")] + [
+        (n, C.c_uint64) for n in ("n_launch_scan", "n_launch_count", "n_launch_compact")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
+           "cdbg_generate_reads", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run",
+           "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats"]
+
+
+def load(path: str | None = None) -> C.CDLL:
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise CdbgError(-2, f"{path} not found: build the HIP extension first "
+                            f"(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    lib = C.CDLL(path)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    lib.cdbg_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    lib.cdbg_destroy.argtypes = [vp]
+    lib.cdbg_destroy.restype = None
+    lib.cdbg_last_error.restype = C.c_char_p
+    lib.cdbg_push_reads.argtypes = [vp, C.c_char_p, C.POINTER(u64), u64]
+    lib.cdbg_push_text.argtypes = [vp, C.c_char_p, u64]
+    lib.cdbg_generate_reads.argtypes = [vp, u64, u64, u64, u64, i32]
+    lib.cdbg_read_text.argtypes = [vp, u64, u64, C.c_char_p]
+    for f in ("cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run"):
+        getattr(lib, f).argtypes = [vp]
+    lib.cdbg_num_solid.argtypes = [vp, C.POINTER(u64)]
+    lib.cdbg_fetch_solid.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint32), u64, C.POINTER(u64)]
+    lib.cdbg_num_unitigs.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    lib.cdbg_fetch_unitigs.argtypes = [vp, u64, u64, C.c_char_p, C.POINTER(u64), C.POINTER(u64)]
+    lib.cdbg_stats.argtypes = [vp, C.POINTER(Stats)]
+    return lib
+
+
+class Graph:
+    """One construction job.  Mirrors the reference's single entry point
+    GraphUnitigsTemplate<span>::create(props, false) (/root/reference/src/bcalm_1.cpp:57)
+    with its three properties -kmer-size / -abundance-min / -in, staged as
+    count() -> compact() -> glue() (or run())."""
+
+    def __init__(self, k: int, abundance_min: int = 2, minimizer_size: int = 0, log2_partitions: int = -1,
+                 device_id: int = 0, world_size: int = 1, rank: int = 0, lib: C.CDLL | None = None):
+        self.lib = lib or load()
+        self.k = k
+        p = Params(k, abundance_min, minimizer_size, log2_partitions, device_id, world_size, rank, 0)
+        self._h = C.c_void_p()
+        self._ck(self.lib.cdbg_create(C.byref(p), C.byref(self._h)))
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise CdbgError(rc, (self.lib.cdbg_last_error() or b"").decode())
+
+    def close(self):
+        if self._h:
+            self.lib.cdbg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- input ----
+    def push_text(self, text):
+        b = text if isinstance(text, (bytes, bytearray)) else text.encode()
+        self._ck(self.lib.cdbg_push_text(self._h, bytes(b), len(b)))
+
+    def push_reads(self, reads):
+        seqs = [r if isinstance(r, bytes) else r.encode() for r in reads]
+        offs = (C.c_uint64 * (len(seqs) + 1))()
+        acc = 0
+        for i, s in enumerate(seqs):
+            offs[i] = acc
+            acc += len(s)
+        offs[len(seqs)] = acc
+        self._ck(self.lib.cdbg_push_reads(self._h, b"".join(seqs), offs, len(seqs)))
+
+    def generate_reads(self, n_reads, read_len, cfg, first_read=0, total_reads=None):
+        total = n_reads if total_reads is None else total_reads
+        self._ck(self.lib.cdbg_generate_reads(self._h, first_read, n_reads, total, read_len, cfg))
+
+    def read_text(self, first, n):
+        buf = C.create_string_buffer(n)
+        self._ck(self.lib.cdbg_read_text(self._h, first, n, buf))
+        return buf.raw
+
+    # ---- stages ----
+    def count(self):
+        self._ck(self.lib.cdbg_count(self._h))
+
+    def compact(self):
+        self._ck(self.lib.cdbg_compact(self._h))
+
+    def glue(self):
+        self._ck(self.lib.cdbg_glue(self._h))
+
+    def run(self):
+        self._ck(self.lib.cdbg_run(self._h))
+
+    # ---- results ----
+    def stats(self) -> dict:
+        s = Stats()
+        self._ck(self.lib.cdbg_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def solid_kmers(self):
+        n = C.c_uint64()
+        self._ck(self.lib.cdbg_num_solid(self._h, C.byref(n)))
+        n = n.value
+        if n == 0:
+            return []
+        kb = C.create_string_buffer(n * (self.k + 1))
+        cnt = (C.c_uint32 * n)()
+        nw = C.c_uint64()
+        self._ck(self.lib.cdbg_fetch_solid(self._h, kb, cnt, n, C.byref(nw)))
+        raw = kb.raw
+        k1 = self.k + 1
+        return sorted((raw[i * k1:i * k1 + self.k].decode(), cnt[i]) for i in range(nw.value))
+
+    def unitigs(self):
+        """-> [(sequence, KC)] in the library's arbitrary order/orientation"""
+        n, tb = C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.cdbg_num_unitigs(self._h, C.byref(n), C.byref(tb)))
+        n, tb = n.value, tb.value
+        if n == 0:
+            return []
+        seq = C.create_string_buffer(max(tb, 1))
+        off = (C.c_uint64 * (n + 1))()
+        kc = (C.c_uint64 * n)()
+        self._ck(self.lib.cdbg_fetch_unitigs(self._h, 0, n, seq, off, kc))
+        raw = seq.raw
+        return [(raw[off[i]:off[i + 1]].decode(), kc[i]) for i in range(n)]

@@ -1,0 +1,558 @@
+// cdbg_impl.cpp -- libcdbg.so: host orchestration behind the C ABI of include/cdbg.h.
+//
+// This is the MI355X replacement for what GraphUnitigsTemplate<span>::create() does
+// behind /root/reference/src/bcalm_1.cpp:57 (configure -> count -> bcalm -> bglue):
+// pick the k-mer width (the Integer::apply dispatch of bcalm_1.cpp:95 becomes a
+// template switch on W = 1, 2, 4), pick minimizer size / partition count from the input
+// volume (the job of DSK's configuration step), then drive
+// the hand-written HIP kernels on one stream with everything resident in HBM.
+//
+// Built two ways from this same source:
+//   hipcc --offload-arch=gfx950  -> bcalm_amd/_build/libcdbg.so   (the product)
+//   g++ -DCDBG_HOSTSIM           -> tests/hostsim/_build/...      (kernel-logic simulator, tests only)
+// The product has NO CPU fallback: without a HIP device cdbg_create() fails.
+#include "../../include/cdbg.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "k_glue.h"
+
+using namespace cdbg;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCK(call)                                                                                   \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(e_ == hipErrorOutOfMemory ? CDBG_E_NOMEM : CDBG_E_NODEVICE, "%s failed: %s (%s:%d)", \
+                        #call, hipGetErrorString(e_), __FILE__, __LINE__);                            \
+    } while (0)
+#define CK(expr) do { int rc_ = (expr); if (rc_ != CDBG_OK) return rc_; } while (0)
+
+template <class T>
+struct DBuf {                                   // owned device array
+    T* p = nullptr; size_t n = 0;
+    int alloc(size_t count, bool zero) {
+        release();
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return fail(CDBG_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+        n = count;
+        if (zero) { e = hipMemset(p, 0, bytes); if (e != hipSuccess) return fail(CDBG_E_NODEVICE, "hipMemset failed"); }
+        return CDBG_OK;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    ~DBuf() { release(); }
+};
+
+constexpr int TS_COUNT_1 = 4096, TS_COUNT_2 = 2048, TS_COUNT_4 = 1024;      // LDS table slots per W
+constexpr int TS_COMPACT_1 = 1024, TS_COMPACT_2 = 1024, TS_COMPACT_4 = 512;
+template <int W> struct Cfg;
+template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1; };
+template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2; };
+template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4; };
+
+uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
+
+}  // namespace
+
+struct cdbg_ctx {
+    cdbg_params prm{};
+    int W = 1, k = 0, m = 0, log_np = 0, rank_bits = 0;
+    uint64_t n_local_parts = 1;
+    hipStream_t stream{};
+    int stage = 0;                               // 0 input, 1 counted, 2 compacted, 3 glued
+    cdbg_stats_t st{};
+
+    std::vector<char> host_text;                 // pushed reads awaiting upload
+    DBuf<uint8_t> reads; uint64_t nbytes = 0, nbytes_padded = 0;
+
+    DBuf<uint32_t> part_count; DBuf<uint64_t> part_off, part_cursor, records;
+    DBuf<uint64_t> dstats; DBuf<uint32_t> derr;
+    DBuf<uint64_t> solid_keys; DBuf<uint32_t> solid_cnt; DBuf<uint64_t> solid_cursor, seg_off; DBuf<uint32_t> seg_n;
+    DBuf<uint32_t> big_list, big_count;
+    uint64_t n_solid_entries = 0;                // home + traveller solid entries
+
+    DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
+    DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_state, glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;
+    uint64_t n_pieces = 0, n_piece_bases = 0;
+
+    DBuf<uint64_t> unitig_off; DBuf<uint32_t> unitig_len; DBuf<uint64_t> unitig_kc; DBuf<uint8_t> unitig_bases;
+    uint64_t n_unitigs = 0, unitig_total = 0;
+};
+
+namespace {
+
+int upload_pending(cdbg_ctx* c) {
+    if (c->host_text.empty()) return CDBG_OK;
+    if (c->reads.p) return fail(CDBG_E_STATE, "reads already resident: push all reads before the first stage");
+    const uint64_t n = c->host_text.size();
+    const uint64_t np = ((n + 15) / 16) * 16 + 256;
+    CK(c->reads.alloc(np, false));
+    HIPCK(hipMemset(c->reads.p, '\n', np));
+    HIPCK(hipMemcpy(c->reads.p, c->host_text.data(), n, hipMemcpyHostToDevice));
+    c->nbytes = n; c->nbytes_padded = np;
+    std::vector<char>().swap(c->host_text);
+    return CDBG_OK;
+}
+
+int read_u64(const uint64_t* dptr, uint64_t* out, size_t n = 1) {
+    HIPCK(hipMemcpy(out, dptr, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return CDBG_OK;
+}
+int read_u32(const uint32_t* dptr, uint32_t* out, size_t n = 1) {
+    HIPCK(hipMemcpy(out, dptr, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CDBG_OK;
+}
+int check_device_error(cdbg_ctx* c, const char* where) {
+    uint32_t e = 0; CK(read_u32(c->derr.p, &e));
+    if (e) return fail(CDBG_E_INTERNAL, "%s: device reported error %u (1 solid overflow, 2 scratch sizing, 3 piece overflow, 4 unitig overflow)", where, e);
+    HIPCK(hipGetLastError());
+    return CDBG_OK;
+}
+struct Timer {
+    hipEvent_t a{}, b{}; hipStream_t s{};
+    int start(hipStream_t st) { s = st; HIPCK(hipEventCreate(&a)); HIPCK(hipEventCreate(&b)); HIPCK(hipEventRecord(a, s)); return CDBG_OK; }
+    int stop(float* ms) { HIPCK(hipEventRecord(b, s)); HIPCK(hipEventSynchronize(b)); HIPCK(hipEventElapsedTime(ms, a, b)); (void)hipEventDestroy(a); (void)hipEventDestroy(b); return CDBG_OK; }
+};
+
+// ---------------------------------------------------------------------------------------
+// configuration (DSK's "configure" role, row a5): partitions and minimizer length from volume
+// ---------------------------------------------------------------------------------------
+void configure(cdbg_ctx* c) {
+    const int W = c->W;
+    const int ts = W == 1 ? TS_COUNT_1 : W == 2 ? TS_COUNT_2 : TS_COUNT_4;
+    const uint64_t target_occ = (uint64_t)ts / 4;            // mean k-mer occurrences per partition
+    int log_np = c->prm.log2_partitions;
+    if (log_np < 0) {
+        log_np = 0;
+        while (log_np < 24 && ((uint64_t)1 << log_np) * target_occ < c->nbytes) ++log_np;
+    }
+    if (log_np < c->rank_bits) log_np = c->rank_bits;
+    if (log_np > 26) log_np = 26;
+    int m = c->prm.minimizer_size;
+    if (m <= 0) m = std::min(16, std::max(6, (log_np + 10) / 2 + 1));
+    m = std::max(1, std::min(m, std::min(16, c->k - 1)));
+    c->log_np = log_np; c->m = m;
+    c->n_local_parts = ((uint64_t)1 << log_np) >> c->rank_bits;
+    c->st.minimizer_size = m; c->st.log2_partitions = log_np; c->st.kmer_words = W;
+}
+
+template <int W>
+int count_impl(cdbg_ctx* c) {
+    constexpr int RW = RecFmt<W>::RW;
+    constexpr int TS = Cfg<W>::TSC;
+    CK(upload_pending(c));
+    if (!c->reads.p || c->nbytes == 0) return fail(CDBG_E_STATE, "no reads: call cdbg_push_reads/cdbg_push_text/cdbg_generate_reads first");
+    configure(c);
+    const uint64_t NPL = c->n_local_parts;
+    hipStream_t s = c->stream;
+    Timer t_total; CK(t_total.start(s));
+
+    CK(c->part_count.alloc(NPL, true));
+    CK(c->part_off.alloc(NPL + 1, false));
+    CK(c->part_cursor.alloc(NPL, false));
+    CK(c->dstats.alloc(32, true));
+    CK(c->derr.alloc(4, true));
+
+    ScanParams sp{};
+    sp.reads = c->reads.p; sp.nbytes = c->nbytes; sp.nbytes_padded = c->nbytes_padded;
+    sp.k = c->k; sp.m = c->m; sp.log_np = c->log_np; sp.rank_bits = c->rank_bits; sp.rank = c->prm.rank;
+    sp.part_count = c->part_count.p; sp.part_cursor = c->part_cursor.p; sp.records = nullptr; sp.stats = c->dstats.p;
+    const uint64_t tiles = (c->nbytes + SCAN_TILE - 1) / SCAN_TILE;
+    c->st.n_launch_scan = tiles;
+
+    // pass 1: histogram of records per partition
+    Timer t; CK(t.start(s));
+    CDBG_LAUNCH((k_scan<W, false>), tiles, SCAN_THREADS, s, sp);
+    CDBG_LAUNCH(k_exscan, 1, EXSCAN_THREADS, s, (const uint32_t*)c->part_count.p, c->part_off.p, NPL);
+    CK(t.stop(&c->st.ms_scan_hist));
+    uint64_t n_records = 0; CK(read_u64(c->part_off.p + NPL, &n_records));
+    uint64_t hs[2] = {0, 0}; CK(read_u64(c->dstats.p, hs, 2));
+    c->st.n_records = n_records; c->st.n_member_kmers = hs[0];
+
+    // pass 2: emit records at exact offsets
+    CK(c->records.alloc(std::max<uint64_t>(n_records, 1) * RW, false));
+    CK(t.start(s));
+    CDBG_LAUNCH(k_copy_u64, (NPL + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_cursor.p, NPL);
+    sp.records = c->records.p;
+    CDBG_LAUNCH((k_scan<W, true>), tiles, SCAN_THREADS, s, sp);
+    CK(t.stop(&c->st.ms_scan_emit));
+
+    // count
+    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096;
+    CK(c->solid_keys.alloc(solid_cap * W, false));
+    CK(c->solid_cnt.alloc(solid_cap, false));
+    CK(c->solid_cursor.alloc(4, true));
+    CK(c->seg_off.alloc(NPL, true));
+    CK(c->seg_n.alloc(NPL, true));
+    CK(c->big_list.alloc(NPL, false));
+    CK(c->big_count.alloc(4, true));
+    HIPCK(hipMemset(c->dstats.p, 0, 32 * sizeof(uint64_t)));
+
+    CountParams cp{};
+    cp.records = c->records.p; cp.part_off = c->part_off.p; cp.part_list = nullptr;
+    cp.k = c->k; cp.amin = (uint32_t)c->prm.abundance_min;
+    cp.solid_keys = c->solid_keys.p; cp.solid_cnt = c->solid_cnt.p; cp.solid_cap = solid_cap; cp.solid_cursor = c->solid_cursor.p;
+    cp.seg_off = c->seg_off.p; cp.seg_n = c->seg_n.p; cp.stats = c->dstats.p;
+    cp.big_list = c->big_list.p; cp.big_count = c->big_count.p; cp.error = c->derr.p;
+    CK(t.start(s));
+    CDBG_LAUNCH((k_count<W, TS, false>), NPL, COUNT_THREADS, s, cp);
+    c->st.n_launch_count = NPL;
+    uint32_t nbig = 0;
+    HIPCK(hipStreamSynchronize(s));
+    CK(read_u32(c->big_count.p, &nbig));
+    DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_state, g_cnt;
+    if (nbig) {                                              // partitions whose distinct k-mers overflow LDS
+        std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list.p, bl.data(), nbig));
+        std::sort(bl.begin(), bl.end());
+        std::vector<uint64_t> offs(nbig + 1, 0);
+        const uint64_t nmax = (uint64_t)RecFmt<W>::CAPB - c->k + 1;
+        for (uint32_t i = 0; i < nbig; ++i) {
+            uint64_t po[2]; CK(read_u64(c->part_off.p + bl[i], po, 2));
+            const uint64_t occ = (po[1] - po[0]) * nmax;
+            offs[i + 1] = offs[i] + pow2_at_least(2 * occ + 4 * COUNT_THREADS);
+        }
+        CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_state.alloc(offs[nbig], false)); CK(g_cnt.alloc(offs[nbig], false));
+        CK(big_off.alloc(nbig + 1, false));
+        HIPCK(hipMemcpy(big_off.p, offs.data(), (nbig + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
+        CountParams bp = cp;
+        bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_state = g_state.p; bp.g_cnt = g_cnt.p; bp.big_off = big_off.p;
+        CDBG_LAUNCH((k_count<W, TS, true>), nbig, COUNT_THREADS, s, bp);
+        c->st.n_big_partitions += nbig;
+    }
+    CK(t.stop(&c->st.ms_count));
+    CK(check_device_error(c, "count"));
+    uint64_t cs[4]; CK(read_u64(c->dstats.p, cs, 4));
+    c->st.n_distinct = cs[0]; c->st.n_occurrences = cs[1]; c->st.n_solid = cs[2]; c->st.n_solid_travellers = cs[3];
+    CK(read_u64(c->solid_cursor.p, &c->n_solid_entries));
+    c->st.input_bytes = c->nbytes;
+    float ms = 0; CK(t_total.stop(&ms)); c->st.ms_total = ms;
+    c->stage = 1;
+    return CDBG_OK;
+}
+
+template <int W>
+int compact_impl(cdbg_ctx* c) {
+    constexpr int TS = Cfg<W>::TSK;
+    if (c->stage < 1) return fail(CDBG_E_STATE, "cdbg_compact before cdbg_count");
+    hipStream_t s = c->stream;
+    const uint64_t NPL = c->n_local_parts;
+    const uint64_t S = c->st.n_solid;
+    Timer t; CK(t.start(s));
+    // glue table: at most one junction per solid traveller entry
+    c->glue_cap = (uint32_t)pow2_at_least(2 * c->st.n_solid_travellers + 64);
+    CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false));
+    CK(c->glue_state.alloc(c->glue_cap, false));
+    CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
+    CK(c->cursors.alloc(8, false));
+
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const uint64_t pcap = attempt == 0 ? std::min<uint64_t>(S, S / 3 + 4096) + 16 : S + 16;
+        const uint64_t bcap = attempt == 0 ? S + pcap * (uint64_t)(c->k - 1) + 64 : S * (uint64_t)c->k + 64;
+        CK(c->piece_n.alloc(pcap, false)); CK(c->piece_kc.alloc(pcap, false)); CK(c->piece_boff.alloc(pcap, false));
+        CK(c->piece_bases.alloc(bcap, false));
+        HIPCK(hipMemsetAsync(c->cursors.p, 0, 8 * sizeof(uint64_t), s));
+        HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), s));
+        HIPCK(hipMemsetAsync(c->glue_state.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->glue_b.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->glue_conf.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->big_count.p, 0, 4 * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+
+        CompactParams kp{};
+        kp.solid_keys = c->solid_keys.p; kp.solid_cnt = c->solid_cnt.p; kp.seg_off = c->seg_off.p; kp.seg_n = c->seg_n.p;
+        kp.part_list = nullptr; kp.k = c->k; kp.m = c->m; kp.log_np = c->log_np; kp.rank_bits = c->rank_bits; kp.rank = c->prm.rank;
+        kp.piece_n = c->piece_n.p; kp.piece_kc = c->piece_kc.p; kp.piece_boff = c->piece_boff.p; kp.piece_bases = c->piece_bases.p;
+        kp.piece_cap = pcap; kp.bases_cap = bcap; kp.piece_cursor = c->cursors.p; kp.bases_cursor = c->cursors.p + 1;
+        kp.glue_keys = c->glue_keys.p; kp.glue_state = c->glue_state.p; kp.glue_a = c->glue_a.p; kp.glue_b = c->glue_b.p;
+        kp.glue_conf = c->glue_conf.p; kp.glue_mask = c->glue_cap - 1;
+        kp.big_list = c->big_list.p; kp.big_count = c->big_count.p; kp.error = c->derr.p; kp.stats = c->dstats.p;
+        CDBG_LAUNCH((k_compact<W, TS, false>), NPL, COMPACT_THREADS, s, kp);
+        c->st.n_launch_compact = NPL;
+        HIPCK(hipStreamSynchronize(s));
+        uint32_t nbig = 0; CK(read_u32(c->big_count.p, &nbig));
+        DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_state, g_cnt, g_lnk, g_aux;
+        if (nbig) {                                          // buckets with more entries than fit LDS
+            std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list.p, bl.data(), nbig));
+            std::sort(bl.begin(), bl.end());
+            std::vector<uint64_t> offs(nbig + 1, 0);
+            for (uint32_t i = 0; i < nbig; ++i) {
+                uint32_t e = 0; CK(read_u32(c->seg_n.p + bl[i], &e));
+                offs[i + 1] = offs[i] + pow2_at_least(2 * (uint64_t)e + 16);
+            }
+            CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_state.alloc(offs[nbig], false)); CK(g_cnt.alloc(offs[nbig], false));
+            CK(g_lnk.alloc(2 * offs[nbig], false)); CK(g_aux.alloc(2 * offs[nbig], false));
+            CK(big_off.alloc(nbig + 1, false));
+            HIPCK(hipMemcpy(big_off.p, offs.data(), (nbig + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+            HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
+            CompactParams bp = kp;
+            bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_state = g_state.p; bp.g_cnt = g_cnt.p;
+            bp.g_lnk = g_lnk.p; bp.g_aux = g_aux.p; bp.big_off = big_off.p;
+            CDBG_LAUNCH((k_compact<W, TS, true>), nbig, COMPACT_THREADS, s, bp);
+            HIPCK(hipStreamSynchronize(s));
+        }
+        uint32_t e = 0; CK(read_u32(c->derr.p, &e));
+        if (e == 3 && attempt == 0) continue;                // piece arrays too small: retry with the exact bound
+        if (nbig) c->st.n_big_partitions += nbig;
+        break;
+    }
+    CK(t.stop(&c->st.ms_compact));
+    CK(check_device_error(c, "compact"));
+    uint64_t cur[2]; CK(read_u64(c->cursors.p, cur, 2));
+    c->n_pieces = cur[0]; c->n_piece_bases = cur[1];
+    uint64_t ks[3]; CK(read_u64(c->dstats.p, ks, 3));
+    c->st.n_pieces = c->n_pieces; c->st.n_glue_open_ends = ks[0]; c->st.n_cycles = ks[2];
+    c->st.ms_total += c->st.ms_compact;
+    c->stage = 2;
+    return CDBG_OK;
+}
+
+template <int W>
+int glue_impl(cdbg_ctx* c) {
+    if (c->stage < 2) return fail(CDBG_E_STATE, "cdbg_glue before cdbg_compact");
+    hipStream_t s = c->stream;
+    const uint64_t NP = c->n_pieces;
+    if (2 * NP >= 0xFFFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 32-bit end ids (%llu)", (unsigned long long)NP);
+    const uint32_t NS = (uint32_t)(2 * NP);
+    Timer t; CK(t.start(s));
+    DBuf<uint32_t> link, nxt_a, nxt_b, acc_a, acc_b, tail_a, tail_b, minp_a, minp_b, flag, head_uid;
+    CK(link.alloc(NS, false)); CK(nxt_a.alloc(NS, false)); CK(nxt_b.alloc(NS, false)); CK(acc_a.alloc(NS, false)); CK(acc_b.alloc(NS, false));
+    CK(tail_a.alloc(NS, false)); CK(tail_b.alloc(NS, false)); CK(minp_a.alloc(NS, false)); CK(minp_b.alloc(NS, false));
+    CK(flag.alloc(4, true)); CK(head_uid.alloc(NS, false));
+    HIPCK(hipMemsetAsync(link.p, 0xFF, (size_t)std::max<uint32_t>(NS, 1) * sizeof(uint32_t), s));
+    HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+    HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
+
+    GlueResolveParams gp{};
+    gp.keys = c->glue_keys.p; gp.state = c->glue_state.p; gp.a = c->glue_a.p; gp.b = c->glue_b.p; gp.conf = c->glue_conf.p;
+    gp.cap = c->glue_cap; gp.W = W; gp.link = link.p; gp.stats = c->dstats.p;
+    CDBG_LAUNCH(k_glue_resolve, (c->glue_cap + GLUE_THREADS - 1) / GLUE_THREADS, GLUE_THREADS, s, gp);
+
+    uint64_t n_cycles_cut = 0;
+    const uint32_t gridS = (NS + GLUE_THREADS - 1) / GLUE_THREADS;
+    RankParams rp{};
+    uint32_t *fa_nxt = nullptr, *fa_acc = nullptr, *fa_tail = nullptr;      // final arrays
+    if (NS) {
+        int max_rounds = 2; while ((1ull << (max_rounds - 1)) < NS) ++max_rounds;
+        for (int pass = 0; pass < 2; ++pass) {
+            rp.n_states = NS; rp.link = link.p; rp.piece_n = c->piece_n.p;
+            rp.nxt_a = nxt_a.p; rp.nxt_b = nxt_b.p; rp.acc_a = acc_a.p; rp.acc_b = acc_b.p;
+            rp.tail_a = tail_a.p; rp.tail_b = tail_b.p; rp.minp_a = minp_a.p; rp.minp_b = minp_b.p; rp.changed = flag.p;
+            CDBG_LAUNCH(k_rank_init, gridS, GLUE_THREADS, s, rp);
+            bool converged = false;
+            for (int r = 0; r < max_rounds; ++r) {
+                HIPCK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), s));
+                CDBG_LAUNCH(k_rank_jump, gridS, GLUE_THREADS, s, rp);
+                std::swap(rp.nxt_a, rp.nxt_b); std::swap(rp.acc_a, rp.acc_b); std::swap(rp.tail_a, rp.tail_b); std::swap(rp.minp_a, rp.minp_b);
+                HIPCK(hipStreamSynchronize(s));
+                uint32_t ch = 0; CK(read_u32(flag.p, &ch));
+                if (!ch) { converged = true; break; }
+            }
+            fa_nxt = rp.nxt_a; fa_acc = rp.acc_a; fa_tail = rp.tail_a;
+            if (converged) break;
+            if (pass == 1) return fail(CDBG_E_INTERNAL, "list ranking did not converge after cutting cycles");
+            // closed chains: cut each at its smallest piece, then rank again
+            HIPCK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), s));
+            CutParams cu{ NS, rp.nxt_a, rp.minp_a, link.p, flag.p };
+            CDBG_LAUNCH(k_cut_cycles, gridS, GLUE_THREADS, s, cu);
+            HIPCK(hipStreamSynchronize(s));
+            uint32_t nc = 0; CK(read_u32(flag.p, &nc)); n_cycles_cut += nc;
+        }
+    }
+    // unitig heads + emission
+    const uint64_t ucap = std::max<uint64_t>(NP, 1);
+    const uint64_t ocap = std::max<uint64_t>(c->n_piece_bases, 1);
+    CK(c->unitig_off.alloc(ucap, false)); CK(c->unitig_len.alloc(ucap, false)); CK(c->unitig_kc.alloc(ucap, false));
+    CK(c->unitig_bases.alloc(ocap, false));
+    HIPCK(hipMemsetAsync(c->cursors.p + 2, 0, 2 * sizeof(uint64_t), s));
+    if (NS) {
+        HeadParams hp{};
+        hp.n_states = NS; hp.k = c->k; hp.link = link.p; hp.acc = fa_acc; hp.tail = fa_tail; hp.head_uid = head_uid.p;
+        hp.unitig_off = c->unitig_off.p; hp.unitig_len = c->unitig_len.p; hp.unitig_kc = c->unitig_kc.p;
+        hp.unitig_cap = ucap; hp.out_cap = ocap; hp.n_unitigs = c->cursors.p + 2; hp.out_cursor = c->cursors.p + 3; hp.error = c->derr.p;
+        CDBG_LAUNCH(k_unitig_heads, gridS, GLUE_THREADS, s, hp);
+        EmitParams ep{};
+        ep.n_pieces = (uint32_t)NP; ep.k = c->k; ep.acc = fa_acc; ep.tail = fa_tail; ep.head_uid = head_uid.p;
+        ep.piece_n = c->piece_n.p; ep.piece_kc = c->piece_kc.p; ep.piece_boff = c->piece_boff.p; ep.piece_bases = c->piece_bases.p;
+        ep.unitig_off = c->unitig_off.p; ep.unitig_kc = c->unitig_kc.p; ep.out = c->unitig_bases.p;
+        CDBG_LAUNCH(k_emit, (uint32_t)((NP + GLUE_THREADS - 1) / GLUE_THREADS), GLUE_THREADS, s, ep);
+    }
+    (void)fa_nxt;
+    CK(t.stop(&c->st.ms_glue));
+    CK(check_device_error(c, "glue"));
+    uint64_t cur[2]; CK(read_u64(c->cursors.p + 2, cur, 2));
+    c->n_unitigs = cur[0]; c->unitig_total = cur[1];
+    uint64_t gs = 0; CK(read_u64(c->dstats.p, &gs));
+    c->st.n_glue_joined = gs; c->st.n_unitigs = c->n_unitigs; c->st.unitig_bases = c->unitig_total; c->st.n_cycles += n_cycles_cut;
+    c->st.ms_total += c->st.ms_glue;
+    c->stage = 3;
+    return CDBG_OK;
+}
+
+}  // namespace
+
+// =======================================================================================
+// C ABI
+// =======================================================================================
+extern "C" {
+
+const char* cdbg_last_error(void) { return g_err.c_str(); }
+
+int cdbg_create(const cdbg_params* p, cdbg_ctx** out) {
+    if (!p || !out) return fail(CDBG_E_PARAM, "null argument");
+    *out = nullptr;
+    if (p->k < 3 || p->k > 127) return fail(CDBG_E_PARAM, "kmer-size %d out of range (3..127)", p->k);
+    if ((p->k & 1) == 0) return fail(CDBG_E_PARAM, "kmer-size %d is even: only odd k is supported (a k-mer must differ from its reverse complement)", p->k);
+    if (p->abundance_min < 1) return fail(CDBG_E_PARAM, "abundance-min must be >= 1");
+    if (p->all_abundance_counts) return fail(CDBG_E_PARAM, "-all-abundance-counts is not implemented yet");
+    const int ws = p->world_size <= 0 ? 1 : p->world_size;
+    if (ws & (ws - 1)) return fail(CDBG_E_PARAM, "world_size must be a power of two");
+    if (p->rank < 0 || p->rank >= ws) return fail(CDBG_E_PARAM, "rank out of range");
+    if (p->minimizer_size > 16) return fail(CDBG_E_PARAM, "minimizer-size must be <= 16");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(CDBG_E_NODEVICE, "no HIP device available (%s): libcdbg has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (p->device_id < 0 || p->device_id >= ndev) return fail(CDBG_E_PARAM, "device_id %d out of range (%d devices)", p->device_id, ndev);
+    HIPCK(hipSetDevice(p->device_id));
+    cdbg_ctx* c = new cdbg_ctx();
+    c->prm = *p; c->prm.world_size = ws;
+    c->k = p->k; c->W = p->k <= 31 ? 1 : p->k <= 63 ? 2 : 4;
+    c->rank_bits = 0; while ((1 << c->rank_bits) < ws) ++c->rank_bits;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(CDBG_E_NODEVICE, "hipStreamCreate failed"); }
+    *out = c;
+    return CDBG_OK;
+}
+
+void cdbg_destroy(cdbg_ctx* c) {
+    if (!c) return;
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int cdbg_push_reads(cdbg_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads) {
+    if (!c || !bases || !offsets) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage != 0 || c->reads.p) return fail(CDBG_E_STATE, "reads must be pushed before the first stage");
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        if (offsets[i + 1] < offsets[i]) return fail(CDBG_E_PARAM, "offsets not monotone at read %llu", (unsigned long long)i);
+        c->host_text.insert(c->host_text.end(), bases + offsets[i], bases + offsets[i + 1]);
+        c->host_text.push_back('\n');
+    }
+    return CDBG_OK;
+}
+int cdbg_push_text(cdbg_ctx* c, const char* text, uint64_t nbytes) {
+    if (!c || (!text && nbytes)) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage != 0 || c->reads.p) return fail(CDBG_E_STATE, "reads must be pushed before the first stage");
+    c->host_text.insert(c->host_text.end(), text, text + nbytes);
+    c->host_text.push_back('\n');
+    return CDBG_OK;
+}
+int cdbg_generate_reads(cdbg_ctx* c, uint64_t first_read, uint64_t n_reads, uint64_t total_reads, uint64_t read_len, int cfg) {
+    if (!c) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage != 0 || c->reads.p || !c->host_text.empty()) return fail(CDBG_E_STATE, "reads already present");
+    if (!n_reads || !read_len || total_reads < n_reads) return fail(CDBG_E_PARAM, "bad synthetic read set");
+    const uint64_t n = n_reads * (read_len + 1);
+    const uint64_t np = ((n + 15) / 16) * 16 + 256;
+    CK(c->reads.alloc(np, false));
+    HIPCK(hipMemsetAsync(c->reads.p + n, '\n', np - n, c->stream));
+    GenParams g{ c->reads.p, first_read, n_reads, total_reads, read_len, cfg };
+    const uint64_t blocks = (n + 255) / 256;
+    if (blocks > 0x7FFFFFFFULL) return fail(CDBG_E_PARAM, "synthetic read set too large for one launch");
+    CDBG_LAUNCH(k_gen_reads, blocks, 256, c->stream, g);
+    HIPCK(hipStreamSynchronize(c->stream));
+    c->nbytes = n; c->nbytes_padded = np;
+    return CDBG_OK;
+}
+int cdbg_read_text(cdbg_ctx* c, uint64_t first_byte, uint64_t nbytes, char* out) {
+    if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    CK(upload_pending(c));
+    if (first_byte + nbytes > c->nbytes) return fail(CDBG_E_PARAM, "range beyond the resident text");
+    HIPCK(hipMemcpy(out, c->reads.p + first_byte, nbytes, hipMemcpyDeviceToHost));
+    return CDBG_OK;
+}
+
+#define DISPATCH_W(fn)                                              \
+    switch (c->W) {                                                  \
+        case 1: return fn<1>(c);                                     \
+        case 2: return fn<2>(c);                                     \
+        default: return fn<4>(c);                                    \
+    }
+int cdbg_count(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); if (c->stage != 0) return fail(CDBG_E_STATE, "cdbg_count called twice"); DISPATCH_W(count_impl) }
+int cdbg_compact(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(compact_impl) }
+int cdbg_glue(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(glue_impl) }
+int cdbg_run(cdbg_ctx* c) { CK(cdbg_count(c)); CK(cdbg_compact(c)); return cdbg_glue(c); }
+
+int cdbg_num_solid(cdbg_ctx* c, uint64_t* n) {
+    if (!c || !n) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage < 1) return fail(CDBG_E_STATE, "cdbg_num_solid before cdbg_count");
+    *n = c->st.n_solid; return CDBG_OK;
+}
+int cdbg_fetch_solid(cdbg_ctx* c, char* kmers, uint32_t* counts, uint64_t capacity, uint64_t* n_written) {
+    if (!c || !kmers || !counts || !n_written) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage < 1) return fail(CDBG_E_STATE, "cdbg_fetch_solid before cdbg_count");
+    if (capacity < c->st.n_solid) return fail(CDBG_E_PARAM, "capacity %llu < %llu solid k-mers", (unsigned long long)capacity, (unsigned long long)c->st.n_solid);
+    const uint64_t S = c->st.n_solid, E = c->n_solid_entries;
+    *n_written = 0;
+    if (!S) return CDBG_OK;
+    DBuf<uint8_t> dk; DBuf<uint32_t> dc; DBuf<uint64_t> dn;
+    CK(dk.alloc(S * (uint64_t)(c->k + 1), false)); CK(dc.alloc(S, false)); CK(dn.alloc(1, true));
+    DecodeParams dp{ c->solid_keys.p, c->solid_cnt.p, E, c->k, c->W, dk.p, dc.p, dn.p };
+    CDBG_LAUNCH(k_decode_solid, (E + 255) / 256, 256, c->stream, dp);
+    HIPCK(hipStreamSynchronize(c->stream));
+    uint64_t nw = 0; CK(read_u64(dn.p, &nw));
+    if (nw != S) return fail(CDBG_E_INTERNAL, "solid k-mer bookkeeping mismatch: %llu decoded vs %llu counted", (unsigned long long)nw, (unsigned long long)S);
+    HIPCK(hipMemcpy(kmers, dk.p, S * (uint64_t)(c->k + 1), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(counts, dc.p, S * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *n_written = S;
+    return CDBG_OK;
+}
+int cdbg_num_unitigs(cdbg_ctx* c, uint64_t* n, uint64_t* total_bases) {
+    if (!c || !n) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_num_unitigs before cdbg_glue");
+    *n = c->n_unitigs; if (total_bases) *total_bases = c->unitig_total; return CDBG_OK;
+}
+int cdbg_fetch_unitigs(cdbg_ctx* c, uint64_t first, uint64_t n, char* seq_buf, uint64_t* seq_off, uint64_t* kc) {
+    if (!c || !seq_buf || !seq_off || !kc) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_fetch_unitigs before cdbg_glue");
+    if (first + n > c->n_unitigs) return fail(CDBG_E_PARAM, "unitig range out of bounds");
+    if (!n) { seq_off[0] = 0; return CDBG_OK; }
+    std::vector<uint64_t> off(n); std::vector<uint32_t> len(n);
+    HIPCK(hipMemcpy(off.data(), c->unitig_off.p + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(len.data(), c->unitig_len.p + first, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(kc, c->unitig_kc.p + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    // unitigs are laid out in allocation order, not id order: copy the whole arena once when
+    // the request covers everything, otherwise one copy per unitig
+    uint64_t w = 0;
+    if (first == 0 && n == c->n_unitigs) {
+        std::vector<char> arena(c->unitig_total);
+        HIPCK(hipMemcpy(arena.data(), c->unitig_bases.p, c->unitig_total, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i) { seq_off[i] = w; memcpy(seq_buf + w, arena.data() + off[i], len[i]); w += len[i]; }
+    } else {
+        for (uint64_t i = 0; i < n; ++i) { seq_off[i] = w; HIPCK(hipMemcpy(seq_buf + w, c->unitig_bases.p + off[i], len[i], hipMemcpyDeviceToHost)); w += len[i]; }
+    }
+    seq_off[n] = w;
+    return CDBG_OK;
+}
+int cdbg_stats(cdbg_ctx* c, cdbg_stats_t* out) {
+    if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    *out = c->st; return CDBG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// devrt.h -- the one place that knows whether we compile for the GPU (hipcc, gfx950)
+// or for the kernel-logic simulator used by the CPU test-suite (tests/hostsim).
+//
+// PRODUCT BUILD: hipcc --offload-arch=gfx950.  There is no CPU fallback in the
+// product: libcdbg.so refuses to create a context without a HIP device.
+//
+// CDBG_HOSTSIM build: compiled by tests/hostsim/build.sh with g++.  Every kernel
+// body is the same source; threads of a workgroup run as cooperative fibers
+// (hostsim.h).  It exists so that `pytest -m "not gpu"` can exercise the real
+// kernel logic (record packing, junction rules, chain walks, glue, ranking) in a
+// container without a GPU.  It is test infrastructure and is never loaded by
+// bcalm_amd/.
+#pragma once
+#include <stdint.h>
+
+#ifdef CDBG_HOSTSIM
+#include "hostsim.h"
+#else
+#include <hip/hip_runtime.h>
+#define CDBG_HD __host__ __device__ __forceinline__
+#define CDBG_DEV __device__ __forceinline__
+#define CDBG_SPIN_YIELD() __builtin_amdgcn_s_sleep(1)
+#define CDBG_LAUNCH(kern, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, stream, __VA_ARGS__)
+#define CDBG_SHARED __shared__
+#endif
+
+namespace cdbg {
+
+// uint64_t is `unsigned long` on LP64 while the HIP atomics are declared for
+// `unsigned long long`; same width, so cast once here.
+CDBG_DEV uint64_t atomic_add_u64(uint64_t* p, uint64_t v) {
+    return (uint64_t)atomicAdd((unsigned long long*)p, (unsigned long long)v);
+}
+CDBG_DEV uint64_t atomic_cas_u64(uint64_t* p, uint64_t cmp, uint64_t v) {
+    return (uint64_t)atomicCAS((unsigned long long*)p, (unsigned long long)cmp, (unsigned long long)v);
+}
+CDBG_DEV uint64_t atomic_exch_u64(uint64_t* p, uint64_t v) {
+    return (uint64_t)atomicExch((unsigned long long*)p, (unsigned long long)v);
+}
+// L1-bypassing (agent-scope) load / volatile LDS flag read
+CDBG_DEV uint64_t ld_agent_u64(const uint64_t* p) {
+#ifdef CDBG_HOSTSIM
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+CDBG_DEV uint32_t ld_volatile_u32(const uint32_t* p) { return *(const volatile uint32_t*)p; }
+CDBG_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+CDBG_DEV uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+CDBG_DEV uint32_t atomic_cas_u32(uint32_t* p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
+CDBG_DEV uint32_t atomic_max_u32(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
+CDBG_DEV uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+
+}  // namespace cdbg

@@ -1,0 +1,266 @@
+// k_compact.h -- stage 2: per-minimizer-bucket unitig compaction in LDS.
+//
+// New MI355X design for the job of bcalm2<span>() / graph3 in gatb-core's
+// bcalm_algo (entered via
+// /root/reference/src/bcalm_1.cpp:57).  The correctness contract is the unitig
+// definition of /root/reference/bidirected-graphs-in-bcalm2/
+// bidirected-graphs-in-bcalm2.md:83-88.
+//
+// A bucket = one minimizer partition = the solid k-mers counted there: HOME k-mers
+// plus TRAVELLER copies (k-mers homed elsewhere that touch one of this bucket's
+// junctions).  By construction the bucket that owns junction J (the (k-1)-mer whose
+// minimizer hashes here) holds EVERY solid k-mer adjacent to J, so whether J is a
+// 1-in/1-out junction is decided locally by probing the LDS table (4 successors +
+// 4 back-probes), with the spec's exclusions (self-loop, hairpin, palindromic
+// junction => x == y => never merged).
+//
+//   end status   DEAD      junction not 1-1 (or excluded)           -> unitig ends here
+//                INTERNAL  1-1 and the neighbour is HOME here       -> merged in LDS
+//                OPEN      junction owned by another bucket, or the 1-1 neighbour is a
+//                          traveller                                  -> resolved by glue
+// Each piece (maximal chain of INTERNAL links) is written once, with its k-mer count,
+// summed abundance and, for OPEN ends, a glue-table insert keyed by the canonical
+// junction (k-1)-mer; the bucket that owns a 1-1 junction with a traveller on either
+// side also posts CONFIRM(J).  Glue joins the two ends of J iff J is confirmed.
+#pragma once
+#include "k_count.h"
+
+namespace cdbg {
+
+constexpr int COMPACT_THREADS = 256;
+constexpr uint32_t LNK_DEAD = 0, LNK_INTERNAL = 1, LNK_OPEN = 2;
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr uint32_t END_LEFT = 0, END_RIGHT = 1;
+
+// ---- glue table: canonical junction (k-1)-mer -> (end a, end b, confirmed) in HBM ----
+template <int W>
+struct GlueTable {
+    KTable<W> t;
+    uint32_t* a; uint32_t* b;      // piece-end id + 1 (0 = empty)
+    uint32_t* conf;                // 1 = junction confirmed 1-1 by its owning bucket
+};
+template <int W>
+CDBG_DEV void glue_post_end(const GlueTable<W>& G, const Kmer<W>& jc, uint32_t end_id) {
+    bool nw; const uint32_t s = ktable_insert<W, true>(G.t, jc, nw);
+    if (atomic_cas_u32(&G.a[s], 0u, end_id + 1u) != 0u) atomic_cas_u32(&G.b[s], 0u, end_id + 1u);
+}
+template <int W>
+CDBG_DEV void glue_post_confirm(const GlueTable<W>& G, const Kmer<W>& jc) {
+    bool nw; const uint32_t s = ktable_insert<W, true>(G.t, jc, nw);
+    atomic_or_u32(&G.conf[s], 1u);
+}
+
+struct CompactParams {
+    const uint64_t* solid_keys; const uint32_t* solid_cnt;
+    const uint64_t* seg_off; const uint32_t* seg_n;
+    const uint32_t* part_list;     // optional (big pass)
+    int k, m, log_np, rank_bits, rank;
+    // pieces
+    uint32_t* piece_n; uint64_t* piece_kc; uint64_t* piece_boff; uint8_t* piece_bases;
+    uint64_t piece_cap, bases_cap;
+    uint64_t* piece_cursor; uint64_t* bases_cursor;
+    // glue table (HBM)
+    uint64_t* glue_keys; uint32_t* glue_state; uint32_t* glue_a; uint32_t* glue_b; uint32_t* glue_conf; uint32_t glue_mask;
+    uint32_t* big_list; uint32_t* big_count; uint32_t* error;
+    uint64_t* stats;               // [0] open ends posted [1] confirms posted [2] in-bucket cycles
+    // HBM scratch (GLOBAL variant)
+    uint64_t* g_keys; uint32_t* g_state; uint32_t* g_cnt; uint32_t* g_lnk; uint32_t* g_aux; const uint64_t* big_off;
+};
+
+// orient stored label x so that `end` is on the right (we leave x through `end`)
+template <int W>
+CDBG_DEV Kmer<W> orient_out(const Kmer<W>& x, uint32_t end, int k) { return end == END_RIGHT ? x : x.rc(k); }
+
+template <int W>
+CDBG_DEV Kmer<W> canon_junction(const Kmer<W>& u_out, int k) {
+    Kmer<W> j = suffix_km1<W>(u_out, k);
+    Kmer<W> r = j.rc(k - 1);
+    return (r < j) ? r : j;
+}
+
+// successors of oriented k-mer u present in the table; returns count, last hit in (slot, enter_end)
+template <int W>
+CDBG_DEV int probe_succ(const KTable<W>& T, const Kmer<W>& u, int k, uint32_t& slot, uint32_t& enter_end) {
+    int n = 0;
+    for (uint32_t c = 0; c < 4; ++c) {
+        Kmer<W> v = u; v.push_right(k, c);
+        const Kmer<W> r = v.rc(k);
+        const bool fwd = !(r < v);                       // v is the canonical label
+        const uint32_t f = ktable_find<W>(T, fwd ? v : r);
+        if (f != NONE32) { ++n; slot = f; enter_end = fwd ? END_LEFT : END_RIGHT; }
+    }
+    return n;
+}
+
+template <int W, int TS, bool GLOBAL>
+__global__ void __launch_bounds__(COMPACT_THREADS) k_compact(CompactParams P) {
+    CDBG_SHARED uint64_t l_keys[GLOBAL ? 1 : TS * W];
+    CDBG_SHARED uint32_t l_state[(GLOBAL || W == 1) ? 1 : TS];
+    CDBG_SHARED uint32_t l_cnt[GLOBAL ? 1 : TS];
+    CDBG_SHARED uint32_t l_lnk[GLOBAL ? 1 : 2 * TS];
+    CDBG_SHARED uint32_t l_aux[GLOBAL ? 1 : 2 * TS];   // [0,cap): visited flags; [cap, 1.5cap): piece starts; [1.5cap, 2cap): entry slots
+    CDBG_SHARED uint32_t s_np, s_nb, s_stat[3];
+    CDBG_SHARED uint64_t s_pbase, s_bbase;
+
+    const int tid = threadIdx.x;
+    const int k = P.k;
+    const uint32_t p = P.part_list ? P.part_list[blockIdx.x] : blockIdx.x;
+    const uint32_t E = P.seg_n[p];
+    if (E == 0) return;
+
+    KTable<W> T; uint32_t *cnt, *lnk, *vis, *pdesc, *slots; uint32_t cap;
+    if (GLOBAL) {
+        const uint64_t o0 = P.big_off[blockIdx.x]; cap = (uint32_t)(P.big_off[blockIdx.x + 1] - o0);
+        T.keys = P.g_keys + o0 * W; T.state = P.g_state + o0; cnt = P.g_cnt + o0;
+        lnk = P.g_lnk + 2 * o0; vis = P.g_aux + 2 * o0; pdesc = vis + cap;
+    } else {
+        if (E > (uint32_t)TS / 2) {                      // does not fit LDS: defer to the big pass
+            if (tid == 0) { const uint32_t i = atomic_add_u32(P.big_count, 1u); P.big_list[i] = p; }
+            return;
+        }
+        cap = TS; T.keys = l_keys; T.state = l_state; cnt = l_cnt; lnk = l_lnk; vis = l_aux; pdesc = l_aux + TS;
+    }
+    T.mask = cap - 1;
+    slots = pdesc + cap / 2;                             // E <= cap/2 entries, <= cap/2 pieces
+    const uint32_t pg = (p << P.rank_bits) | (uint32_t)P.rank;     // global partition id of this bucket
+
+    if (tid == 0) { s_np = 0; s_nb = 0; s_stat[0] = s_stat[1] = s_stat[2] = 0; }
+    ktable_clear<W>(T, tid, COMPACT_THREADS);
+    for (uint32_t i = tid; i < cap; i += COMPACT_THREADS) vis[i] = 0;
+    __syncthreads();
+
+    // ---- load the bucket: home + traveller solid k-mers ----
+    const uint64_t so = P.seg_off[p];
+    for (uint32_t e = tid; e < E; e += COMPACT_THREADS) {
+        Kmer<W> x;
+        for (int i = 0; i < W; ++i) x.w[i] = P.solid_keys[(so + e) * W + i];
+        bool nw; const uint32_t s = ktable_insert<W, GLOBAL>(T, x, nw);
+        cnt[s] = P.solid_cnt[so + e];
+        slots[e] = s;
+    }
+    __syncthreads();
+
+    // ---- classify both ends of every entry ----
+    for (uint32_t it = tid; it < 2 * E; it += COMPACT_THREADS) {
+        const uint32_t s = slots[it >> 1], end = it & 1u, idx = s * 2 + end;
+        const bool home = !(cnt[s] & TRAV_FLAG);
+        const Kmer<W> x = ktable_key<W>(T, s);
+        const Kmer<W> u = orient_out<W>(x, end, k);
+        const Kmer<W> jc = canon_junction<W>(u, k);
+        uint32_t link = LNK_DEAD;
+        if (part_of(junction_min<W>(jc, k, P.m), P.log_np) != pg) {
+            link = LNK_OPEN;                             // junction owned elsewhere: glue decides
+        } else {
+            uint32_t y = 0, ye = 0, z = 0, ze = 0;
+            if (probe_succ<W>(T, u, k, y, ye) == 1 && y != s) {
+                const Kmer<W> uy = orient_out<W>(ktable_key<W>(T, y), ye, k);   // leave y back through the entering end
+                if (probe_succ<W>(T, uy, k, z, ze) == 1) {
+                    const bool yhome = !(cnt[y] & TRAV_FLAG);
+                    if (home && yhome) link = LNK_INTERNAL | (ye << 2) | (y << 3);
+                    else {
+                        // 1-1 junction with a traveller on at least one side: confirm it for glue (once)
+                        if (home || (!yhome && s < y)) { glue_post_confirm<W>(GlueTable<W>{ { P.glue_keys, P.glue_state, P.glue_mask }, P.glue_a, P.glue_b, P.glue_conf }, jc); atomic_add_u32(&s_stat[1], 1u); }
+                        if (home) link = LNK_OPEN;
+                    }
+                }
+            }
+        }
+        if (home) lnk[idx] = link; else lnk[idx] = LNK_DEAD;
+    }
+    __syncthreads();
+
+    // ---- walk 1: every terminal end measures its piece; the smaller terminal id registers it ----
+    for (uint32_t it = tid; it < 2 * E; it += COMPACT_THREADS) {
+        const uint32_t s = slots[it >> 1], end = it & 1u, idx = s * 2 + end;
+        if (cnt[s] & TRAV_FLAG) continue;
+        if ((lnk[idx] & 3u) == LNK_INTERNAL) continue;   // not a terminal
+        uint32_t cur = s, ex = end ^ 1u, n = 1;
+        vis[cur] = 1;
+        for (;;) {
+            const uint32_t l = lnk[cur * 2 + ex];
+            if ((l & 3u) != LNK_INTERNAL) break;
+            cur = l >> 3; ex = ((l >> 2) & 1u) ^ 1u; ++n;
+            vis[cur] = 1;
+        }
+        const uint32_t other = cur * 2 + ex;
+        if (idx <= other) {
+            const uint32_t li = atomic_add_u32(&s_np, 1u);
+            pdesc[li] = idx;                             // start terminal (bit 31 clear: linear piece)
+            atomic_add_u32(&s_nb, n + (uint32_t)k - 1u);
+        }
+    }
+    __syncthreads();
+    // ---- closed chains entirely inside the bucket (isolated cycles): cut at the smallest slot ----
+    for (uint32_t it = tid; it < E; it += COMPACT_THREADS) {
+        const uint32_t s = slots[it];
+        if ((cnt[s] & TRAV_FLAG) || vis[s]) continue;
+        uint32_t cur = s, ex = END_RIGHT, n = 0; bool is_min = true;
+        do {
+            const uint32_t l = lnk[cur * 2 + ex];
+            cur = l >> 3; ex = ((l >> 2) & 1u) ^ 1u; ++n;
+            if (cur < s) is_min = false;
+        } while (cur != s);
+        if (is_min) {
+            const uint32_t li = atomic_add_u32(&s_np, 1u);
+            pdesc[li] = (s * 2 + END_LEFT) | 0x80000000u;   // cyclic piece starting at s, walking right
+            atomic_add_u32(&s_nb, n + (uint32_t)k - 1u);
+            atomic_add_u32(&s_stat[2], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t pb = atomic_add_u64(P.piece_cursor, (uint64_t)s_np);
+        uint64_t bb = atomic_add_u64(P.bases_cursor, (uint64_t)s_nb);
+        if (pb + s_np > P.piece_cap || bb + s_nb > P.bases_cap) { *P.error = 3; s_np = 0; }
+        s_pbase = pb; s_bbase = bb; s_nb = 0;
+    }
+    __syncthreads();
+
+    // ---- walk 2: one lane per piece writes bases, size, abundance and posts its open ends ----
+    const uint32_t np = s_np;
+    const GlueTable<W> G{ { P.glue_keys, P.glue_state, P.glue_mask }, P.glue_a, P.glue_b, P.glue_conf };
+    for (uint32_t li = tid; li < np; li += COMPACT_THREADS) {
+        const uint32_t d = pdesc[li];
+        const bool cyclic = d & 0x80000000u;
+        const uint32_t start = d & 0x7FFFFFFFu;
+        const uint32_t s0 = start >> 1, e0 = start & 1u;
+        // first pass over the chain for the length (needed to place the bases)
+        uint32_t cur = s0, ex = e0 ^ 1u, n = 1;
+        for (;;) {
+            const uint32_t l = lnk[cur * 2 + ex];
+            if ((l & 3u) != LNK_INTERNAL) break;
+            const uint32_t nx = l >> 3;
+            if (cyclic && nx == s0) break;
+            cur = nx; ex = ((l >> 2) & 1u) ^ 1u; ++n;
+        }
+        const uint32_t nbases = n + (uint32_t)k - 1u;
+        const uint64_t boff = s_bbase + atomic_add_u32(&s_nb, nbases);
+        uint8_t* out = P.piece_bases + boff;
+        uint64_t kc = 0; uint32_t w = 0;
+        cur = s0; ex = e0 ^ 1u;
+        for (uint32_t t = 0; t < n; ++t) {
+            const Kmer<W> u = orient_out<W>(ktable_key<W>(T, cur), ex, k);
+            if (t == 0) { for (int i = 0; i < k; ++i) out[w++] = (uint8_t)("ACGT"[u.base(k, i)]); }
+            else out[w++] = (uint8_t)("ACGT"[u.base(k, k - 1)]);
+            kc += (uint64_t)(cnt[cur] & ~TRAV_FLAG);
+            if (t + 1 < n) { const uint32_t l = lnk[cur * 2 + ex]; cur = l >> 3; ex = ((l >> 2) & 1u) ^ 1u; }
+        }
+        const uint64_t pid = s_pbase + li;
+        P.piece_n[pid] = n; P.piece_kc[pid] = kc; P.piece_boff[pid] = boff;
+        if (!cyclic) {
+            // left end of the piece = start terminal (s0, e0); right end = (cur, ex)
+            if ((lnk[s0 * 2 + e0] & 3u) == LNK_OPEN) {
+                glue_post_end<W>(G, canon_junction<W>(orient_out<W>(ktable_key<W>(T, s0), e0, k), k), (uint32_t)(pid * 2 + 0));
+                atomic_add_u32(&s_stat[0], 1u);
+            }
+            if ((lnk[cur * 2 + ex] & 3u) == LNK_OPEN) {
+                glue_post_end<W>(G, canon_junction<W>(orient_out<W>(ktable_key<W>(T, cur), ex, k), k), (uint32_t)(pid * 2 + 1));
+                atomic_add_u32(&s_stat[0], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) for (int i = 0; i < 3; ++i) if (s_stat[i]) atomic_add_u64(&P.stats[i], (uint64_t)s_stat[i]);
+}
+
+}  // namespace cdbg

@@ -1,0 +1,154 @@
+// k_glue.h -- stage 3: glue pieces into maximal unitigs.
+//
+// New MI355X design for the job of bglue<span>() + unionFind in gatb-core's
+// bglue_algo (UF API hinted by
+// /root/reference/example/uf/testUF.cpp:9-57) and of the unitig record writer
+// (/root/reference/README.md:62-72: LN, KC, km).
+//
+// Every piece has at most one partner per end, so "gluing" is list ranking, not a
+// general union-find: (1) hash-join of open piece ends on the canonical junction
+// (k-1)-mer (the table was filled by k_compact; a junction is joined iff its owning
+// bucket confirmed it 1-in/1-out), (2) pointer jumping over traversal states
+// (state e = "enter piece e>>1 through end e&1"; succ(e) = link[e^1]) computing for
+// every state its tail and the number of k-mers from it to the tail, (3) closed
+// chains (isolated circular unitigs, /root/reference/example/circular_unitigs_unittests)
+// are cut at their smallest piece, (4) one lane per piece copies its bases to its
+// place inside the unitig, reverse-complemented when the chosen direction enters the
+// piece from the right.  KC is the sum of the pieces' abundances.
+#pragma once
+#include "k_compact.h"
+
+namespace cdbg {
+
+constexpr int GLUE_THREADS = 256;
+
+// ---- (1) sweep the glue table: confirmed junction with two ends -> mutual links ----
+struct GlueResolveParams {
+    const uint64_t* keys; const uint32_t* state; const uint32_t* a; const uint32_t* b; const uint32_t* conf;
+    uint32_t cap; int W;
+    uint32_t* link;                // [2 * n_pieces], NONE32 = no partner
+    uint64_t* stats;               // [0] junctions joined
+};
+__global__ void k_glue_resolve(GlueResolveParams P) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= P.cap) return;
+    if (!P.conf[s]) return;
+    const uint32_t a = P.a[s], b = P.b[s];
+    if (a == 0 || b == 0) return;
+    P.link[a - 1] = b - 1;
+    P.link[b - 1] = a - 1;
+    atomic_add_u64(&P.stats[0], 1ULL);
+}
+
+// ---- (2) pointer jumping ----
+struct RankParams {
+    uint32_t n_states;             // 2 * n_pieces
+    const uint32_t* link; const uint32_t* piece_n;
+    uint32_t* nxt_a; uint32_t* nxt_b;      // ping-pong successor
+    uint32_t* acc_a; uint32_t* acc_b;      // k-mers from this state to its current nxt (exclusive of nxt's own)
+    uint32_t* tail_a; uint32_t* tail_b;
+    uint32_t* minp_a; uint32_t* minp_b;    // smallest piece id seen along the jumps (cycle leader election)
+    uint32_t* changed;
+};
+__global__ void k_rank_init(RankParams P) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.n_states) return;
+    P.nxt_a[e] = P.link[e ^ 1u];
+    P.acc_a[e] = P.piece_n[e >> 1];
+    P.tail_a[e] = e;
+    P.minp_a[e] = e >> 1;
+}
+// one doubling round: (nxt, acc, tail, minp) a -> b
+__global__ void k_rank_jump(RankParams P) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.n_states) return;
+    const uint32_t nx = P.nxt_a[e];
+    uint32_t acc = P.acc_a[e], tl = P.tail_a[e], mp = P.minp_a[e], nn = nx;
+    if (nx != NONE32) {
+        acc += P.acc_a[nx]; tl = P.tail_a[nx]; nn = P.nxt_a[nx];
+        const uint32_t m2 = P.minp_a[nx]; mp = m2 < mp ? m2 : mp;
+        *P.changed = 1u;
+    }
+    P.nxt_b[e] = nn; P.acc_b[e] = acc; P.tail_b[e] = tl; P.minp_b[e] = mp;
+}
+// states still unresolved after ceil(log2(n_states))+1 rounds lie on closed chains:
+// cut the chain at the left end of its smallest piece
+struct CutParams { uint32_t n_states; const uint32_t* nxt; const uint32_t* minp; uint32_t* link; uint32_t* n_cycles; };
+__global__ void k_cut_cycles(CutParams P) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.n_states) return;
+    if (P.nxt[e] == NONE32) return;
+    if ((e & 1u) || P.minp[e] != (e >> 1)) return;        // only the leader piece's left-end state acts
+    const uint32_t partner = P.link[e];
+    P.link[e] = NONE32;
+    if (partner != NONE32) P.link[partner] = NONE32;
+    atomic_add_u32(P.n_cycles, 1u);
+}
+
+// ---- (3) unitig heads: allocate id and output space ----
+struct HeadParams {
+    uint32_t n_states; int k;
+    const uint32_t* link; const uint32_t* acc; const uint32_t* tail;
+    uint32_t* head_uid;            // per state (valid for head states)
+    uint64_t* unitig_off; uint32_t* unitig_len; uint64_t* unitig_kc;
+    uint64_t unitig_cap, out_cap;
+    uint64_t* n_unitigs; uint64_t* out_cursor; uint32_t* error;
+};
+__global__ void k_unitig_heads(HeadParams P) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.n_states) return;
+    if (P.link[e] != NONE32) return;                       // has a predecessor: not a head
+    if (!(P.tail[e] > P.tail[e ^ 1u])) return;             // the other direction of this path is the chosen one
+    const uint64_t uid = atomic_add_u64(P.n_unitigs, 1ULL);
+    const uint32_t len = P.acc[e] + (uint32_t)P.k - 1u;
+    const uint64_t off = atomic_add_u64(P.out_cursor, (uint64_t)len);
+    if (uid >= P.unitig_cap || off + len > P.out_cap) { *P.error = 4; P.head_uid[e] = NONE32; return; }
+    P.head_uid[e] = (uint32_t)uid;
+    P.unitig_off[uid] = off; P.unitig_len[uid] = len; P.unitig_kc[uid] = 0;
+}
+
+// ---- (4) emit: one lane per piece ----
+struct EmitParams {
+    uint32_t n_pieces; int k;
+    const uint32_t* acc; const uint32_t* tail; const uint32_t* head_uid;
+    const uint32_t* piece_n; const uint64_t* piece_kc; const uint64_t* piece_boff; const uint8_t* piece_bases;
+    const uint64_t* unitig_off; uint64_t* unitig_kc; uint8_t* out;
+};
+CDBG_DEV uint8_t comp_ascii(uint8_t c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; }
+__global__ void k_emit(EmitParams P) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P.n_pieces) return;
+    const uint32_t e0 = 2 * p, e1 = 2 * p + 1;
+    // direction d visits this piece in state e; its reverse visits it in e^1; chosen: larger tail
+    const uint32_t e = (P.tail[e0] > P.tail[e1]) ? e0 : e1;
+    const uint32_t head = P.tail[e ^ 1u] ^ 1u;             // head of d = mirror of the tail of the reverse direction
+    const uint32_t uid = P.head_uid[head];
+    if (uid == NONE32) return;
+    const uint32_t koff = P.acc[head] - P.acc[e];          // k-mers before this piece
+    const uint32_t n = P.piece_n[p];
+    const uint32_t nb = n + (uint32_t)P.k - 1u;
+    const uint8_t* src = P.piece_bases + P.piece_boff[p];
+    uint8_t* dst = P.out + P.unitig_off[uid] + koff;
+    const uint32_t skip = koff ? (uint32_t)P.k - 1u : 0u;  // the overlap was written by the previous piece
+    if ((e & 1u) == END_LEFT) { for (uint32_t i = skip; i < nb; ++i) dst[i] = src[i]; }
+    else { for (uint32_t i = skip; i < nb; ++i) dst[i] = comp_ascii(src[nb - 1 - i]); }
+    atomic_add_u64(&P.unitig_kc[uid], P.piece_kc[p]);
+}
+
+// ---- fetch helpers: solid k-mers as ASCII (stage-1 parity surface) ----
+struct DecodeParams { const uint64_t* keys; const uint32_t* cnt; uint64_t n; int k, W; uint8_t* out_kmers; uint32_t* out_cnt; uint64_t* n_out; };
+__global__ void k_decode_solid(DecodeParams P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const uint32_t c = P.cnt[i];
+    if (c & TRAV_FLAG) return;                             // traveller copies are not part of the k-mer set
+    const uint64_t o = atomic_add_u64(P.n_out, 1ULL);
+    for (int b = 0; b < P.k; ++b) {
+        const int pos = 2 * (P.k - 1 - b);
+        P.out_kmers[o * (uint64_t)(P.k + 1) + b] = (uint8_t)("ACGT"[(P.keys[i * P.W + (pos >> 6)] >> (pos & 63)) & 3u]);
+    }
+    P.out_kmers[o * (uint64_t)(P.k + 1) + P.k] = 0;
+    P.out_cnt[o] = c;
+}
+
+}  // namespace cdbg

@@ -1,0 +1,297 @@
+// k_scan.h -- stage 1a: reads -> minimizer-partitioned super-k-mer records.
+//
+// Replaces (new design, not a translation) the read scan / super-k-mer splitter of
+// gatb-core's DSK "fill partitions" step that GraphUnitigsTemplate<span>::create
+// drives (/root/reference/src/bcalm_1.cpp:57), and
+// folds BCALM 2's "doubled k-mer" routing of bcalm_algo (row a7) into the same pass.
+//
+// MI355X-first formulation: the whole read set is ONE byte stream in HBM in which
+// any non-ACGT byte ('\n' between reads, 'N', ...) breaks the sequence, so the scan
+// is position-parallel: one lane per junction ((k-1)-mer start), 4096 junctions per
+// workgroup tile staged once through LDS as 2-bit codes.
+//
+//   key(m-mer)  = mix32(canonical m-mer)                    (hash-ordered minimizers)
+//   g(j)        = min key over the k-m m-mers of junction j  (LDS doubling window-min)
+//   run         = maximal stretch of valid junctions with equal g
+//   record(run) = the k-mers touching the run's junctions: j_lo-1 .. j_hi.  Interior
+//                 k-mers have both junctions in the run (home here).  The first/last
+//                 k-mer has its other junction elsewhere: it is HOME in the partition
+//                 of the smaller g and a TRAVELLER (flagged copy) in the other, so each
+//                 bucket later sees every k-mer adjacent to each of its junctions
+//                 without any exchange step.
+//   partition   = part_of(g); each k-mer is counted exactly once per partition.
+//
+// Record layout (RW = 2W uint64 words, r[0] least significant):
+//   bits [0,8)  n = number of member k-mers       bit 8  member 0 is a traveller
+//   bit 9  member n-1 is a traveller               bits [16, 64*RW): bases, 2 bit each,
+//   base i at bits [64*RW-2(i+1), 64*RW-2i)  (first base on top), n+k-1 bases.
+#pragma once
+#include "kmer.h"
+
+namespace cdbg {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_TILE = 4096;                       // junctions per workgroup
+constexpr int SCAN_PKW = (SCAN_TILE + 16 + 256) / 16 + 11;   // packed words (16 bases each) incl. halo/over-read; EVEN
+static_assert(SCAN_PKW % 2 == 0, "validity halves must fill whole 32-bit words");
+constexpr int SCAN_NKEY = SCAN_TILE + 192;
+
+template <int W> struct RecFmt {
+    static constexpr int RW = 2 * W;
+    static constexpr int CAPB = 32 * RW - 8;          // bases that fit beside the 16 meta bits
+};
+
+struct ScanParams {
+    const uint8_t* reads;        // padded to a multiple of 16 with separator bytes
+    uint64_t nbytes;             // valid bytes
+    uint64_t nbytes_padded;      // allocated/initialised bytes (multiple of 16)
+    int k, m, log_np;            // global partition count = 1 << log_np
+    int rank_bits, rank;         // this GPU owns partitions p with (p & ((1<<rank_bits)-1)) == rank
+    uint32_t* part_count;        // HIST pass: records per local partition
+    uint64_t* part_cursor;       // EMIT pass: running cursors, pre-loaded with exclusive offsets
+    uint64_t* records;           // EMIT pass: RW words per record
+    uint64_t* stats;             // [0] member k-mers emitted (incl. travellers), [1] traveller members
+};
+
+CDBG_DEV uint64_t scan_get64(const uint32_t* pk, int bitoff) {
+    const int w = bitoff >> 5, sh = bitoff & 31;
+    uint64_t x = ((uint64_t)pk[w] << 32) | pk[w + 1];
+    return sh ? ((x << sh) | ((uint64_t)pk[w + 2] >> (32 - sh))) : x;
+}
+// all bases [q, q+len) valid?  vm: one bit per base, LSB-first in 32-bit words
+CDBG_DEV bool scan_all_valid(const uint32_t* vm, int q, int len) {
+    while (len > 0) {
+        const int w = q >> 5, sh = q & 31;
+        uint64_t x = ((uint64_t)vm[w + 1] << 32) | vm[w];
+        uint32_t bits = (uint32_t)(x >> sh);
+        const int c = len < 32 ? len : 32;
+        const uint32_t msk = c == 32 ? 0xFFFFFFFFu : ((1u << c) - 1u);
+        if ((bits & msk) != msk) return false;
+        q += c; len -= c;
+    }
+    return true;
+}
+
+template <int W, bool EMIT>
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
+    constexpr int RW = RecFmt<W>::RW;
+    constexpr int CAPB = RecFmt<W>::CAPB;
+    CDBG_SHARED uint32_t pk[SCAN_PKW];
+    CDBG_SHARED uint32_t vm[SCAN_PKW / 2 + 4];
+    CDBG_SHARED uint32_t ka[SCAN_NKEY];
+    CDBG_SHARED uint32_t kb[SCAN_NKEY];
+    CDBG_SHARED uint64_t brk[SCAN_TILE / 64 + 2];
+    CDBG_SHARED uint64_t stt[SCAN_TILE / 64 + 2];
+
+    const int tid = threadIdx.x;
+    const int k = P.k, m = P.m;
+    const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILE;
+    const int64_t base = t0 - 16;                     // byte offset of tile-local base index 0
+
+    // ---- 1. load 16 bytes per lane-iteration, encode to 2 bit + validity ----
+    for (int w = tid; w < SCAN_PKW; w += SCAN_THREADS) {
+        const int64_t off = base + 16 * (int64_t)w;
+        uint32_t packed = 0, vbits = 0;
+        if (off >= 0 && off < (int64_t)P.nbytes_padded) {
+            const uint4 v = *reinterpret_cast<const uint4*>(P.reads + off);
+            const uint32_t wd[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t c = (wd[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                const uint32_t ok = ((c & 0xC0u) == 0x40u) & ((0x10008Au >> (c & 0x1Fu)) & 1u);
+                packed |= base_code(c) << (30 - 2 * j);
+                vbits |= ok << j;
+            }
+        }
+        pk[w] = packed;
+        reinterpret_cast<uint16_t*>(vm)[w] = (uint16_t)vbits;
+    }
+    if (tid < 4) vm[SCAN_PKW / 2 + tid] = 0;           // over-read words of scan_all_valid
+    __syncthreads();
+
+    // ---- 2. m-mer ordering keys; index i <-> tile base index q = 15 + i ----
+    const int WN = k - m;                              // m-mers per junction
+    const int nkey = SCAN_TILE + WN + 1;
+    for (int i = tid; i < SCAN_NKEY; i += SCAN_THREADS) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (i < nkey) {
+            const int q = 15 + i;
+            if (scan_all_valid(vm, q, m)) {
+                const uint64_t x = ((uint64_t)pk[q >> 4] << 32) | pk[(q >> 4) + 1];
+                const uint32_t v = (uint32_t)((x << (2 * (q & 15))) >> (64 - 2 * m));
+                key = mmer_key(v, m);
+            }
+        }
+        ka[i] = key;
+    }
+    __syncthreads();
+
+    // ---- 3. sliding-window minimum of width WN by doubling (ping-pong in LDS) ----
+    uint32_t* cur = ka; uint32_t* oth = kb;
+    int width = 1;
+    while (2 * width <= WN) {
+        for (int i = tid; i < SCAN_NKEY; i += SCAN_THREADS) {
+            const uint32_t a = cur[i];
+            const uint32_t b = (i + width < SCAN_NKEY) ? cur[i + width] : 0xFFFFFFFFu;
+            oth[i] = a < b ? a : b;
+        }
+        __syncthreads();
+        uint32_t* t = cur; cur = oth; oth = t;
+        width *= 2;
+    }
+    if (width != WN) {
+        const int d = WN - width;
+        for (int i = tid; i < SCAN_NKEY; i += SCAN_THREADS) {
+            const uint32_t a = cur[i];
+            const uint32_t b = (i + d < SCAN_NKEY) ? cur[i + d] : 0xFFFFFFFFu;
+            oth[i] = a < b ? a : b;
+        }
+        __syncthreads();
+        uint32_t* t = cur; cur = oth; oth = t;
+    }
+    const uint32_t* g = cur;                           // g[jq], jq in [0, TILE+1]; junction jq <-> q = 15 + jq
+
+    // ---- 4. run structure: brk bit (jq-1) = junction jq does NOT continue the previous run ----
+    for (int it = 0; it < SCAN_TILE / SCAN_THREADS; ++it) {
+        const int jq = 1 + it * SCAN_THREADS + tid;
+        const int q = 15 + jq;
+        const bool v = scan_all_valid(vm, q, k - 1);
+        const bool cont = v && jq != 1 && scan_all_valid(vm, q - 1, k - 1) && g[jq] == g[jq - 1];
+        const unsigned long long bm = __ballot(!cont);
+        const unsigned long long sm = __ballot(v && !cont);
+        if ((tid & 63) == 0) { brk[(jq - 1) >> 6] = bm; stt[(jq - 1) >> 6] = sm; }
+    }
+    if (tid == 0) { brk[SCAN_TILE / 64] = ~0ULL; brk[SCAN_TILE / 64 + 1] = ~0ULL; }
+    __syncthreads();
+
+    // ---- 5. one lane per run start: find the run end, apply the boundary rules, emit ----
+    const int NMAX = CAPB - k + 1;                     // member k-mers per record
+    const uint32_t rank_mask = (1u << P.rank_bits) - 1u;
+    uint64_t n_members = 0, n_trav = 0;
+    for (int it = 0; it < SCAN_TILE / SCAN_THREADS; ++it) {
+        const int jq = 1 + it * SCAN_THREADS + tid;
+        const int bit = jq - 1;
+        if (!((stt[bit >> 6] >> (bit & 63)) & 1ULL)) continue;
+        const uint32_t gq = g[jq];
+        const uint32_t part = part_of(gq, P.log_np);
+        if ((part & rank_mask) != (uint32_t)P.rank) continue;
+        const uint32_t lpart = part >> P.rank_bits;
+        // run end: next break bit after `bit`
+        int e;
+        {
+            int nb = bit + 1;
+            unsigned long long wv = brk[nb >> 6] >> (nb & 63);
+            if (wv) e = nb + __ffsll((long long)wv) - 1;
+            else {
+                int wi = (nb >> 6) + 1;
+                while (brk[wi] == 0) ++wi;
+                e = wi * 64 + __ffsll((long long)brk[wi]) - 1;
+            }
+            // e = bit index of the next break => last junction of the run is jq index e (bit e-1)
+            if (e > SCAN_TILE) e = SCAN_TILE;
+        }
+        const int s = jq;                              // run = junctions [s, e]
+        // boundary members
+        bool first_incl = false, first_trav = false, last_incl = false, last_trav = false;
+        if (scan_all_valid(vm, 15 + s - 1, k)) {       // k-mer s-1 (its right junction is s)
+            const uint32_t g2 = g[s - 1];
+            if (gq < g2) first_incl = true;
+            else if (part_of(g2, P.log_np) != part) { first_incl = true; first_trav = true; }
+        }
+        if (scan_all_valid(vm, 15 + e, k)) {           // k-mer e (its left junction is e)
+            const uint32_t g2 = g[e + 1];
+            if (gq < g2) last_incl = true;
+            else if (part_of(g2, P.log_np) != part) { last_incl = true; last_trav = true; }
+            else if (gq == g2) last_incl = true;       // artificial split (tile edge): keep it here
+        }
+        // chunk the run into records of at most NMAX members
+        int c = s; bool firstchunk = true;
+        while (c <= e) {
+            const int ms = (firstchunk && first_incl) ? c - 1 : c;
+            int ce = ms + NMAX - 1; if (ce > e) ce = e;
+            const int me = (ce == e && !last_incl) ? e - 1 : ce;
+            const int n = me - ms + 1;
+            if (n > 0) {
+                uint32_t meta = (uint32_t)n;
+                const bool ft = firstchunk && first_incl && first_trav;
+                const bool lt = (ce == e) && last_incl && last_trav;
+                if (ft) meta |= 0x100u;
+                if (lt) meta |= 0x200u;
+                if (EMIT) {
+                    const uint64_t slot = atomic_add_u64(&P.part_cursor[lpart], 1ULL);
+                    uint64_t* dst = P.records + slot * RW;
+                    const int bitoff = 2 * (15 + ms);
+#pragma unroll
+                    for (int wv = 0; wv < RW; ++wv) {
+                        uint64_t x = scan_get64(pk, bitoff + 64 * wv);
+                        if (wv == RW - 1) x = (x & ~0xFFFFULL) | meta;
+                        dst[RW - 1 - wv] = x;
+                    }
+                } else {
+                    atomic_add_u32(&P.part_count[lpart], 1u);
+                }
+                n_members += (uint64_t)n;
+                n_trav += (ft ? 1 : 0) + (lt ? 1 : 0);
+            }
+            firstchunk = false;
+            c = ce + 1;
+        }
+    }
+    if (!EMIT && n_members) {
+        atomic_add_u64(&P.stats[0], n_members);
+        if (n_trav) atomic_add_u64(&P.stats[1], n_trav);
+    }
+}
+
+// ---- exclusive prefix sum of n uint32 counts into n+1 uint64 offsets (single workgroup) ----
+constexpr int EXSCAN_THREADS = 1024;
+__global__ void __launch_bounds__(EXSCAN_THREADS) k_exscan(const uint32_t* cnt, uint64_t* off, uint64_t n) {
+    CDBG_SHARED uint64_t part[EXSCAN_THREADS];
+    const uint64_t tid = threadIdx.x;
+    const uint64_t chunk = (n + EXSCAN_THREADS - 1) / EXSCAN_THREADS;
+    const uint64_t lo = tid * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    uint64_t s = 0;
+    for (uint64_t i = lo; i < hi; ++i) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t acc = 0;
+        for (int i = 0; i < EXSCAN_THREADS; ++i) { const uint64_t v = part[i]; part[i] = acc; acc += v; }
+        off[n] = acc;
+    }
+    __syncthreads();
+    uint64_t acc = part[tid];
+    for (uint64_t i = lo; i < hi; ++i) { off[i] = acc; acc += cnt[i]; }
+}
+__global__ void k_copy_u64(const uint64_t* src, uint64_t* dst, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// ---- counter-based synthetic reads, resident in HBM ----
+// identical bit-for-bit to oracle/cdbg_oracle.c:orc_synth_reads
+struct GenParams {
+    uint8_t* out; uint64_t first_read, n_reads, total_reads, read_len; int cfg;
+};
+__global__ void k_gen_reads(GenParams P) {
+    const uint64_t L1 = P.read_len + 1;
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P.n_reads * L1) return;
+    const uint64_t i = idx / L1, j = idx % L1;
+    if (j == P.read_len) { P.out[idx] = '\n'; return; }
+    const uint64_t SEED_G = 0xBCA10000ULL + (uint64_t)P.cfg, SEED_R = 0xBCA11000ULL + (uint64_t)P.cfg,
+                   SEED_E = 0xBCA12000ULL + (uint64_t)P.cfg;
+    uint64_t G = (P.total_reads * P.read_len + 29) / 30;
+    if (G < P.read_len) G = P.read_len;
+    const uint64_t r = P.first_read + i;
+    const uint64_t start = mix64(SEED_R + 2 * r) % (G - P.read_len + 1);
+    const int strand = (int)(mix64(SEED_R + 2 * r + 1) & 1ULL);
+    const uint64_t gp = strand ? start + P.read_len - 1 - j : start + j;
+    uint32_t b = (uint32_t)(mix64(SEED_G + gp) >> 62);
+    if (strand) b = 3u - b;
+    const uint64_t x = mix64(SEED_E + r * P.read_len + j);
+    if (x % 10000 < 100) b = (b + 1 + (uint32_t)((x >> 32) % 3)) & 3u;
+    P.out[idx] = (uint8_t)("ACGT"[b]);
+}
+
+}  // namespace cdbg

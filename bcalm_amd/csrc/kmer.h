@@ -1,0 +1,173 @@
+// kmer.h -- multi-word 2-bit k-mers for host and device code.
+//
+// Plays the role of gatb-core's Integer / LargeInt<N> selected by Integer::apply
+// (/root/reference/src/bcalm_1.cpp:95, KSIZE_LIST in /root/reference/README.md:91-99):
+// W 64-bit words hold a k-mer of up to 32*W-1 bases; W = 1, 2, 4 cover the
+// BASELINE configs k = 31, 55, 127.  New code, MI355X-first: plain structs of
+// uint64_t that live in VGPRs, no virtual dispatch, everything __forceinline__.
+//
+// Encoding: A=0 C=1 G=2 T=3 (numeric order == lexicographic order, the canonical
+// convention of /root/reference/scripts/unitigEvaluator.cpp:64-66,70-82), first
+// base in the MOST significant position, w[0] = least significant word.
+#pragma once
+#include <stdint.h>
+
+#include "devrt.h"
+
+namespace cdbg {
+
+// ASCII -> 2-bit code for ACGTacgt; validity must be checked separately.
+CDBG_HD uint32_t base_code(uint32_t c) { return ((c >> 1) ^ (c >> 2)) & 3u; }
+CDBG_HD bool base_valid(uint32_t c) {
+    c &= 0xDFu;                                   // fold case
+    return c == 'A' || c == 'C' || c == 'G' || c == 'T';
+}
+
+// reverse the order of the 32 2-bit groups of x (no complement)
+CDBG_HD uint64_t rev2(uint64_t x) {
+    x = __builtin_bswap64(x);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    return x;
+}
+CDBG_HD uint32_t rev2_32(uint32_t x) {
+    x = __builtin_bswap32(x);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    return x;
+}
+
+// 32-bit bijective mixer (lowbias32): orders m-mers for minimizer selection.
+CDBG_HD uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+CDBG_HD uint64_t mix64(uint64_t x) {          // splitmix64 finaliser (with increment)
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+template <int W>
+struct Kmer {
+    uint64_t w[W];
+
+    CDBG_HD static Kmer zero() { Kmer r; for (int i = 0; i < W; ++i) r.w[i] = 0; return r; }
+    CDBG_HD static Kmer ones() { Kmer r; for (int i = 0; i < W; ++i) r.w[i] = ~0ULL; return r; }
+
+    CDBG_HD bool operator==(const Kmer& o) const {
+        bool e = true;
+        for (int i = 0; i < W; ++i) e &= (w[i] == o.w[i]);
+        return e;
+    }
+    CDBG_HD bool operator!=(const Kmer& o) const { return !(*this == o); }
+    CDBG_HD bool operator<(const Kmer& o) const {
+        for (int i = W - 1; i > 0; --i) {
+            if (w[i] != o.w[i]) return w[i] < o.w[i];
+        }
+        return w[0] < o.w[0];
+    }
+
+    // keep the low 2*k bits
+    CDBG_HD void mask(int k) {
+        const int bits = 2 * k;
+        for (int i = 0; i < W; ++i) {
+            const int lo = 64 * i;
+            if (bits >= lo + 64) continue;
+            if (bits <= lo) w[i] = 0;
+            else w[i] &= (~0ULL) >> (64 - (bits - lo));
+        }
+    }
+    // logical shifts of the whole W-word integer by s bits, 0 <= s < 64*W
+    CDBG_HD Kmer shr(int s) const {
+        Kmer r;
+        const int ws = s >> 6, bs = s & 63;
+        for (int i = 0; i < W; ++i) {
+            uint64_t lo = (i + ws < W) ? w[i + ws] : 0;
+            uint64_t hi = (i + ws + 1 < W) ? w[i + ws + 1] : 0;
+            r.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+        }
+        return r;
+    }
+    CDBG_HD Kmer shl(int s) const {
+        Kmer r;
+        const int ws = s >> 6, bs = s & 63;
+        for (int i = W - 1; i >= 0; --i) {
+            uint64_t hi = (i - ws >= 0) ? w[i - ws] : 0;
+            uint64_t lo = (i - ws - 1 >= 0) ? w[i - ws - 1] : 0;
+            r.w[i] = bs ? ((hi << bs) | (lo >> (64 - bs))) : hi;
+        }
+        return r;
+    }
+    // append base c on the right (drop the leftmost base of a k-mer)
+    CDBG_HD void push_right(int k, uint32_t c) {
+        for (int i = W - 1; i > 0; --i) w[i] = (w[i] << 2) | (w[i - 1] >> 62);
+        w[0] = (w[0] << 2) | (uint64_t)c;
+        mask(k);
+    }
+    // prepend base c on the left (drop the rightmost base)
+    CDBG_HD void push_left(int k, uint32_t c) {
+        for (int i = 0; i < W - 1; ++i) w[i] = (w[i] >> 2) | (w[i + 1] << 62);
+        w[W - 1] >>= 2;
+        const int pos = 2 * (k - 1);
+        w[pos >> 6] |= (uint64_t)c << (pos & 63);
+    }
+    // i-th base counted from the left end of a k-mer
+    CDBG_HD uint32_t base(int k, int i) const {
+        const int pos = 2 * (k - 1 - i);
+        return (uint32_t)(w[pos >> 6] >> (pos & 63)) & 3u;
+    }
+    // reverse complement of a k-mer
+    CDBG_HD Kmer rc(int k) const {
+        Kmer r;
+        for (int i = 0; i < W; ++i) r.w[i] = ~rev2(w[W - 1 - i]);
+        r = r.shr(64 * W - 2 * k);
+        return r;                               // high bits are already zero after the shift
+    }
+    CDBG_HD Kmer canonical(int k) const {
+        Kmer r = rc(k);
+        return (r < *this) ? r : *this;
+    }
+    CDBG_HD uint32_t hash() const {
+        uint64_t h = 0;
+        for (int i = 0; i < W; ++i) h = mix64(h ^ w[i]);
+        return (uint32_t)(h >> 17);
+    }
+};
+
+// (k-1)-mer on the right / left side of a k-mer (as a number with the same layout)
+template <int W>
+CDBG_HD Kmer<W> suffix_km1(const Kmer<W>& x, int k) { Kmer<W> r = x; r.mask(k - 1); return r; }
+template <int W>
+CDBG_HD Kmer<W> prefix_km1(const Kmer<W>& x, int /*k*/) { return x.shr(2); }
+
+// m-mer (m <= 16) starting at base i of a sequence of `len` bases held in a Kmer-like integer
+template <int W>
+CDBG_HD uint32_t mmer_at(const Kmer<W>& x, int len, int i, int m) {
+    const int pos = 2 * (len - m - i);
+    uint64_t v = x.w[pos >> 6] >> (pos & 63);
+    if ((pos & 63) + 2 * m > 64 && (pos >> 6) + 1 < W) v |= x.w[(pos >> 6) + 1] << (64 - (pos & 63));
+    return (uint32_t)(v & ((m == 16) ? 0xFFFFFFFFULL : ((1ULL << (2 * m)) - 1)));
+}
+// ordering key of an m-mer: bijective hash of its canonical form
+CDBG_HD uint32_t mmer_key(uint32_t v, int m) {
+    uint32_t r = (~rev2_32(v)) >> (32 - 2 * m);
+    return mix32(r < v ? r : v);
+}
+// minimizer key of the (k-1)-mer `j` (given as an integer of k-1 bases)
+template <int W>
+CDBG_HD uint32_t junction_min(const Kmer<W>& j, int k, int m) {
+    uint32_t g = 0xFFFFFFFFu;
+    for (int i = 0; i + m <= k - 1; ++i) {
+        uint32_t key = mmer_key(mmer_at<W>(j, k - 1, i, m), m);
+        g = key < g ? key : g;
+    }
+    return g;
+}
+// partition of a minimizer key; log_np == 0 -> single partition
+CDBG_HD uint32_t part_of(uint32_t g, int log_np) {
+    return log_np ? (uint32_t)((g * 0x9E3779B1u) >> (32 - log_np)) : 0u;
+}
+
+}  // namespace cdbg

@@ -1,0 +1,108 @@
+/* cdbg.h -- C ABI of libcdbg.so: MI355X-native compacted de Bruijn graph construction.
+ *
+ * DROP-IN BOUNDARY.  The reference has no FFI: its whole hot path is ONE statically
+ * linked C++ call,
+ *     GraphUnitigsTemplate<span>::create(IProperties*, false)
+ *         /root/reference/src/bcalm_1.cpp:57   (span chosen by Integer::apply, :95)
+ * fed by the option parser borrowed at /root/reference/src/bcalm_1.cpp:31 and the three
+ * properties the wrapper itself reads: STR_URI_INPUT (:55), STR_URI_OUTPUT (:69-72),
+ * STR_KMER_SIZE (:92).  This header is what a binding for that call site binds instead
+ * (INTEGRATION.md shows the replacement of bcalm_1.cpp's Functor body and the ctypes
+ * stub).  Plain C types only, opaque context, caller-owned host buffers, no C++
+ * exception crosses the boundary (the reference maps gatb Exceptions to a message +
+ * exit 1 at /root/reference/src/main.cpp:39-48; here: negative return code +
+ * cdbg_last_error()).
+ *
+ * Stage entry points mirror what create() runs internally:
+ *   cdbg_count    a4-a6  read scan -> minimizer partitions -> solid (k-mer, count)
+ *   cdbg_compact  a7-a8  per-bucket compaction in LDS -> pieces + glue records
+ *   cdbg_glue     a9     hash-join on junction (k-1)-mers + list ranking -> unitigs
+ * All functions return 0 on success and a negative code on error.
+ */
+#ifndef CDBG_H
+#define CDBG_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cdbg_ctx cdbg_ctx;
+
+typedef struct cdbg_params {
+    int k;                    /* -kmer-size (README.md:17-19); odd, 3..127 */
+    int abundance_min;        /* -abundance-min (README.md:21-25): keep k-mers seen >= this many times */
+    int minimizer_size;       /* -minimizer-size (example/circular_unitigs_unittests/CMD:4); 0 = auto */
+    int log2_partitions;      /* minimizer partitions = 1 << this; -1 = auto from the input volume */
+    int device_id;            /* HIP device ordinal */
+    int world_size;           /* GPUs sharing the minimizer space (power of two); 1 = single GPU */
+    int rank;                 /* this context owns partitions p with p % world_size == rank */
+    int all_abundance_counts; /* reserved for -all-abundance-counts (README.md:74-80); must be 0 */
+} cdbg_params;
+
+typedef struct cdbg_stats_t {
+    uint64_t input_bytes;         /* bytes scanned (bases + separators) */
+    uint64_t n_records;           /* super-k-mer records written */
+    uint64_t n_member_kmers;      /* k-mer occurrences stored in records (home + traveller copies) */
+    uint64_t n_occurrences;       /* k-mer occurrences (home only) */
+    uint64_t n_distinct;          /* distinct canonical k-mers (the metric's numerator) */
+    uint64_t n_solid;             /* solid k-mers (count >= abundance_min) */
+    uint64_t n_solid_travellers;  /* solid traveller copies held next to foreign junctions */
+    uint64_t n_pieces;            /* compacted pieces before glue */
+    uint64_t n_glue_open_ends;    /* open piece ends posted to the glue table */
+    uint64_t n_glue_joined;       /* junctions joined by glue */
+    uint64_t n_unitigs;
+    uint64_t unitig_bases;
+    uint64_t n_big_partitions;    /* partitions that fell back to HBM tables (count + compact) */
+    uint64_t n_cycles;            /* circular unitigs cut open (in-bucket + across buckets) */
+    int minimizer_size, log2_partitions, kmer_words;
+    float ms_scan_hist, ms_scan_emit, ms_count, ms_compact, ms_glue, ms_total;
+    uint64_t n_launch_scan, n_launch_count, n_launch_compact;   /* workgroups launched */
+} cdbg_stats_t;
+
+/* error codes */
+#define CDBG_OK 0
+#define CDBG_E_PARAM (-1)     /* bad parameter (even k, k out of range, ...) */
+#define CDBG_E_NODEVICE (-2)  /* no HIP device / HIP call failed: there is NO CPU fallback */
+#define CDBG_E_NOMEM (-3)
+#define CDBG_E_STATE (-4)     /* stages called out of order */
+#define CDBG_E_INTERNAL (-5)
+
+int  cdbg_create(const cdbg_params* params, cdbg_ctx** out);
+void cdbg_destroy(cdbg_ctx* ctx);
+const char* cdbg_last_error(void);
+
+/* Input.  Host ASCII, caller-owned, borrowed for the call; may be called repeatedly.
+ * push_reads: read i is bases[offsets[i] .. offsets[i+1]).  push_text: sequences already
+ * separated by any byte outside ACGTacgt ('\n', 'N', ...; such bytes break k-mers, like
+ * /root/reference/scripts/unitigEvaluator.cpp:130-131). */
+int cdbg_push_reads(cdbg_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_reads);
+int cdbg_push_text(cdbg_ctx* ctx, const char* text, uint64_t nbytes);
+/* Synthetic reads generated directly in HBM (BASELINE.md section 2 generator): reads
+ * [first_read, first_read + n_reads) of a set of total_reads reads of read_len bases. */
+int cdbg_generate_reads(cdbg_ctx* ctx, uint64_t first_read, uint64_t n_reads, uint64_t total_reads,
+                        uint64_t read_len, int cfg);
+/* copy (part of) the resident read text back to the host (tests, FASTA dumps) */
+int cdbg_read_text(cdbg_ctx* ctx, uint64_t first_byte, uint64_t nbytes, char* out);
+
+/* The three hot stages, in order.  cdbg_run = count + compact + glue. */
+int cdbg_count(cdbg_ctx* ctx);
+int cdbg_compact(cdbg_ctx* ctx);
+int cdbg_glue(cdbg_ctx* ctx);
+int cdbg_run(cdbg_ctx* ctx);
+
+/* Results.  Solid k-mers: kmers has (k+1)-byte stride, NUL-terminated ASCII, canonical strand. */
+int cdbg_num_solid(cdbg_ctx* ctx, uint64_t* n);
+int cdbg_fetch_solid(cdbg_ctx* ctx, char* kmers, uint32_t* counts, uint64_t capacity, uint64_t* n_written);
+/* Unitigs [first, first+n): sequences concatenated into seq_buf (ASCII, no terminators),
+ * seq_off[n+1] offsets into seq_buf, kc[n] summed abundances (KC; LN = length,
+ * km = KC / (LN-k+1): /root/reference/README.md:62-70).  Orientation and order are
+ * unspecified, as in the reference (README.md:84-87). */
+int cdbg_num_unitigs(cdbg_ctx* ctx, uint64_t* n, uint64_t* total_bases);
+int cdbg_fetch_unitigs(cdbg_ctx* ctx, uint64_t first, uint64_t n, char* seq_buf, uint64_t* seq_off, uint64_t* kc);
+int cdbg_stats(cdbg_ctx* ctx, cdbg_stats_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDBG_H */

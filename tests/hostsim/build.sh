@@ -1,0 +1,11 @@
+#!/bin/bash
+# Builds the kernel-logic simulator (TEST INFRASTRUCTURE, see bcalm_amd/csrc/hostsim.h):
+# the same source as libcdbg.so, compiled with g++ and -DCDBG_HOSTSIM so that workgroup
+# threads run as fibers on the CPU.  Never loaded by bcalm_amd/.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+mkdir -p "$HERE/_build"
+g++ -O2 -g -std=c++17 -Wall -Wno-unused-function -Wno-unknown-pragmas -Wno-unused-variable -DCDBG_HOSTSIM -shared -fPIC \
+    -I"$ROOT/include" "$ROOT/bcalm_amd/csrc/cdbg_impl.cpp" -o "$HERE/_build/libcdbg_hostsim.so"
+echo "built $HERE/_build/libcdbg_hostsim.so"

@@ -1,0 +1,17 @@
+"""Binds the kernel-logic simulator (tests/hostsim/_build/libcdbg_hostsim.so).
+TEST INFRASTRUCTURE: same C ABI, same kernel source, workgroup threads as CPU fibers."""
+import os
+import subprocess
+
+from bcalm_amd import api
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "hostsim", "_build", "libcdbg_hostsim.so")
+SRC = os.path.join(os.path.dirname(HERE), "bcalm_amd", "csrc")
+
+
+def load():
+    newest = max(os.path.getmtime(os.path.join(SRC, f)) for f in os.listdir(SRC))
+    if not os.path.exists(SO) or os.path.getmtime(SO) < newest:
+        subprocess.check_call([os.path.join(HERE, "hostsim", "build.sh")], stdout=subprocess.DEVNULL)
+    return api.load(SO)

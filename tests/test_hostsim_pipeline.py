@@ -1,0 +1,94 @@
+"""CPU tests of the real kernel source through the SIMT simulator (tests/hostsim):
+scan -> count -> compact -> glue against the oracle, over every golden input, with the
+partition count and minimizer length swept so that every code path (travellers, open
+ends, confirms, cross-bucket cycles, big-partition fallback) is exercised."""
+import json
+import os
+import random
+import sys
+
+import pytest
+
+import hostsim_lib
+import oracle_lib
+from parity import assert_parity, run_graph
+
+ROOT = oracle_lib.ROOT
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+
+
+@pytest.fixture(scope="module")
+def sim():
+    return hostsim_lib.load()
+
+
+def _case(key):
+    name, k, amin = key.split("/")
+    return name, int(k), int(amin)
+
+
+@pytest.mark.parametrize("key", sorted(GOLD))
+@pytest.mark.parametrize("log_np,m", [(0, 0), (3, 0), (6, 5), (9, 4)])
+def test_golden_parity(oracle, sim, key, log_np, m):
+    name, k, amin = _case(key)
+    text = oracle_lib.read_input(name)
+    got = assert_parity(oracle, sim, text, k, amin, log2_partitions=log_np, minimizer_size=min(m, k - 1) if m else 0)
+    exp = GOLD[key]
+    assert oracle_lib.canonical_set(oracle, got["unitigs"], k) == [tuple(u) for u in exp["unitigs"]]
+    assert oracle_lib.solid_sha256(got["solid"]) == exp["solid"]["sha256"]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_low_complexity(oracle, sim, seed):
+    """two-letter genomes: palindromic junctions, hairpins, self-loops, cycles"""
+    rng = random.Random(4200 + seed)
+    k = rng.choice([5, 7, 9, 11, 13])
+    g = "".join(rng.choice("AT" if seed % 2 else "ACG") for _ in range(rng.randrange(60, 400)))
+    reads = []
+    for _ in range(rng.randrange(3, 30)):
+        L = rng.randrange(1, len(g)); s = rng.randrange(0, len(g) - L + 1)
+        reads.append(g[s:s + L])
+    text = "\n".join(reads) + "\n"
+    assert_parity(oracle, sim, text, k, rng.choice([1, 1, 2]), log2_partitions=rng.choice([0, 2, 5]),
+                  minimizer_size=rng.choice([2, 3, 4]))
+
+
+def test_synthetic_generator_matches_oracle(oracle, sim):
+    from bcalm_amd import api
+    g = api.Graph(31, 2, lib=sim)
+    g.generate_reads(40, 150, 3, first_read=5, total_reads=100)
+    got = g.read_text(0, 40 * 151)
+    g.close()
+    assert got == oracle.synth_reads(40, 150, 3, first=5, total=100)
+
+
+def test_synthetic_reads_parity(oracle, sim):
+    text = oracle.synth_reads(300, 150, 3).decode()
+    assert_parity(oracle, sim, text, 31, 2, log2_partitions=5)
+
+
+def test_world_size_two_partition_split(oracle, sim):
+    """minimizer space split over two ranks: each rank counts exactly its share (N>1 path, no GPU)"""
+    text = oracle_lib.read_input("rand_b")
+    k, amin = 31, 2
+    exp = oracle.run(text, k, amin, want_solid=True)
+    from bcalm_amd import api
+    solid = []
+    for rank in range(2):
+        g = api.Graph(k, amin, lib=sim, log2_partitions=4, world_size=2, rank=rank)
+        g.push_text(text); g.count(); solid += g.solid_kmers(); g.close()
+    assert sorted(solid) == exp["solid"]
+
+
+def test_errors(sim):
+    from bcalm_amd import api
+    with pytest.raises(api.CdbgError):
+        api.Graph(30, 1, lib=sim)                 # even k
+    with pytest.raises(api.CdbgError):
+        api.Graph(129, 1, lib=sim)
+    g = api.Graph(21, 1, lib=sim)
+    with pytest.raises(api.CdbgError):
+        g.count()                                 # no reads
+    with pytest.raises(api.CdbgError):
+        g.glue()                                  # out of order
+    g.close()
