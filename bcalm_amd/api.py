@@ -40,7 +40,7 @@ class Stats(C.Structure):
 
 
 EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
-           "cdbg_generate_reads", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run",
+           "cdbg_generate_reads", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
            "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats"]
 
 
@@ -59,7 +59,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_push_text.argtypes = [vp, C.c_char_p, u64]
     lib.cdbg_generate_reads.argtypes = [vp, u64, u64, u64, u64, i32]
     lib.cdbg_read_text.argtypes = [vp, u64, u64, C.c_char_p]
-    for f in ("cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run"):
+    for f in ("cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset"):
         getattr(lib, f).argtypes = [vp]
     lib.cdbg_num_solid.argtypes = [vp, C.POINTER(u64)]
     lib.cdbg_fetch_solid.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint32), u64, C.POINTER(u64)]
@@ -140,6 +140,9 @@ class Graph:
 
     def run(self):
         self._ck(self.lib.cdbg_run(self._h))
+
+    def reset(self):
+        self._ck(self.lib.cdbg_reset(self._h))
 
     # ---- results ----
     def stats(self) -> dict:

@@ -44,17 +44,22 @@ int fail(int code, const char* fmt, ...) {
 
 template <class T>
 struct DBuf {                                   // owned device array
-    T* p = nullptr; size_t n = 0;
+    T* p = nullptr; size_t n = 0, cap = 0;
+    // (re)size to `count` elements; an existing allocation that is large enough is kept,
+    // so that a context can be re-run (cdbg_reset) without touching the allocator
     int alloc(size_t count, bool zero) {
-        release();
-        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) { p = nullptr; return fail(CDBG_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+        const size_t want = std::max<size_t>(count, 1);
+        if (!p || cap < want) {
+            release();
+            hipError_t e = hipMalloc(&p, want * sizeof(T));
+            if (e != hipSuccess) { p = nullptr; return fail(CDBG_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e)); }
+            cap = want;
+        }
         n = count;
-        if (zero) { e = hipMemset(p, 0, bytes); if (e != hipSuccess) return fail(CDBG_E_NODEVICE, "hipMemset failed"); }
+        if (zero) { hipError_t e = hipMemset(p, 0, want * sizeof(T)); if (e != hipSuccess) return fail(CDBG_E_NODEVICE, "hipMemset failed"); }
         return CDBG_OK;
     }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; cap = 0; } }
     ~DBuf() { release(); }
 };
 
@@ -65,6 +70,7 @@ template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMP
 template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2; };
 template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4; };
 
+constexpr uint64_t MAX_GRID = 1u << 22;          // workgroups per launch (grid * block must stay < 2^32)
 uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 
 }  // namespace
@@ -210,7 +216,8 @@ int count_impl(cdbg_ctx* c) {
     cp.seg_off = c->seg_off.p; cp.seg_n = c->seg_n.p; cp.stats = c->dstats.p;
     cp.big_list = c->big_list.p; cp.big_count = c->big_count.p; cp.error = c->derr.p;
     CK(t.start(s));
-    CDBG_LAUNCH((k_count<W, TS, false>), NPL, COUNT_THREADS, s, cp);
+    cp.n_items = (uint32_t)NPL;
+    CDBG_LAUNCH((k_count<W, TS, false>), std::min<uint64_t>(NPL, MAX_GRID), COUNT_THREADS, s, cp);
     c->st.n_launch_count = NPL;
     uint32_t nbig = 0;
     HIPCK(hipStreamSynchronize(s));
@@ -232,6 +239,7 @@ int count_impl(cdbg_ctx* c) {
         HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
         CountParams bp = cp;
         bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_state = g_state.p; bp.g_cnt = g_cnt.p; bp.big_off = big_off.p;
+        bp.n_items = nbig;
         CDBG_LAUNCH((k_count<W, TS, true>), nbig, COUNT_THREADS, s, bp);
         c->st.n_big_partitions += nbig;
     }
@@ -284,7 +292,8 @@ int compact_impl(cdbg_ctx* c) {
         kp.glue_keys = c->glue_keys.p; kp.glue_state = c->glue_state.p; kp.glue_a = c->glue_a.p; kp.glue_b = c->glue_b.p;
         kp.glue_conf = c->glue_conf.p; kp.glue_mask = c->glue_cap - 1;
         kp.big_list = c->big_list.p; kp.big_count = c->big_count.p; kp.error = c->derr.p; kp.stats = c->dstats.p;
-        CDBG_LAUNCH((k_compact<W, TS, false>), NPL, COMPACT_THREADS, s, kp);
+        kp.n_items = (uint32_t)NPL;
+        CDBG_LAUNCH((k_compact<W, TS, false>), std::min<uint64_t>(NPL, MAX_GRID), COMPACT_THREADS, s, kp);
         c->st.n_launch_compact = NPL;
         HIPCK(hipStreamSynchronize(s));
         uint32_t nbig = 0; CK(read_u32(c->big_count.p, &nbig));
@@ -305,6 +314,7 @@ int compact_impl(cdbg_ctx* c) {
             CompactParams bp = kp;
             bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_state = g_state.p; bp.g_cnt = g_cnt.p;
             bp.g_lnk = g_lnk.p; bp.g_aux = g_aux.p; bp.big_off = big_off.p;
+            bp.n_items = nbig;
             CDBG_LAUNCH((k_compact<W, TS, true>), nbig, COMPACT_THREADS, s, bp);
             HIPCK(hipStreamSynchronize(s));
         }
@@ -473,8 +483,7 @@ int cdbg_generate_reads(cdbg_ctx* c, uint64_t first_read, uint64_t n_reads, uint
     CK(c->reads.alloc(np, false));
     HIPCK(hipMemsetAsync(c->reads.p + n, '\n', np - n, c->stream));
     GenParams g{ c->reads.p, first_read, n_reads, total_reads, read_len, cfg };
-    const uint64_t blocks = (n + 255) / 256;
-    if (blocks > 0x7FFFFFFFULL) return fail(CDBG_E_PARAM, "synthetic read set too large for one launch");
+    const uint64_t blocks = std::min<uint64_t>((n + 255) / 256, MAX_GRID);
     CDBG_LAUNCH(k_gen_reads, blocks, 256, c->stream, g);
     HIPCK(hipStreamSynchronize(c->stream));
     c->nbytes = n; c->nbytes_padded = np;
@@ -498,6 +507,12 @@ int cdbg_count(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context");
 int cdbg_compact(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(compact_impl) }
 int cdbg_glue(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(glue_impl) }
 int cdbg_run(cdbg_ctx* c) { CK(cdbg_count(c)); CK(cdbg_compact(c)); return cdbg_glue(c); }
+int cdbg_reset(cdbg_ctx* c) {
+    if (!c) return fail(CDBG_E_PARAM, "null context");
+    c->stage = 0; c->st = cdbg_stats_t{};
+    c->n_solid_entries = c->n_pieces = c->n_piece_bases = c->n_unitigs = c->unitig_total = 0;
+    return CDBG_OK;                                  // reads and every device buffer stay resident
+}
 
 int cdbg_num_solid(cdbg_ctx* c, uint64_t* n) {
     if (!c || !n) return fail(CDBG_E_PARAM, "null argument");

@@ -65,6 +65,7 @@ struct CompactParams {
     uint64_t* stats;               // [0] open ends posted [1] confirms posted [2] in-bucket cycles
     // HBM scratch (GLOBAL variant)
     uint64_t* g_keys; uint32_t* g_state; uint32_t* g_cnt; uint32_t* g_lnk; uint32_t* g_aux; const uint64_t* big_off;
+    uint32_t n_items;              // buckets (or part_list entries) to process
 };
 
 // orient stored label x so that `end` is on the right (we leave x through `end`)
@@ -93,7 +94,7 @@ CDBG_DEV int probe_succ(const KTable<W>& T, const Kmer<W>& u, int k, uint32_t& s
 }
 
 template <int W, int TS, bool GLOBAL>
-__global__ void __launch_bounds__(COMPACT_THREADS) k_compact(CompactParams P) {
+CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item) {
     CDBG_SHARED uint64_t l_keys[GLOBAL ? 1 : TS * W];
     CDBG_SHARED uint32_t l_state[(GLOBAL || W == 1) ? 1 : TS];
     CDBG_SHARED uint32_t l_cnt[GLOBAL ? 1 : TS];
@@ -104,13 +105,13 @@ __global__ void __launch_bounds__(COMPACT_THREADS) k_compact(CompactParams P) {
 
     const int tid = threadIdx.x;
     const int k = P.k;
-    const uint32_t p = P.part_list ? P.part_list[blockIdx.x] : blockIdx.x;
+    const uint32_t p = P.part_list ? P.part_list[item] : item;
     const uint32_t E = P.seg_n[p];
     if (E == 0) return;
 
     KTable<W> T; uint32_t *cnt, *lnk, *vis, *pdesc, *slots; uint32_t cap;
     if (GLOBAL) {
-        const uint64_t o0 = P.big_off[blockIdx.x]; cap = (uint32_t)(P.big_off[blockIdx.x + 1] - o0);
+        const uint64_t o0 = P.big_off[item]; cap = (uint32_t)(P.big_off[item + 1] - o0);
         T.keys = P.g_keys + o0 * W; T.state = P.g_state + o0; cnt = P.g_cnt + o0;
         lnk = P.g_lnk + 2 * o0; vis = P.g_aux + 2 * o0; pdesc = vis + cap;
     } else {
@@ -261,6 +262,14 @@ __global__ void __launch_bounds__(COMPACT_THREADS) k_compact(CompactParams P) {
     }
     __syncthreads();
     if (tid == 0) for (int i = 0; i < 3; ++i) if (s_stat[i]) atomic_add_u64(&P.stats[i], (uint64_t)s_stat[i]);
+}
+
+template <int W, int TS, bool GLOBAL>
+__global__ void __launch_bounds__(COMPACT_THREADS) k_compact(CompactParams P) {
+    for (uint32_t item = blockIdx.x; item < P.n_items; item += gridDim.x) {
+        compact_bucket<W, TS, GLOBAL>(P, item);
+        __syncthreads();                                 // LDS is reused by the next bucket
+    }
 }
 
 }  // namespace cdbg

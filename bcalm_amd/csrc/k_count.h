@@ -140,10 +140,13 @@ struct CountParams {
     uint32_t* error;               // set to 1 on output overflow
     // HBM scratch table (GLOBAL variant): slot i of the big pass uses [big_off[i], big_off[i+1]) slots
     uint64_t* g_keys; uint32_t* g_state; uint32_t* g_cnt; const uint64_t* big_off;
+    uint32_t n_items;              // partitions (or part_list entries) to process
 };
 
+// one partition, processed by the whole workgroup; `item` = index of the work item (== partition
+// unless a part_list is given)
 template <int W, int TS, bool GLOBAL>
-__global__ void __launch_bounds__(COUNT_THREADS) k_count(CountParams P) {
+CDBG_DEV void count_partition(const CountParams& P, const uint32_t item) {
     constexpr int RW = RecFmt<W>::RW;
     CDBG_SHARED uint64_t l_keys[GLOBAL ? 1 : TS * W];
     CDBG_SHARED uint32_t l_state[(GLOBAL || W == 1) ? 1 : TS];
@@ -153,12 +156,12 @@ __global__ void __launch_bounds__(COUNT_THREADS) k_count(CountParams P) {
     CDBG_SHARED uint32_t s_stat[4];
 
     const int tid = threadIdx.x;
-    const uint32_t p = P.part_list ? P.part_list[blockIdx.x] : blockIdx.x;
+    const uint32_t p = P.part_list ? P.part_list[item] : item;
     const uint64_t rec0 = P.part_off[p], rec1 = P.part_off[p + 1];
 
     KTable<W> T; uint32_t* cnt; uint32_t cap;
     if (GLOBAL) {
-        const uint64_t o0 = P.big_off[blockIdx.x]; cap = (uint32_t)(P.big_off[blockIdx.x + 1] - o0);
+        const uint64_t o0 = P.big_off[item]; cap = (uint32_t)(P.big_off[item + 1] - o0);
         T.keys = P.g_keys + o0 * W; T.state = P.g_state + o0; cnt = P.g_cnt + o0;
     } else {
         cap = TS; T.keys = l_keys; T.state = l_state; cnt = l_cnt;
@@ -238,6 +241,15 @@ __global__ void __launch_bounds__(COUNT_THREADS) k_count(CountParams P) {
         const uint64_t o = obase + atomic_add_u32(&s_wr, 1u);
         for (int i = 0; i < W; ++i) P.solid_keys[o * W + i] = T.keys[(uint64_t)s * W + i];
         P.solid_cnt[o] = c;
+    }
+}
+
+// grid-stride over partitions (HIP limits grid*block to < 2^32 work-items)
+template <int W, int TS, bool GLOBAL>
+__global__ void __launch_bounds__(COUNT_THREADS) k_count(CountParams P) {
+    for (uint32_t item = blockIdx.x; item < P.n_items; item += gridDim.x) {
+        count_partition<W, TS, GLOBAL>(P, item);
+        __syncthreads();                                 // LDS is reused by the next partition
     }
 }
 

@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     CDBG_SHARED uint32_t kb[SCAN_NKEY];
     CDBG_SHARED uint64_t brk[SCAN_TILE / 64 + 2];
     CDBG_SHARED uint64_t stt[SCAN_TILE / 64 + 2];
+    CDBG_SHARED uint32_t s_members, s_trav;
 
     const int tid = threadIdx.x;
     const int k = P.k, m = P.m;
@@ -107,6 +108,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
         reinterpret_cast<uint16_t*>(vm)[w] = (uint16_t)vbits;
     }
     if (tid < 4) vm[SCAN_PKW / 2 + tid] = 0;           // over-read words of scan_all_valid
+    if (tid == 0) { s_members = 0; s_trav = 0; }
     __syncthreads();
 
     // ---- 2. m-mer ordering keys; index i <-> tile base index q = 15 + i ----
@@ -237,9 +239,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
             c = ce + 1;
         }
     }
-    if (!EMIT && n_members) {
-        atomic_add_u64(&P.stats[0], n_members);
-        if (n_trav) atomic_add_u64(&P.stats[1], n_trav);
+    if (!EMIT) {                                        // one device atomic per workgroup, not per lane
+        if (n_members) atomic_add_u32(&s_members, (uint32_t)n_members);
+        if (n_trav) atomic_add_u32(&s_trav, (uint32_t)n_trav);
+        __syncthreads();
+        if (tid == 0 && s_members) { atomic_add_u64(&P.stats[0], (uint64_t)s_members); atomic_add_u64(&P.stats[1], (uint64_t)s_trav); }
     }
 }
 
@@ -275,10 +279,10 @@ struct GenParams {
 };
 __global__ void k_gen_reads(GenParams P) {
     const uint64_t L1 = P.read_len + 1;
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P.n_reads * L1) return;
+    const uint64_t total = P.n_reads * L1, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
     const uint64_t i = idx / L1, j = idx % L1;
-    if (j == P.read_len) { P.out[idx] = '\n'; return; }
+    if (j == P.read_len) { P.out[idx] = '\n'; continue; }
     const uint64_t SEED_G = 0xBCA10000ULL + (uint64_t)P.cfg, SEED_R = 0xBCA11000ULL + (uint64_t)P.cfg,
                    SEED_E = 0xBCA12000ULL + (uint64_t)P.cfg;
     uint64_t G = (P.total_reads * P.read_len + 29) / 30;
@@ -292,6 +296,7 @@ __global__ void k_gen_reads(GenParams P) {
     const uint64_t x = mix64(SEED_E + r * P.read_len + j);
     if (x % 10000 < 100) b = (b + 1 + (uint32_t)((x >> 32) % 3)) & 3u;
     P.out[idx] = (uint8_t)("ACGT"[b]);
+    }
 }
 
 }  // namespace cdbg

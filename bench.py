@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- reads -> unitigs throughput on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full pass of the hot path (count -> compact -> glue) over one resident
+batch of synthetic reads.  Workload at N=1: BASELINE config 3 (100 M x 150 bp synthetic
+reads, k=31, abundance-min 2), generated directly in HBM by the counter-based generator
+of BASELINE.md section 2, so inputs are resident when the timed region starts.
+
+value   = distinct canonical k-mers processed per second, whole job (all ranks).
+roofline = the dominant kernel's ALGORITHMIC bytes (SURVEY.md section 8d stage-interface
+          model, evaluated with the measured n_occ / S / P / U) / its launch duration,
+          measured with HIP events on the library's own stream (cdbg_stats ms_*), against
+          the 8 TB/s HBM3E peak.  `pipeline` inside it is the same for the whole step.
+cpu_baseline = the CPU oracle (oracle/cdbg_oracle.c, a spec restatement: kind "port",
+          one core) timed on a bounded sample of the same workload shape.  It is a
+          reported baseline, not the target.  The reference binary itself is not
+          buildable (gatb-core submodule absent).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def alg_bytes(k, st, n_reads, read_len):
+    """SURVEY.md section 8(d) stage-interface bytes, with measured counts."""
+    W = 1 if k <= 31 else 2 if k <= 63 else 4
+    Kb = 8 * W
+    sbar = (k - 10 + 2) / 2.0
+    n_occ, S, P, U = st["n_occurrences"], st["n_solid"], st["n_pieces"], st["n_unitigs"]
+    A1 = n_reads * read_len
+    A2 = 2 * n_occ * (1 + (k - 1) / sbar) / 4
+    A3 = 2 * S * (Kb + 4)
+    A4 = 2 * ((S + P * (k - 1)) / 4 + 16 * P)
+    A5 = (S + U * (k - 1)) / 4 + 16 * U
+    per_kernel = {
+        "k_scan<hist>": A1,                    # reads every ASCII base once
+        "k_scan<emit>": A1 + A2 / 2,           # reads bases again, writes the super-k-mer records
+        "k_count": A2 / 2 + A3 / 2,            # reads records, writes solid (k-mer, count)
+        "k_compact": A3 / 2 + A4 / 2,          # reads solid k-mers, writes pieces + glue records
+        "glue(k_glue_resolve+k_rank_*+k_emit)": A4 / 2 + A5,
+    }
+    return per_kernel, A1 + A2 + A3 + A4 + A5
+
+
+def cpu_baseline(k, amin, read_len, cfg, sample_reads):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    orc = oracle_lib.load()
+    text = orc.synth_reads(sample_reads, read_len, cfg)
+    t0 = time.time()
+    r = orc.run(text, k, amin)
+    dt = time.time() - t0
+    return {"value": r["stats"]["distinct"] / dt, "unit": "kmers/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_reads} x {read_len} bp synthetic reads (same generator, 30x coverage), "
+                      f"{r['stats']['distinct']} distinct k-mers in {dt:.1f} s; CPU restatement of the spec, "
+                      f"NOT BCALM2 (its gatb-core sources are absent)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("CDBG_BENCH_READS", 100_000_000)),
+                    help="reads per GPU (BASELINE config 3: 100M); smaller values are dev runs, not the metric")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--abundance-min", type=int, default=2)
+    ap.add_argument("--cfg", type=int, default=3)
+    ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import bcalm_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    lib = bcalm_amd.load()                      # raises without the HIP extension: no fallback
+    # N > 1 (round 1): every rank owns a disjoint read set of the same size and runs the full
+    # path on it (weak scaling, no data-path collective).  The minimizer-sharded single-graph
+    # mode (world_size/rank in cdbg_params + RCCL all-to-all of glue records) is not wired yet.
+    g = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank)
+    g.generate_reads(a.reads, a.read_len, a.cfg + 16 * rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        g.run()
+        g.reset()
+    sync()
+    t0 = time.perf_counter()
+    st = None
+    acc = {x: 0.0 for x in ("ms_scan_hist", "ms_scan_emit", "ms_count", "ms_compact", "ms_glue", "ms_total")}
+    for i in range(a.steps):
+        g.run()
+        st = g.stats()
+        for x in acc:
+            acc[x] += st[x]
+        if i + 1 < a.steps:
+            g.reset()
+    sync()
+    dt = time.perf_counter() - t0
+    n_distinct = st["n_distinct"]
+
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        n = torch.tensor([n_distinct], device="cuda", dtype=torch.int64)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        total_distinct = int(n.item())
+    else:
+        total_distinct = n_distinct
+
+    if rank == 0:
+        per_kernel, alg_total = alg_bytes(a.k, st, a.reads, a.read_len)
+        ms = {"k_scan<hist>": acc["ms_scan_hist"], "k_scan<emit>": acc["ms_scan_emit"], "k_count": acc["ms_count"],
+              "k_compact": acc["ms_compact"], "glue(k_glue_resolve+k_rank_*+k_emit)": acc["ms_glue"]}
+        dom = max(ms, key=lambda x: ms[x])
+        dom_ms = ms[dom] / a.steps
+        achieved = per_kernel[dom] / (dom_ms * 1e-3) / 1e9
+        gpu_ms = acc["ms_total"] / a.steps
+        out = {
+            "metric": "distinct k-mers/s reads->unitigs k=%d" % a.k,
+            "value": total_distinct * a.steps / dt,
+            "unit": "kmers/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: synthetic %d x %d bp reads per GPU, k=%d, abundance-min %d, 1%% substitutions, 30x coverage"
+                                   % (a.reads, a.read_len, a.k, a.abundance_min),
+                       "timing_boundary": "reads resident in HBM (ASCII) -> unitigs + KC resident in HBM; includes the stages' host syncs",
+                       "multi_gpu": "independent read sets per rank (no collective)" if world > 1 else "single GPU",
+                       "minimizer_size": st["minimizer_size"], "log2_partitions": st["log2_partitions"]},
+            "counts": {x: st[x] for x in ("n_occurrences", "n_distinct", "n_solid", "n_pieces", "n_unitigs", "n_records", "n_big_partitions")},
+            "stage_ms": {x: acc[x] / a.steps for x in acc},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "alg_bytes_per_launch": per_kernel[dom], "avg_launch_ms": dom_ms,
+                         "pipeline": {"alg_bytes": alg_total, "gpu_ms": gpu_ms,
+                                      "achieved": alg_total / (gpu_ms * 1e-3) / 1e9,
+                                      "frac": alg_total / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.k, a.abundance_min, a.read_len, a.cfg, a.cpu_sample_reads)
+        print(json.dumps(out), flush=True)
+    g.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

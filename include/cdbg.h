@@ -90,6 +90,9 @@ int cdbg_count(cdbg_ctx* ctx);
 int cdbg_compact(cdbg_ctx* ctx);
 int cdbg_glue(cdbg_ctx* ctx);
 int cdbg_run(cdbg_ctx* ctx);
+/* forget the results but keep the resident reads and all device buffers, so the same job can
+ * be run again (benchmark steps) without allocator traffic */
+int cdbg_reset(cdbg_ctx* ctx);
 
 /* Results.  Solid k-mers: kmers has (k+1)-byte stride, NUL-terminated ASCII, canonical strand. */
 int cdbg_num_solid(cdbg_ctx* ctx, uint64_t* n);

@@ -1,0 +1,121 @@
+"""GPU parity tests proper (-m gpu): the HIP library through its C ABI against the CPU
+oracle, bit-exact on (k-mer, count) sets and on canonical unitig sets (sequence + KC)."""
+import json
+import os
+import random
+
+import pytest
+
+import oracle_lib
+from parity import assert_parity, run_graph
+
+pytestmark = pytest.mark.gpu
+ROOT = oracle_lib.ROOT
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import bcalm_amd
+    return bcalm_amd.load()          # fails loudly when the extension is missing
+
+
+def _case(key):
+    name, k, amin = key.split("/")
+    return name, int(k), int(amin)
+
+
+@pytest.mark.parametrize("key", sorted(GOLD))
+@pytest.mark.parametrize("log_np,m", [(-1, 0), (0, 0), (6, 5), (10, 4)])
+def test_golden_parity(oracle, hip, key, log_np, m):
+    name, k, amin = _case(key)
+    text = oracle_lib.read_input(name)
+    got = assert_parity(oracle, hip, text, k, amin, log2_partitions=log_np, minimizer_size=min(m, k - 1) if m else 0)
+    assert oracle_lib.canonical_set(oracle, got["unitigs"], k) == [tuple(u) for u in GOLD[key]["unitigs"]]
+    assert oracle_lib.solid_sha256(got["solid"]) == GOLD[key]["solid"]["sha256"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_low_complexity(oracle, hip, seed):
+    rng = random.Random(9000 + seed)
+    k = rng.choice([5, 7, 9, 11, 13, 33, 65])
+    g = "".join(rng.choice("AT" if seed % 2 else "ACG") for _ in range(rng.randrange(60, 1500)))
+    reads = []
+    for _ in range(rng.randrange(3, 60)):
+        L = rng.randrange(1, len(g)); s = rng.randrange(0, len(g) - L + 1)
+        reads.append(g[s:s + L])
+    text = "\n".join(reads) + "\n"
+    assert_parity(oracle, hip, text, k, rng.choice([1, 1, 2]), log2_partitions=rng.choice([0, 2, 5, 8]),
+                  minimizer_size=rng.choice([2, 3, 4]))
+
+
+def test_generator_bit_exact(oracle, hip):
+    import bcalm_amd
+    g = bcalm_amd.Graph(31, 2, lib=hip)
+    g.generate_reads(1000, 150, 3, first_read=17, total_reads=5000)
+    got = g.read_text(0, 1000 * 151)
+    g.close()
+    assert got == oracle.synth_reads(1000, 150, 3, first=17, total=5000)
+
+
+@pytest.mark.parametrize("k,amin,n_reads,read_len,cfg", [(31, 2, 60000, 150, 3), (55, 2, 30000, 150, 4), (127, 2, 4000, 1000, 5), (21, 1, 20000, 100, 2)])
+def test_synthetic_parity(oracle, hip, k, amin, n_reads, read_len, cfg):
+    """BASELINE configs 3/4/5 shapes at sizes the oracle finishes in seconds"""
+    import bcalm_amd
+    text = oracle.synth_reads(n_reads, read_len, cfg)
+    exp = oracle.run(text, k, amin)
+    g = bcalm_amd.Graph(k, amin, lib=hip)
+    g.generate_reads(n_reads, read_len, cfg)
+    g.run()
+    st = g.stats()
+    canon = oracle_lib.canonical_set(oracle, g.unitigs(), k)
+    g.close()
+    assert st["n_distinct"] == exp["stats"]["distinct"]
+    assert st["n_solid"] == exp["stats"]["solid"]
+    assert st["n_occurrences"] == exp["stats"]["occurrences"]
+    assert canon == exp["unitigs"]
+
+
+def test_determinism(oracle, hip):
+    """same input, repeated runs and different partitionings -> identical canonical set"""
+    text = oracle.synth_reads(20000, 150, 3)
+    ref = None
+    for log_np in (-1, 8, 12, -1):
+        got = run_graph(hip, text, 31, 2, log2_partitions=log_np)
+        canon = oracle_lib.canonical_set(oracle, got["unitigs"], 31)
+        if ref is None:
+            ref = canon
+        assert canon == ref
+
+
+def test_unitig_properties_large(hip):
+    """size-independent properties at a size the oracle would not finish quickly:
+    every solid k-mer appears exactly once over all unitigs, KC sums to solid occurrences"""
+    import bcalm_amd
+    k = 31
+    g = bcalm_amd.Graph(k, 2, lib=hip)
+    g.generate_reads(400000, 150, 3)
+    g.count()
+    solid = g.solid_kmers()
+    g.compact(); g.glue()
+    ut = g.unitigs()
+    st = g.stats()
+    g.close()
+    comp = str.maketrans("ACGT", "TGCA")
+    seen = set()
+    for s, kc in ut:
+        for i in range(len(s) - k + 1):
+            x = s[i:i + k]; r = x.translate(comp)[::-1]
+            c = x if x <= r else r
+            assert c not in seen
+            seen.add(c)
+    assert len(seen) == len(solid) == st["n_solid"]
+    assert seen == {x for x, _ in solid}
+    assert sum(kc for _, kc in ut) == sum(c for _, c in solid)
+    assert sum(len(s) for s, _ in ut) == st["unitig_bases"]
+
+
+def test_no_device_fallback_symbols(hip):
+    import bcalm_amd
+    for sym in bcalm_amd.EXPORTS:
+        assert hasattr(hip, sym)
