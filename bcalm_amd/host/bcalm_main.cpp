@@ -1,0 +1,185 @@
+// bcalm -- command-line host of the MI355X-native constructor.
+//
+// Keeps the reference's CLI surface and output contract, re-stated from scratch:
+//   ./bcalm -in reads.fa -kmer-size 31 -abundance-min 2 [-out prefix] [-minimizer-size m]
+//     /root/reference/README.md:11-25 (usage), src/bcalm_1.cpp:55,61 (-in required,
+//     "Specifiy -in"), :68-74 (<prefix> = -out or basename of -in), src/main.cpp:30-37
+//     (-version / -v), :39-48 (error -> "EXCEPTION: ..." on stdout, exit code 1),
+//     README.md:45-50 (FASTA/FASTQ, gzipped or not, or a file listing input files),
+//     README.md:62-72 (>id LN:i: KC:i: km:f: header), scripts/convertToGFA.py:74,36-49 (GFA).
+// Everything between parsing and writing is three calls into libcdbg.so (include/cdbg.h):
+// this file is the replacement for bcalm_1::execute()/Functor (src/bcalm_1.cpp:49-97).
+#include <zlib.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "cdbg.h"
+
+#ifndef CDBG_VERSION
+#define CDBG_VERSION "cdbg-mi355x r1 (CLI-compatible with BCALM 2 v2.2.3)"
+#endif
+
+namespace {
+
+struct Options {
+    std::string in, out;
+    int k = 31, amin = 2, m = 0, device = 0, log_np = -1;
+    bool gfa = false, verbose = false;
+};
+
+[[noreturn]] void usage_error(const std::string& msg) { throw std::runtime_error(msg); }
+
+Options parse(int argc, char** argv) {
+    Options o;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto need = [&](const char* name) -> const char* {
+            if (i + 1 >= argc) usage_error(std::string("option ") + name + " needs a value");
+            return argv[++i];
+        };
+        if (a == "-in") o.in = need("-in");
+        else if (a == "-out") o.out = need("-out");
+        else if (a == "-kmer-size") o.k = atoi(need("-kmer-size"));
+        else if (a == "-abundance-min") o.amin = atoi(need("-abundance-min"));
+        else if (a == "-minimizer-size") o.m = atoi(need("-minimizer-size"));
+        else if (a == "-device") o.device = atoi(need("-device"));
+        else if (a == "-log2-partitions") o.log_np = atoi(need("-log2-partitions"));
+        else if (a == "-gfa") o.gfa = true;
+        else if (a == "-verbose") { o.verbose = true; if (i + 1 < argc && argv[i + 1][0] != '-') ++i; }
+        else if (a == "-nb-cores" || a == "-max-memory" || a == "-max-disk" || a == "-out-tmp" || a == "-out-dir" ||
+                 a == "-repartition-type" || a == "-minimizer-type" || a == "-histo-max" || a == "-solidity-kind")
+            need(a.c_str());                     // accepted for CLI compatibility; meaningless on the GPU path
+        else usage_error("Unknown parameter '" + a + "'");
+    }
+    return o;
+}
+
+std::string base_name(const std::string& path) {          // strip directory and the last extension
+    size_t s = path.find_last_of('/');
+    std::string b = s == std::string::npos ? path : path.substr(s + 1);
+    size_t d = b.find_last_of('.');
+    if (d != std::string::npos && d > 0) b = b.substr(0, d);
+    if (b.size() > 3 && b.substr(b.size() - 3) == ".fa") b = b.substr(0, b.size() - 3);   // reads.fa.gz -> reads
+    return b;
+}
+
+// FASTA / FASTQ, plain or gzip (zlib reads both), one call to cdbg_push_text per chunk
+void read_sequences(const std::string& path, cdbg_ctx* ctx, uint64_t& n_seq, uint64_t& n_bases) {
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) usage_error("cannot open input file " + path);
+    gzbuffer(f, 1 << 20);
+    std::vector<char> line(1 << 22);
+    std::string chunk; chunk.reserve(64 << 20);
+    int fmt = 0, fq_line = 0;                   // fmt: 0 unknown, 1 FASTA, 2 FASTQ
+    auto flush = [&]() {
+        if (chunk.empty()) return;
+        if (cdbg_push_text(ctx, chunk.data(), chunk.size()) != 0) usage_error(cdbg_last_error());
+        chunk.clear();
+    };
+    bool partial = false;                       // previous gzgets returned an unterminated piece
+    while (gzgets(f, line.data(), (int)line.size())) {
+        size_t n = strlen(line.data());
+        const bool complete = n && line[n - 1] == '\n';
+        while (n && (line[n - 1] == '\n' || line[n - 1] == '\r')) --n;
+        const bool starts_line = !partial;
+        partial = !complete;
+        if (fmt == 0 && starts_line && n) fmt = line[0] == '@' ? 2 : 1;
+        if (fmt == 2) {
+            if (starts_line) fq_line = (fq_line % 4) + 1;
+            if (fq_line == 2) { chunk.append(line.data(), n); n_bases += n; if (complete) { chunk.push_back('\n'); ++n_seq; } }
+        } else {
+            if (starts_line && n && line[0] == '>') { if (!chunk.empty() && chunk.back() != '\n') chunk.push_back('\n'); ++n_seq; }
+            else if (!(starts_line && n && line[0] == ';')) { chunk.append(line.data(), n); n_bases += n; }
+        }
+        if (chunk.size() > (48u << 20) && (chunk.back() == '\n')) flush();
+    }
+    gzclose(f);
+    if (!chunk.empty() && chunk.back() != '\n') chunk.push_back('\n');
+    flush();
+}
+
+bool looks_like_file_list(const std::string& path) {       // README.md:47-50 "ls -1 *.fastq > list_reads"
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[4096]; bool is_list = false;
+    if (gzgets(f, buf, sizeof buf)) {
+        size_t n = strlen(buf); while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) buf[--n] = 0;
+        if (n && buf[0] != '>' && buf[0] != '@' && buf[0] != ';') { gzFile g = gzopen(buf, "rb"); if (g) { is_list = true; gzclose(g); } }
+    }
+    gzclose(f);
+    return is_list;
+}
+
+void check(int rc) { if (rc != 0) throw std::runtime_error(cdbg_last_error()); }
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc > 1 && (!strcmp(argv[1], "-version") || !strcmp(argv[1], "-v"))) {
+        printf("BCALM 2 CLI, MI355X-native engine, version %s\nUsing libcdbg (HIP, gfx950) instead of gatb-core\n", CDBG_VERSION);
+        return EXIT_SUCCESS;
+    }
+    try {
+        Options o = parse(argc, argv);
+        printf("BCALM 2 CLI, MI355X-native engine, version %s\n", CDBG_VERSION);
+        if (o.in.empty()) usage_error("Specifiy -in");             // sic: the reference's message (bcalm_1.cpp:61)
+        const std::string prefix = o.out.empty() ? base_name(o.in) : o.out;
+        auto t0 = std::chrono::steady_clock::now();
+
+        cdbg_params p{}; p.k = o.k; p.abundance_min = o.amin; p.minimizer_size = o.m; p.log2_partitions = o.log_np;
+        p.device_id = o.device; p.world_size = 1; p.rank = 0;
+        cdbg_ctx* ctx = nullptr;
+        check(cdbg_create(&p, &ctx));
+        uint64_t n_seq = 0, n_bases = 0;
+        if (looks_like_file_list(o.in)) {
+            gzFile f = gzopen(o.in.c_str(), "rb"); char buf[4096];
+            while (gzgets(f, buf, sizeof buf)) { size_t n = strlen(buf); while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) buf[--n] = 0; if (n) read_sequences(buf, ctx, n_seq, n_bases); }
+            gzclose(f);
+        } else read_sequences(o.in, ctx, n_seq, n_bases);
+        auto t1 = std::chrono::steady_clock::now();
+        check(cdbg_count(ctx));
+        check(cdbg_compact(ctx));
+        check(cdbg_glue(ctx));
+        cdbg_stats_t st; check(cdbg_stats(ctx, &st));
+        uint64_t nu = 0, tb = 0; check(cdbg_num_unitigs(ctx, &nu, &tb));
+        std::vector<char> seq(tb + 1); std::vector<uint64_t> off(nu + 1), kc(nu ? nu : 1);
+        check(cdbg_fetch_unitigs(ctx, 0, nu, seq.data(), off.data(), kc.data()));
+        auto t2 = std::chrono::steady_clock::now();
+
+        const std::string fa = prefix + ".unitigs.fa";
+        FILE* out = fopen(fa.c_str(), "w");
+        if (!out) usage_error("cannot write " + fa);
+        FILE* gfa = nullptr;
+        if (o.gfa) { gfa = fopen((prefix + ".unitigs.gfa").c_str(), "w"); if (gfa) fprintf(gfa, "H\tVN:Z:1.0\tks:i:%d\n", o.k); }
+        for (uint64_t i = 0; i < nu; ++i) {
+            const uint64_t len = off[i + 1] - off[i];
+            const double km = (double)kc[i] / (double)(len - (uint64_t)o.k + 1);
+            fprintf(out, ">%llu LN:i:%llu KC:i:%llu km:f:%.1f \n", (unsigned long long)i, (unsigned long long)len, (unsigned long long)kc[i], km);
+            fwrite(seq.data() + off[i], 1, len, out); fputc('\n', out);
+            if (gfa) { fprintf(gfa, "S\t%llu\t", (unsigned long long)i); fwrite(seq.data() + off[i], 1, len, gfa);
+                       fprintf(gfa, "\tLN:i:%llu\tKC:i:%llu\tkm:f:%.1f\n", (unsigned long long)len, (unsigned long long)kc[i], km); }
+        }
+        fclose(out); if (gfa) fclose(gfa);
+        auto t3 = std::chrono::steady_clock::now();
+        auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+        printf("input: %llu sequences, %llu bases (%.2f s parse)\n", (unsigned long long)n_seq, (unsigned long long)n_bases, sec(t0, t1));
+        printf("k-mers: %llu occurrences, %llu distinct, %llu solid (abundance >= %d)\n", (unsigned long long)st.n_occurrences,
+               (unsigned long long)st.n_distinct, (unsigned long long)st.n_solid, o.amin);
+        printf("graph: %llu pieces -> %llu unitigs, %llu bases; minimizer size %d, 2^%d partitions\n", (unsigned long long)st.n_pieces,
+               (unsigned long long)st.n_unitigs, (unsigned long long)st.unitig_bases, st.minimizer_size, st.log2_partitions);
+        printf("GPU: scan %.2f+%.2f ms, count %.2f ms, compact %.2f ms, glue %.2f ms; H2D+stages+D2H %.2f s; write %.2f s\n",
+               st.ms_scan_hist, st.ms_scan_emit, st.ms_count, st.ms_compact, st.ms_glue, sec(t1, t2), sec(t2, t3));
+        printf("unitigs written to %s\n", fa.c_str());
+        cdbg_destroy(ctx);
+    } catch (const std::exception& e) {
+        printf("EXCEPTION: %s\n", e.what());
+        return EXIT_FAILURE;
+    }
+    return EXIT_SUCCESS;
+}

@@ -1,0 +1,115 @@
+"""CPU tests (no GPU): the HIP library loads and exports exactly the C ABI that
+include/cdbg.h declares, fails loudly without a device (no CPU fallback), and the
+`bcalm` host keeps the reference's CLI contract (exercised through the simulator build)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import oracle_lib
+
+ROOT = oracle_lib.ROOT
+HDR = open(os.path.join(ROOT, "include", "cdbg.h")).read()
+DECLARED = sorted(set(re.findall(r"\b(cdbg_[a-z_]+)\s*\(", HDR)))
+
+
+def _hip_lib():
+    import bcalm_amd
+    if not os.path.exists(bcalm_amd.DEFAULT_LIB):
+        import __graft_entry__ as ge
+        ge.build()
+    return bcalm_amd.load()
+
+
+def test_header_symbols_exported():
+    lib = _hip_lib()
+    import bcalm_amd
+    assert DECLARED, "no declarations parsed"
+    for sym in DECLARED:
+        assert hasattr(lib, sym), f"{sym} declared in include/cdbg.h but not exported by libcdbg.so"
+    assert sorted(bcalm_amd.EXPORTS) == DECLARED
+
+
+def test_product_has_no_cpu_fallback():
+    """without a HIP device the product refuses to run (on a GPU box it succeeds instead)"""
+    import bcalm_amd
+    lib = _hip_lib()
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = os.path.exists("/dev/kfd")
+    if has_gpu:
+        g = bcalm_amd.Graph(21, 1, lib=lib); g.close()
+    else:
+        with pytest.raises(bcalm_amd.CdbgError) as e:
+            bcalm_amd.Graph(21, 1, lib=lib)
+        assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_package_never_binds_oracle_or_simulator():
+    """product sources must not reference the checker or the simulator library"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "bcalm_amd")):
+        if "_build" in dirpath or "__pycache__" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")) and f != "hostsim.h" and f != "devrt.h":
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "liboracle" not in txt and "oracle_lib" not in txt and "libcdbg_hostsim" not in txt, f
+
+
+@pytest.fixture(scope="module")
+def cli():
+    import hostsim_lib
+    hostsim_lib.load()
+    exe = os.path.join(ROOT, "tests", "hostsim", "_build", "bcalm_hostsim")
+    assert os.path.exists(exe)
+    return exe
+
+
+def _parse_fa(path):
+    recs = []
+    lines = open(path).read().split("\n")
+    for i in range(0, len(lines) - 1, 2):
+        h = lines[i]
+        m = re.match(r">(\d+) LN:i:(\d+) KC:i:(\d+) km:f:(\d+\.\d) ", h)
+        assert m, h
+        recs.append((lines[i + 1], int(m.group(2)), int(m.group(3)), float(m.group(4))))
+    return recs
+
+
+def test_cli_contract(cli, oracle, tmp_path):
+    inp = os.path.join(ROOT, "tests", "golden", "inputs", "pufferize_refs.fa")
+    r = subprocess.run([cli, "-in", inp, "-kmer-size", "9", "-abundance-min", "1", "-minimizer-size", "5"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    fa = tmp_path / "pufferize_refs.unitigs.fa"        # <basename of -in>.unitigs.fa  (bcalm_1.cpp:68-74)
+    assert fa.exists()
+    recs = _parse_fa(fa)
+    exp = oracle.run(oracle_lib.read_input("pufferize_refs"), 9, 1)
+    assert oracle_lib.canonical_set(oracle, [(s, kc) for s, _, kc, _ in recs], 9) == exp["unitigs"]
+    for s, ln, kc, km in recs:
+        assert ln == len(s) and abs(km - round(kc / (ln - 9 + 1), 1)) < 1e-9
+    # -out prefix, gz input, FASTQ input
+    import gzip
+    fq = tmp_path / "r.fastq.gz"
+    with gzip.open(fq, "wt") as f:
+        f.write("@a\nACTGATGCAGATGACACTGATGCAGATGAC\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n@b\nATGACACTGATGCAGATGACAGTAGTGGGG\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n")
+    r = subprocess.run([cli, "-in", str(fq), "-kmer-size", "21", "-abundance-min", "1", "-out", "xyz", "-gfa"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    recs = _parse_fa(tmp_path / "xyz.unitigs.fa")
+    exp = oracle.run("ACTGATGCAGATGACACTGATGCAGATGAC\nATGACACTGATGCAGATGACAGTAGTGGGG\n", 21, 1)
+    assert oracle_lib.canonical_set(oracle, [(s, kc) for s, _, kc, _ in recs], 21) == exp["unitigs"]
+    assert (tmp_path / "xyz.unitigs.gfa").read_text().startswith("H\tVN:Z:1.0\tks:i:21\n")
+
+
+def test_cli_errors(cli, tmp_path):
+    r = subprocess.run([cli, "-kmer-size", "21"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "EXCEPTION: Specifiy -in" in r.stdout          # main.cpp:44-48, bcalm_1.cpp:61
+    r = subprocess.run([cli, "-in", "/nonexistent.fa"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "EXCEPTION:" in r.stdout
+    r = subprocess.run([cli, "-in", os.path.join(ROOT, "tests", "golden", "inputs", "tiny_read.fa"), "-kmer-size", "20"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "even" in r.stdout
+    r = subprocess.run([cli, "-v"], capture_output=True, text=True)
+    assert r.returncode == 0 and "version" in r.stdout
