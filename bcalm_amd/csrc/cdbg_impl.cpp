@@ -63,13 +63,20 @@ struct DBuf {                                   // owned device array
     ~DBuf() { release(); }
 };
 
-constexpr int TS_COUNT_1 = 4096, TS_COUNT_2 = 2048, TS_COUNT_4 = 1024;      // LDS table slots per W
+#ifndef CDBG_TSC1
+#define CDBG_TSC1 4096
+#endif
+#ifndef CDBG_NTC1
+#define CDBG_NTC1 512
+#endif
+constexpr int TS_COUNT_1 = CDBG_TSC1, TS_COUNT_2 = 2048, TS_COUNT_4 = 1024;      // LDS table slots per W
 constexpr int TS_COMPACT_1 = 1024, TS_COMPACT_2 = 1024, TS_COMPACT_4 = 512;
 template <int W> struct Cfg;
-template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1; };
-template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2; };
-template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4; };
+template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1, NTC = CDBG_NTC1; };
+template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, NTC = 512; };
+template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, NTC = 256; };
 
+constexpr uint64_t PERSISTENT_GRID = 256 * 12;     // persistent workgroups for the per-partition kernels (256 CUs)
 constexpr uint64_t MAX_GRID = 1u << 22;          // workgroups per launch (grid * block must stay < 2^32)
 uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 
@@ -141,7 +148,9 @@ struct Timer {
 void configure(cdbg_ctx* c) {
     const int W = c->W;
     const int ts = W == 1 ? TS_COUNT_1 : W == 2 ? TS_COUNT_2 : TS_COUNT_4;
-    const uint64_t target_occ = (uint64_t)ts / 4;            // mean k-mer occurrences per partition
+    // mean k-mer occurrences per partition: ~0.3 distinct per occurrence at sequencing depth fills the
+    // LDS table to ~45 %; inputs with more distinct k-mers per occurrence take several LDS passes
+    const uint64_t target_occ = (uint64_t)ts * 3 / 2;
     int log_np = c->prm.log2_partitions;
     if (log_np < 0) {
         log_np = 0;
@@ -178,16 +187,22 @@ int count_impl(cdbg_ctx* c) {
     sp.reads = c->reads.p; sp.nbytes = c->nbytes; sp.nbytes_padded = c->nbytes_padded;
     sp.k = c->k; sp.m = c->m; sp.log_np = c->log_np; sp.rank_bits = c->rank_bits; sp.rank = c->prm.rank;
     sp.part_count = c->part_count.p; sp.part_cursor = c->part_cursor.p; sp.records = nullptr; sp.stats = c->dstats.p;
-    const uint64_t tiles = (c->nbytes + SCAN_TILE - 1) / SCAN_TILE;
+    // instruction-lean scan when the window fits registers; generic LDS-doubling scan otherwise
+    const bool fast_scan = c->k <= 48 && (c->k - c->m) <= SCANF_WNMAX;
+    const uint64_t tiles = fast_scan ? (c->nbytes + SCANF_TILE - 1) / SCANF_TILE : (c->nbytes + SCAN_TILE - 1) / SCAN_TILE;
     c->st.n_launch_scan = tiles;
 
     // pass 1: histogram of records per partition
     Timer t; CK(t.start(s));
-    CDBG_LAUNCH((k_scan<W, false>), tiles, SCAN_THREADS, s, sp);
+    if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, false>), tiles, SCAN_THREADS, s, sp);
+    else CDBG_LAUNCH((k_scan<W, false>), tiles, SCAN_THREADS, s, sp);
     CDBG_LAUNCH(k_exscan, 1, EXSCAN_THREADS, s, (const uint32_t*)c->part_count.p, c->part_off.p, NPL);
     CK(t.stop(&c->st.ms_scan_hist));
     uint64_t n_records = 0; CK(read_u64(c->part_off.p + NPL, &n_records));
     uint64_t hs[2] = {0, 0}; CK(read_u64(c->dstats.p, hs, 2));
+#ifdef CDBG_PROFILE_PHASES
+    { uint64_t ph[6]; CK(read_u64(c->dstats.p + 16, ph, 6)); fprintf(stderr, "k_scan<hist> phase ticks: load %llu keys %llu winmin %llu flags %llu collect %llu emit %llu\n", (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3], (unsigned long long)ph[4], (unsigned long long)ph[5]); }
+#endif
     c->st.n_records = n_records; c->st.n_member_kmers = hs[0];
 
     // pass 2: emit records at exact offsets
@@ -195,11 +210,12 @@ int count_impl(cdbg_ctx* c) {
     CK(t.start(s));
     CDBG_LAUNCH(k_copy_u64, (NPL + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_cursor.p, NPL);
     sp.records = c->records.p;
-    CDBG_LAUNCH((k_scan<W, true>), tiles, SCAN_THREADS, s, sp);
+    if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, true>), tiles, SCAN_THREADS, s, sp);
+    else CDBG_LAUNCH((k_scan<W, true>), tiles, SCAN_THREADS, s, sp);
     CK(t.stop(&c->st.ms_scan_emit));
 
     // count
-    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096;
+    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + (PERSISTENT_GRID + 1) * (uint64_t)COUNT_CHUNK;
     CK(c->solid_keys.alloc(solid_cap * W, false));
     CK(c->solid_cnt.alloc(solid_cap, false));
     CK(c->solid_cursor.alloc(4, true));
@@ -216,8 +232,8 @@ int count_impl(cdbg_ctx* c) {
     cp.seg_off = c->seg_off.p; cp.seg_n = c->seg_n.p; cp.stats = c->dstats.p;
     cp.big_list = c->big_list.p; cp.big_count = c->big_count.p; cp.error = c->derr.p;
     CK(t.start(s));
-    cp.n_items = (uint32_t)NPL;
-    CDBG_LAUNCH((k_count<W, TS, false>), std::min<uint64_t>(NPL, MAX_GRID), COUNT_THREADS, s, cp);
+    cp.n_items = (uint32_t)NPL; cp.max_passes = 64;
+    CDBG_LAUNCH((k_count<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, cp);
     c->st.n_launch_count = NPL;
     uint32_t nbig = 0;
     HIPCK(hipStreamSynchronize(s));
@@ -231,7 +247,7 @@ int count_impl(cdbg_ctx* c) {
         for (uint32_t i = 0; i < nbig; ++i) {
             uint64_t po[2]; CK(read_u64(c->part_off.p + bl[i], po, 2));
             const uint64_t occ = (po[1] - po[0]) * nmax;
-            offs[i + 1] = offs[i] + pow2_at_least(2 * occ + 4 * COUNT_THREADS);
+            offs[i + 1] = offs[i] + pow2_at_least(2 * occ + 4 * 256);
         }
         CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_state.alloc(offs[nbig], false)); CK(g_cnt.alloc(offs[nbig], false));
         CK(big_off.alloc(nbig + 1, false));
@@ -239,13 +255,16 @@ int count_impl(cdbg_ctx* c) {
         HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
         CountParams bp = cp;
         bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_state = g_state.p; bp.g_cnt = g_cnt.p; bp.big_off = big_off.p;
-        bp.n_items = nbig;
-        CDBG_LAUNCH((k_count<W, TS, true>), nbig, COUNT_THREADS, s, bp);
+        bp.n_items = nbig; bp.max_passes = 1;
+        CDBG_LAUNCH((k_count<W, TS, 256, true>), nbig, 256, s, bp);
         c->st.n_big_partitions += nbig;
     }
     CK(t.stop(&c->st.ms_count));
     CK(check_device_error(c, "count"));
     uint64_t cs[4]; CK(read_u64(c->dstats.p, cs, 4));
+#ifdef CDBG_PROFILE_PHASES
+    { uint64_t ph[8]; CK(read_u64(c->dstats.p + 8, ph, 8)); fprintf(stderr, "k_count phase ticks (100MHz wall clock, summed over WGs): part_off %llu clear %llu insert %llu sweep1+reserve %llu write %llu tail %llu\n", (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3], (unsigned long long)ph[4], (unsigned long long)ph[5]); }
+#endif
     c->st.n_distinct = cs[0]; c->st.n_occurrences = cs[1]; c->st.n_solid = cs[2]; c->st.n_solid_travellers = cs[3];
     CK(read_u64(c->solid_cursor.p, &c->n_solid_entries));
     c->st.input_bytes = c->nbytes;
@@ -270,9 +289,11 @@ int compact_impl(cdbg_ctx* c) {
     CK(c->cursors.alloc(8, false));
 
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const uint64_t pcap = attempt == 0 ? std::min<uint64_t>(S, S / 3 + 4096) + 16 : S + 16;
-        const uint64_t bcap = attempt == 0 ? S + pcap * (uint64_t)(c->k - 1) + 64 : S * (uint64_t)c->k + 64;
-        CK(c->piece_n.alloc(pcap, false)); CK(c->piece_kc.alloc(pcap, false)); CK(c->piece_boff.alloc(pcap, false));
+        const uint64_t pslack = (PERSISTENT_GRID + 1) * (uint64_t)PIECE_CHUNK, bslack = (PERSISTENT_GRID + 1) * (uint64_t)BASES_CHUNK;
+        const uint64_t pcap = (attempt == 0 ? std::min<uint64_t>(S, S / 3 + 4096) + 16 : S + 16) + pslack;
+        const uint64_t bcap = (attempt == 0 ? S + (pcap - pslack) * (uint64_t)(c->k - 1) + 64 : S * (uint64_t)c->k + 64) + bslack;
+        CK(c->piece_n.alloc(pcap, false)); HIPCK(hipMemsetAsync(c->piece_n.p, 0, pcap * sizeof(uint32_t), s));
+        CK(c->piece_kc.alloc(pcap, false)); CK(c->piece_boff.alloc(pcap, false));
         CK(c->piece_bases.alloc(bcap, false));
         HIPCK(hipMemsetAsync(c->cursors.p, 0, 8 * sizeof(uint64_t), s));
         HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), s));
@@ -293,7 +314,7 @@ int compact_impl(cdbg_ctx* c) {
         kp.glue_conf = c->glue_conf.p; kp.glue_mask = c->glue_cap - 1;
         kp.big_list = c->big_list.p; kp.big_count = c->big_count.p; kp.error = c->derr.p; kp.stats = c->dstats.p;
         kp.n_items = (uint32_t)NPL;
-        CDBG_LAUNCH((k_compact<W, TS, false>), std::min<uint64_t>(NPL, MAX_GRID), COMPACT_THREADS, s, kp);
+        CDBG_LAUNCH((k_compact<W, TS, false>), std::min<uint64_t>(NPL, PERSISTENT_GRID), COMPACT_THREADS, s, kp);
         c->st.n_launch_compact = NPL;
         HIPCK(hipStreamSynchronize(s));
         uint32_t nbig = 0; CK(read_u32(c->big_count.p, &nbig));
@@ -327,8 +348,8 @@ int compact_impl(cdbg_ctx* c) {
     CK(check_device_error(c, "compact"));
     uint64_t cur[2]; CK(read_u64(c->cursors.p, cur, 2));
     c->n_pieces = cur[0]; c->n_piece_bases = cur[1];
-    uint64_t ks[3]; CK(read_u64(c->dstats.p, ks, 3));
-    c->st.n_pieces = c->n_pieces; c->st.n_glue_open_ends = ks[0]; c->st.n_cycles = ks[2];
+    uint64_t ks[4]; CK(read_u64(c->dstats.p, ks, 4));
+    c->st.n_pieces = ks[3]; c->st.n_glue_open_ends = ks[0]; c->st.n_cycles = ks[2];
     c->st.ms_total += c->st.ms_compact;
     c->stage = 2;
     return CDBG_OK;
@@ -528,8 +549,9 @@ int cdbg_fetch_solid(cdbg_ctx* c, char* kmers, uint32_t* counts, uint64_t capaci
     if (!S) return CDBG_OK;
     DBuf<uint8_t> dk; DBuf<uint32_t> dc; DBuf<uint64_t> dn;
     CK(dk.alloc(S * (uint64_t)(c->k + 1), false)); CK(dc.alloc(S, false)); CK(dn.alloc(1, true));
-    DecodeParams dp{ c->solid_keys.p, c->solid_cnt.p, E, c->k, c->W, dk.p, dc.p, dn.p };
-    CDBG_LAUNCH(k_decode_solid, (E + 255) / 256, 256, c->stream, dp);
+    (void)E;
+    DecodeParams dp{ c->solid_keys.p, c->solid_cnt.p, c->seg_off.p, c->seg_n.p, c->n_local_parts, c->k, c->W, dk.p, dc.p, dn.p, S };
+    CDBG_LAUNCH(k_decode_solid, (c->n_local_parts + 255) / 256, 256, c->stream, dp);
     HIPCK(hipStreamSynchronize(c->stream));
     uint64_t nw = 0; CK(read_u64(dn.p, &nw));
     if (nw != S) return fail(CDBG_E_INTERNAL, "solid k-mer bookkeeping mismatch: %llu decoded vs %llu counted", (unsigned long long)nw, (unsigned long long)S);

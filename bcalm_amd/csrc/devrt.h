@@ -23,6 +23,9 @@
 #define CDBG_LAUNCH(kern, grid, block, stream, ...) \
     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, stream, __VA_ARGS__)
 #define CDBG_SHARED __shared__
+// wave-level rendezvous between an LDS write and reads of it by other lanes of the SAME wave:
+// the hardware executes a wave's LDS instructions in order, so only the compiler needs a barrier
+#define CDBG_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
 namespace cdbg {

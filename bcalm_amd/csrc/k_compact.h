@@ -28,6 +28,7 @@
 namespace cdbg {
 
 constexpr int COMPACT_THREADS = 256;
+constexpr uint32_t PIECE_CHUNK = 4096, BASES_CHUNK = 1u << 18;   // per-workgroup reservations (one device atomic each)
 constexpr uint32_t LNK_DEAD = 0, LNK_INTERNAL = 1, LNK_OPEN = 2;
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr uint32_t END_LEFT = 0, END_RIGHT = 1;
@@ -62,7 +63,7 @@ struct CompactParams {
     // glue table (HBM)
     uint64_t* glue_keys; uint32_t* glue_state; uint32_t* glue_a; uint32_t* glue_b; uint32_t* glue_conf; uint32_t glue_mask;
     uint32_t* big_list; uint32_t* big_count; uint32_t* error;
-    uint64_t* stats;               // [0] open ends posted [1] confirms posted [2] in-bucket cycles
+    uint64_t* stats;               // [0] open ends posted [1] confirms posted [2] in-bucket cycles [3] pieces written
     // HBM scratch (GLOBAL variant)
     uint64_t* g_keys; uint32_t* g_state; uint32_t* g_cnt; uint32_t* g_lnk; uint32_t* g_aux; const uint64_t* big_off;
     uint32_t n_items;              // buckets (or part_list entries) to process
@@ -94,13 +95,14 @@ CDBG_DEV int probe_succ(const KTable<W>& T, const Kmer<W>& u, int k, uint32_t& s
 }
 
 template <int W, int TS, bool GLOBAL>
-CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item) {
+CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64_t (&acc)[4],
+                             uint64_t& pc_base, uint32_t& pc_left, uint64_t& bc_base, uint32_t& bc_left) {
     CDBG_SHARED uint64_t l_keys[GLOBAL ? 1 : TS * W];
     CDBG_SHARED uint32_t l_state[(GLOBAL || W == 1) ? 1 : TS];
     CDBG_SHARED uint32_t l_cnt[GLOBAL ? 1 : TS];
     CDBG_SHARED uint32_t l_lnk[GLOBAL ? 1 : 2 * TS];
     CDBG_SHARED uint32_t l_aux[GLOBAL ? 1 : 2 * TS];   // [0,cap): visited flags; [cap, 1.5cap): piece starts; [1.5cap, 2cap): entry slots
-    CDBG_SHARED uint32_t s_np, s_nb, s_stat[3];
+    CDBG_SHARED uint32_t s_np, s_nb, s_stat[4];
     CDBG_SHARED uint64_t s_pbase, s_bbase;
 
     const int tid = threadIdx.x;
@@ -125,7 +127,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item) {
     slots = pdesc + cap / 2;                             // E <= cap/2 entries, <= cap/2 pieces
     const uint32_t pg = (p << P.rank_bits) | (uint32_t)P.rank;     // global partition id of this bucket
 
-    if (tid == 0) { s_np = 0; s_nb = 0; s_stat[0] = s_stat[1] = s_stat[2] = 0; }
+    if (tid == 0) { s_np = 0; s_nb = 0; s_stat[0] = s_stat[1] = s_stat[2] = s_stat[3] = 0; }
     ktable_clear<W>(T, tid, COMPACT_THREADS);
     for (uint32_t i = tid; i < cap; i += COMPACT_THREADS) vis[i] = 0;
     __syncthreads();
@@ -210,8 +212,15 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item) {
     }
     __syncthreads();
     if (tid == 0) {
-        uint64_t pb = atomic_add_u64(P.piece_cursor, (uint64_t)s_np);
-        uint64_t bb = atomic_add_u64(P.bases_cursor, (uint64_t)s_nb);
+        s_stat[3] = s_np;                                // pieces really written (ids also cover reservation gaps)
+        // sub-allocate piece ids and base bytes from this workgroup's chunks
+        uint64_t pb, bb;
+        if (s_np > PIECE_CHUNK) pb = atomic_add_u64(P.piece_cursor, (uint64_t)s_np);
+        else { if (s_np > pc_left) { pc_base = atomic_add_u64(P.piece_cursor, (uint64_t)PIECE_CHUNK); pc_left = PIECE_CHUNK; }
+               pb = pc_base; pc_base += s_np; pc_left -= s_np; }
+        if (s_nb > BASES_CHUNK) bb = atomic_add_u64(P.bases_cursor, (uint64_t)s_nb);
+        else { if (s_nb > bc_left) { bc_base = atomic_add_u64(P.bases_cursor, (uint64_t)BASES_CHUNK); bc_left = BASES_CHUNK; }
+               bb = bc_base; bc_base += s_nb; bc_left -= s_nb; }
         if (pb + s_np > P.piece_cap || bb + s_nb > P.bases_cap) { *P.error = 3; s_np = 0; }
         s_pbase = pb; s_bbase = bb; s_nb = 0;
     }
@@ -261,15 +270,18 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item) {
         }
     }
     __syncthreads();
-    if (tid == 0) for (int i = 0; i < 3; ++i) if (s_stat[i]) atomic_add_u64(&P.stats[i], (uint64_t)s_stat[i]);
+    if (tid == 0) for (int i = 0; i < 4; ++i) acc[i] += (uint64_t)s_stat[i];
 }
 
 template <int W, int TS, bool GLOBAL>
 __global__ void __launch_bounds__(COMPACT_THREADS) k_compact(CompactParams P) {
+    uint64_t acc[4] = {0, 0, 0, 0};
+    uint64_t pc_base = 0, bc_base = 0; uint32_t pc_left = 0, bc_left = 0;
     for (uint32_t item = blockIdx.x; item < P.n_items; item += gridDim.x) {
-        compact_bucket<W, TS, GLOBAL>(P, item);
+        compact_bucket<W, TS, GLOBAL>(P, item, acc, pc_base, pc_left, bc_base, bc_left);
         __syncthreads();                                 // LDS is reused by the next bucket
     }
+    if (threadIdx.x == 0) for (int i = 0; i < 4; ++i) if (acc[i]) atomic_add_u64(&P.stats[i], acc[i]);
 }
 
 }  // namespace cdbg

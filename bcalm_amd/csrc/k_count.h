@@ -13,11 +13,17 @@
 // segment per partition.  A partition whose distinct k-mers do not fit LDS is put on
 // the `big` list and re-run by the same code with its table in HBM scratch.
 #pragma once
-#include "k_scan.h"
+#include "k_scan_fast.h"
 
 namespace cdbg {
 
-constexpr int COUNT_THREADS = 256;
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+#define CDBG_PH(i) do { if (threadIdx.x == 0) { const uint64_t t_ = wall_clock64(); ph[i] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+#define CDBG_PH(i) do { } while (0)
+#endif
+constexpr int COUNT_MAP = 1664;                       // per-wave member map entries (records of a batch x members)
+constexpr uint32_t COUNT_CHUNK = 32768;                // solid entries a workgroup reserves per device atomic
 constexpr uint32_t TRAV_FLAG = 0x80000000u;          // in a count word: this entry is a traveller copy
 constexpr uint32_t ST_EMPTY = 0u, ST_BUSY = 1u;      // slot states for multi-word keys (W > 1)
 
@@ -52,21 +58,23 @@ CDBG_DEV Kmer<W> ktable_key(const KTable<W>& t, uint32_t s) {
     return r;
 }
 // find-or-insert; returns slot, sets is_new.  GLOBAL selects the fence flavour.
+// Gives up (returns 0xFFFFFFFF) after max_probe occupied slots, so a full table cannot hang a lane.
 template <int W, bool GLOBAL>
-CDBG_DEV uint32_t ktable_insert(const KTable<W>& t, const Kmer<W>& key, bool& is_new) {
+CDBG_DEV uint32_t ktable_insert(const KTable<W>& t, const Kmer<W>& key, bool& is_new, uint32_t max_probe = 0xFFFFFFFFu) {
     const uint32_t h = key.hash();
     uint32_t s = h & t.mask;
     is_new = false;
     if (W == 1) {
-        for (;;) {
+        for (uint32_t probes = 0; probes < max_probe; ++probes) {
             const uint64_t old = atomic_cas_u64(&t.keys[s], ~0ULL, key.w[0]);
             if (old == ~0ULL) { is_new = true; return s; }
             if (old == key.w[0]) return s;
             s = (s + 1) & t.mask;
         }
+        return 0xFFFFFFFFu;
     } else {
         const uint32_t tag = (h >> 1) | 0x80000000u;
-        for (;;) {
+        for (uint32_t probes = 0; probes < max_probe;) {
             const uint32_t st = atomic_cas_u32(&t.state[s], ST_EMPTY, ST_BUSY);
             if (st == ST_EMPTY) {
                 for (int i = 0; i < W; ++i) t.keys[(uint64_t)s * W + i] = key.w[i];
@@ -80,8 +88,9 @@ CDBG_DEV uint32_t ktable_insert(const KTable<W>& t, const Kmer<W>& key, bool& is
                 for (int i = 0; i < W; ++i) eq &= ((GLOBAL ? ld_agent_u64(&t.keys[(uint64_t)s * W + i]) : t.keys[(uint64_t)s * W + i]) == key.w[i]);
                 if (eq) return s;
             }
-            s = (s + 1) & t.mask;
+            s = (s + 1) & t.mask; ++probes;
         }
+        return 0xFFFFFFFFu;
     }
 }
 // lookup only (table no longer being modified); returns slot or 0xFFFFFFFF
@@ -112,15 +121,39 @@ CDBG_DEV uint32_t ktable_find(const KTable<W>& t, const Kmer<W>& key) {
 }
 
 // ---- record decoding ----
+template <int N>
+CDBG_DEV uint64_t sel_word(const uint64_t (&r)[N], int idx) {      // r[idx] without dynamic register indexing
+    uint64_t w = r[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) w = (idx == j) ? r[j] : w;
+    return idx < N ? w : 0ULL;
+}
 template <int W>
 struct RecView {
     uint64_t r[RecFmt<W>::RW];
+    // member k-mer t (bases [t, t+k)) as a number: one funnel shift of the RW-word record
+    CDBG_DEV Kmer<W> kmer(int t, int k) const {
+        const int sh = 64 * RecFmt<W>::RW - 2 * (t + k);
+        const int ws = sh >> 6, bs = sh & 63;
+        Kmer<W> x;
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const uint64_t lo = sel_word<RecFmt<W>::RW>(r, i + ws), hi = sel_word<RecFmt<W>::RW>(r, i + ws + 1);
+            x.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
+        }
+        x.mask(k);
+        return x;
+    }
     CDBG_DEV int n() const { return (int)(r[0] & 0xFFu); }
     CDBG_DEV bool first_trav() const { return (r[0] >> 8) & 1u; }
     CDBG_DEV bool last_trav() const { return (r[0] >> 9) & 1u; }
     CDBG_DEV uint32_t base(int i) const {
         const int pos = 64 * RecFmt<W>::RW - 2 * (i + 1);
-        return (uint32_t)(r[pos >> 6] >> (pos & 63)) & 3u;
+        const int wi = pos >> 6;
+        uint64_t w = r[0];                               // select chain: keeps r[] in registers (no scratch)
+#pragma unroll
+        for (int j = 1; j < RecFmt<W>::RW; ++j) w = (wi == j) ? r[j] : w;
+        return (uint32_t)(w >> (pos & 63)) & 3u;
     }
 };
 
@@ -141,23 +174,45 @@ struct CountParams {
     // HBM scratch table (GLOBAL variant): slot i of the big pass uses [big_off[i], big_off[i+1]) slots
     uint64_t* g_keys; uint32_t* g_state; uint32_t* g_cnt; const uint64_t* big_off;
     uint32_t n_items;              // partitions (or part_list entries) to process
+    uint32_t max_passes;           // LDS multi-pass limit before a partition is deferred to the HBM pass
 };
 
-// one partition, processed by the whole workgroup; `item` = index of the work item (== partition
-// unless a part_list is given)
-template <int W, int TS, bool GLOBAL>
-CDBG_DEV void count_partition(const CountParams& P, const uint32_t item) {
+// ---------------------------------------------------------------------------
+// One partition, processed by the whole workgroup.
+//
+// Insert phase, member-parallel: each wave loads a batch of records (one per lane), builds
+// a prefix sum of their member counts with wave shuffles and a member->record map in LDS,
+// then every lane extracts ONE k-mer per step (funnel shift of the record fetched from the
+// owning lane with ds_bpermute), so all 64 lanes insert on every step regardless of how
+// many k-mers each record holds.
+//
+// npass == 1: build the table once, sweep for statistics + solid count, reserve the
+// output segment, sweep again to write it.
+// npass  > 1 (the distinct k-mers do not fit the LDS table): the partition's records are
+// streamed npass times and pass j only inserts the k-mers whose hash selects j; phase 0
+// counts, then the segment is reserved, phase 1 repeats the passes and writes.  The records
+// of one partition are a few hundred KB, so the re-reads are served by L2/MALL.
+// `start_np` / `strikes` adapt the starting number of passes per workgroup.
+// ---------------------------------------------------------------------------
+template <int W, int TS, int NT, bool GLOBAL>
+CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_t (&acc)[4],
+                              uint32_t& start_np, uint32_t& strikes, uint64_t& chunk_base, uint32_t& chunk_left,
+                              uint64_t (&ph)[8], uint64_t& t_prev) {
     constexpr int RW = RecFmt<W>::RW;
+    constexpr int NW = NT / 64;
     CDBG_SHARED uint64_t l_keys[GLOBAL ? 1 : TS * W];
     CDBG_SHARED uint32_t l_state[(GLOBAL || W == 1) ? 1 : TS];
     CDBG_SHARED uint32_t l_cnt[GLOBAL ? 1 : TS];
+    CDBG_SHARED uint8_t l_map[NW][COUNT_MAP];
     CDBG_SHARED uint32_t s_fill, s_over, s_nsolid, s_wr;
     CDBG_SHARED uint64_t s_base;
     CDBG_SHARED uint32_t s_stat[4];
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t p = P.part_list ? P.part_list[item] : item;
     const uint64_t rec0 = P.part_off[p], rec1 = P.part_off[p + 1];
+    CDBG_PH(0);
+    if (rec1 == rec0) { if (tid == 0) { P.seg_off[p] = 0; P.seg_n[p] = 0; } return; }
 
     KTable<W> T; uint32_t* cnt; uint32_t cap;
     if (GLOBAL) {
@@ -167,90 +222,166 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item) {
         cap = TS; T.keys = l_keys; T.state = l_state; cnt = l_cnt;
     }
     T.mask = cap - 1;
-    const uint32_t maxfill = cap - cap / 4 - COUNT_THREADS;       // leave room for in-flight claims
-
-    if (tid == 0) { s_fill = 0; s_over = 0; s_nsolid = 0; s_wr = 0; }
-    if (tid < 4) s_stat[tid] = 0;
-    if (rec1 == rec0) { if (tid == 0) { P.seg_off[p] = 0; P.seg_n[p] = 0; } return; }
-    ktable_clear<W>(T, tid, COUNT_THREADS);
-    for (uint32_t i = tid; i < cap; i += COUNT_THREADS) cnt[i] = 0;
-    __syncthreads();
-
-    // ---- count: one record per lane-iteration ----
+    const uint32_t maxfill = cap - cap / 4;                       // load limit; inserts also give up after 64 probes
     const int k = P.k;
-    for (uint64_t r = rec0 + tid; r < rec1; r += COUNT_THREADS) {
-        if (ld_volatile_u32(&s_over)) break;
-        RecView<W> R;
+    const int nmax = RecFmt<W>::CAPB - k + 1;                      // members per record
+    int RB = 64; while (RB * nmax > COUNT_MAP) RB >>= 1;           // records per wave batch (map capacity)
+    uint8_t* map = l_map[wave];
+
+    uint32_t npass = GLOBAL ? 1u : start_np;
+    for (;;) {                                                    // attempts with npass, 2 npass, ...
+        if (tid == 0) { s_nsolid = 0; s_wr = 0; s_over = 0; }
+        if (tid < 4) s_stat[tid] = 0;
+        bool overflow = false;
+        const int nphase = npass == 1 ? 1 : 2;
+        for (int phase = 0; phase < nphase && !overflow; ++phase) {
+            for (uint32_t pass = 0; pass < npass; ++pass) {
+                // ---- build the table of this pass ----
+                if (tid == 0) s_fill = 0;
+                ktable_clear<W>(T, tid, NT);
+                for (uint32_t i = tid; i < cap; i += NT) cnt[i] = 0;
+                __syncthreads();
+                CDBG_PH(1);
+                for (uint64_t b0 = rec0 + (uint64_t)wave * RB; b0 < rec1; b0 += (uint64_t)NW * RB) {   // wave-uniform
+                    if (__any((int)ld_volatile_u32(&s_over))) break;
+                    const int nrec = (int)((rec1 - b0) < (uint64_t)RB ? (rec1 - b0) : (uint64_t)RB);
+                    RecView<W> R; int n = 0;
 #pragma unroll
-        for (int i = 0; i < RW; ++i) R.r[i] = P.records[r * RW + i];
-        const int n = R.n();
-        Kmer<W> fw = Kmer<W>::zero(), rc = Kmer<W>::zero();
-        for (int i = 0; i < k - 1; ++i) { const uint32_t b = R.base(i); fw.push_right(k, b); rc.push_left(k, 3u - b); }
-        for (int t = 0; t < n; ++t) {
-            const uint32_t b = R.base(t + k - 1);
-            fw.push_right(k, b); rc.push_left(k, 3u - b);
-            const Kmer<W>& can = (rc < fw) ? rc : fw;
-            bool is_new;
-            const uint32_t s = ktable_insert<W, GLOBAL>(T, can, is_new);
-            if (is_new) { if (atomic_add_u32(&s_fill, 1u) >= maxfill) s_over = 1; }
-            atomic_add_u32(&cnt[s], 1u);
-            const bool trav = (t == 0 && R.first_trav()) || (t == n - 1 && R.last_trav());
-            if (trav && !(cnt[s] & TRAV_FLAG)) atomic_or_u32(&cnt[s], TRAV_FLAG);
-            if (ld_volatile_u32(&s_over)) break;
+                    for (int i = 0; i < RW; ++i) R.r[i] = 0;
+                    if (lane < nrec) {
+#pragma unroll
+                        for (int i = 0; i < RW; ++i) R.r[i] = P.records[(b0 + lane) * RW + i];
+                        n = R.n();
+                    }
+                    int incl = n;                                  // inclusive prefix sum over the wave
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+                    const int excl = incl - n;
+                    const int total = __shfl(incl, 63);
+                    for (int j = 0; j < n; ++j) map[excl + j] = (uint8_t)lane;
+                    CDBG_WAVE_SYNC();
+                    for (int g0 = 0; g0 < total; g0 += 64) {       // wave-uniform trip count
+                        const int g = g0 + lane;
+                        const bool active = g < total;
+                        const int ri = active ? (int)map[g] : 0;
+                        RecView<W> Q;
+#pragma unroll
+                        for (int i = 0; i < RW; ++i) Q.r[i] = __shfl(R.r[i], ri);
+                        const int ex = __shfl(excl, ri);
+                        if (active) {
+                            const int t = g - ex, qn = Q.n();
+                            const Kmer<W> fw = Q.kmer(t, k);
+                            const Kmer<W> rc = fw.rc(k);
+                            const Kmer<W>& can = (rc < fw) ? rc : fw;
+                            if (npass == 1 || ((can.hash() >> 20) & (npass - 1)) == pass) {
+                                bool is_new;
+                                const uint32_t s = ktable_insert<W, GLOBAL>(T, can, is_new, 64u);
+                                if (s == 0xFFFFFFFFu) s_over = 1;   // table (nearly) full: this pass is void
+                                else {
+                                    if (is_new) { if (atomic_add_u32(&s_fill, 1u) >= maxfill) s_over = 1; }
+                                    const bool trav = (t == 0 && Q.first_trav()) || (t == qn - 1 && Q.last_trav());
+                                    atomic_add_u32(&cnt[s], 1u);
+                                    if (trav) atomic_or_u32(&cnt[s], TRAV_FLAG);
+                                }
+                            }
+                        }
+                    }
+                    CDBG_WAVE_SYNC();                              // map is rewritten by the next batch
+                }
+                __syncthreads();
+                CDBG_PH(2);
+                if (s_over) { overflow = true; break; }
+                // ---- sweep: statistics + number of solid entries (phase 0) ----
+                if (phase == 0) {
+                    uint32_t my_solid = 0, st_dist = 0, st_occ = 0, st_sh = 0, st_st = 0;
+                    for (uint32_t s = tid; s < cap; s += NT) {
+                        if (!ktable_used<W>(T, s)) continue;
+                        const uint32_t c = cnt[s], n = c & ~TRAV_FLAG; const bool trav = c & TRAV_FLAG;
+                        if (!trav) { ++st_dist; st_occ += n; }
+                        if (n >= P.amin) { ++my_solid; if (trav) ++st_st; else ++st_sh; }
+                    }
+                    // wave-level tree reduction first (an LDS atomic with per-lane values is serialised
+                    // lane by lane by the compiler), then one LDS atomic per wave and counter
+                    uint32_t pk0 = st_dist | (my_solid << 16), pk1 = st_sh | (st_st << 16);
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) { pk0 += __shfl_xor(pk0, d); pk1 += __shfl_xor(pk1, d); st_occ += __shfl_xor(st_occ, d); }
+                    if (lane == 0) {
+                        if (pk0 >> 16) atomic_add_u32(&s_nsolid, pk0 >> 16);
+                        if (pk0 & 0xFFFFu) atomic_add_u32(&s_stat[0], pk0 & 0xFFFFu);
+                        if (st_occ) atomic_add_u32(&s_stat[1], st_occ);
+                        if (pk1 & 0xFFFFu) atomic_add_u32(&s_stat[2], pk1 & 0xFFFFu);
+                        if (pk1 >> 16) atomic_add_u32(&s_stat[3], pk1 >> 16);
+                    }
+                    __syncthreads();
+                    if (pass == npass - 1 && tid == 0) {          // everything counted: reserve the segment
+                        // sub-allocate from this workgroup's chunk: one device atomic per COUNT_CHUNK entries
+                        uint64_t b;
+                        if (s_nsolid > COUNT_CHUNK) b = atomic_add_u64(P.solid_cursor, (uint64_t)s_nsolid);
+                        else {
+                            if (s_nsolid > chunk_left) { chunk_base = atomic_add_u64(P.solid_cursor, (uint64_t)COUNT_CHUNK); chunk_left = COUNT_CHUNK; }
+                            b = chunk_base; chunk_base += s_nsolid; chunk_left -= s_nsolid;
+                        }
+                        if (b + s_nsolid > P.solid_cap) { *P.error = 1; b = 0; s_nsolid = 0; }
+                        s_base = b;
+                        P.seg_off[p] = b; P.seg_n[p] = s_nsolid;
+                    }
+                    if (pass == npass - 1) __syncthreads();
+                    CDBG_PH(3);
+                }
+                // ---- sweep: write solid entries (single pass: right away; multi-pass: phase 1) ----
+                if (npass == 1 || phase == 1) {
+                    const uint64_t obase = s_base;
+                    if (s_nsolid) {
+                        for (uint32_t s = tid; s < cap; s += NT) {
+                            if (!ktable_used<W>(T, s)) continue;
+                            const uint32_t c = cnt[s];
+                            if ((c & ~TRAV_FLAG) < P.amin) continue;
+                            const uint64_t o = obase + atomic_add_u32(&s_wr, 1u);
+                            for (int i = 0; i < W; ++i) P.solid_keys[o * W + i] = T.keys[(uint64_t)s * W + i];
+                            P.solid_cnt[o] = c;
+                        }
+                    }
+                }
+                __syncthreads();
+                CDBG_PH(4);
+            }
+        }
+        if (!overflow) break;
+        __syncthreads();
+        if (GLOBAL) { if (tid == 0) *P.error = 2; return; }     // scratch sizing bug: cannot happen by construction
+        npass *= 2;
+        if (npass > P.max_passes) {                               // hopeless in LDS: defer to the HBM pass
+            if (tid == 0) { const uint32_t i = atomic_add_u32(P.big_count, 1u); P.big_list[i] = p; P.seg_off[p] = 0; P.seg_n[p] = 0; }
+            return;
         }
     }
-    __syncthreads();
-    if (s_over) {                                            // does not fit: defer to the big pass
-        if (tid == 0) {
-            if (GLOBAL) *P.error = 2;                        // scratch sizing bug: cannot happen by construction
-            else { const uint32_t i = atomic_add_u32(P.big_count, 1u); P.big_list[i] = p; P.seg_off[p] = 0; P.seg_n[p] = 0; }
-        }
-        return;
-    }
-
-    // ---- sweep 1: statistics + number of solid entries ----
-    uint32_t my_solid = 0, st_dist = 0, st_occ = 0, st_sh = 0, st_st = 0;
-    for (uint32_t s = tid; s < cap; s += COUNT_THREADS) {
-        if (!ktable_used<W>(T, s)) continue;
-        const uint32_t c = cnt[s], n = c & ~TRAV_FLAG; const bool trav = c & TRAV_FLAG;
-        if (!trav) { ++st_dist; st_occ += n; }
-        if (n >= P.amin) { ++my_solid; if (trav) ++st_st; else ++st_sh; }
-    }
-    if (my_solid) atomic_add_u32(&s_nsolid, my_solid);
-    if (st_dist) atomic_add_u32(&s_stat[0], st_dist);
-    if (st_occ) atomic_add_u32(&s_stat[1], st_occ);
-    if (st_sh) atomic_add_u32(&s_stat[2], st_sh);
-    if (st_st) atomic_add_u32(&s_stat[3], st_st);
-    __syncthreads();
-    if (tid == 0) {
-        uint64_t b = atomic_add_u64(P.solid_cursor, (uint64_t)s_nsolid);
-        if (b + s_nsolid > P.solid_cap) { *P.error = 1; b = 0; s_nsolid = 0; }
-        s_base = b;
-        P.seg_off[p] = b; P.seg_n[p] = s_nsolid;
-        for (int i = 0; i < 4; ++i) if (s_stat[i]) atomic_add_u64(&P.stats[i], (uint64_t)s_stat[i]);
-    }
-    __syncthreads();
-    if (s_nsolid == 0) return;
-
-    // ---- sweep 2: write the partition's solid segment ----
-    const uint64_t obase = s_base;
-    for (uint32_t s = tid; s < cap; s += COUNT_THREADS) {
-        if (!ktable_used<W>(T, s)) continue;
-        const uint32_t c = cnt[s];
-        if ((c & ~TRAV_FLAG) < P.amin) continue;
-        const uint64_t o = obase + atomic_add_u32(&s_wr, 1u);
-        for (int i = 0; i < W; ++i) P.solid_keys[o * W + i] = T.keys[(uint64_t)s * W + i];
-        P.solid_cnt[o] = c;
+    if (tid == 0) for (int i = 0; i < 4; ++i) acc[i] += (uint64_t)s_stat[i];
+    if (!GLOBAL) {                                                // adapt the starting pass count of this workgroup
+        if (npass > start_np) { if (++strikes >= 2) { start_np = npass; strikes = 0; } }
+        else if (strikes) --strikes;
     }
 }
 
-// grid-stride over partitions (HIP limits grid*block to < 2^32 work-items)
-template <int W, int TS, bool GLOBAL>
-__global__ void __launch_bounds__(COUNT_THREADS) k_count(CountParams P) {
+// persistent workgroups, grid-stride over partitions (HIP limits grid*block to < 2^32 work-items);
+// statistics are accumulated in registers and published with one atomic per workgroup
+template <int W, int TS, int NT, bool GLOBAL>
+__global__ void __launch_bounds__(NT) k_count(CountParams P) {
+    uint64_t acc[4] = {0, 0, 0, 0};
+    uint32_t start_np = 1, strikes = 0;
+    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_prev = 0;
+    uint64_t chunk_base = 0; uint32_t chunk_left = 0;
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+    t_prev = wall_clock64();
+#endif
     for (uint32_t item = blockIdx.x; item < P.n_items; item += gridDim.x) {
-        count_partition<W, TS, GLOBAL>(P, item);
+        count_partition<W, TS, NT, GLOBAL>(P, item, acc, start_np, strikes, chunk_base, chunk_left, ph, t_prev);
         __syncthreads();                                 // LDS is reused by the next partition
+        CDBG_PH(5);
     }
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+    if (threadIdx.x == 0) for (int i = 0; i < 8; ++i) if (ph[i]) atomic_add_u64(&P.stats[8 + i], ph[i]);
+#endif
+    if (threadIdx.x == 0) for (int i = 0; i < 4; ++i) if (acc[i]) atomic_add_u64(&P.stats[i], acc[i]);
 }
 
 }  // namespace cdbg

@@ -30,14 +30,20 @@ struct GlueResolveParams {
     uint64_t* stats;               // [0] junctions joined
 };
 __global__ void k_glue_resolve(GlueResolveParams P) {
+    CDBG_SHARED uint32_t s_joined;
+    if (threadIdx.x == 0) s_joined = 0;
+    __syncthreads();
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= P.cap) return;
-    if (!P.conf[s]) return;
-    const uint32_t a = P.a[s], b = P.b[s];
-    if (a == 0 || b == 0) return;
-    P.link[a - 1] = b - 1;
-    P.link[b - 1] = a - 1;
-    atomic_add_u64(&P.stats[0], 1ULL);
+    if (s < P.cap && P.conf[s]) {
+        const uint32_t a = P.a[s], b = P.b[s];
+        if (a != 0 && b != 0) {
+            P.link[a - 1] = b - 1;
+            P.link[b - 1] = a - 1;
+            atomic_add_u32(&s_joined, 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_joined) atomic_add_u64(&P.stats[0], (uint64_t)s_joined);
 }
 
 // ---- (2) pointer jumping ----
@@ -95,13 +101,27 @@ struct HeadParams {
     uint64_t* n_unitigs; uint64_t* out_cursor; uint32_t* error;
 };
 __global__ void k_unitig_heads(HeadParams P) {
+    CDBG_SHARED uint32_t s_n; CDBG_SHARED uint64_t s_len, s_ubase, s_obase;
+    if (threadIdx.x == 0) { s_n = 0; s_len = 0; }
+    __syncthreads();
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= P.n_states) return;
-    if (P.link[e] != NONE32) return;                       // has a predecessor: not a head
-    if (!(P.tail[e] > P.tail[e ^ 1u])) return;             // the other direction of this path is the chosen one
-    const uint64_t uid = atomic_add_u64(P.n_unitigs, 1ULL);
-    const uint32_t len = P.acc[e] + (uint32_t)P.k - 1u;
-    const uint64_t off = atomic_add_u64(P.out_cursor, (uint64_t)len);
+    // head of the chosen direction: no predecessor, and the larger tail of the two directions
+    // (piece ids inside unused reservation gaps have piece_n == 0 => acc == 0: not a unitig)
+    const bool head = e < P.n_states && P.link[e] == NONE32 && P.tail[e] > P.tail[e ^ 1u] && P.acc[e] != 0;
+    uint32_t len = 0, my_i = 0; uint64_t my_o = 0;
+    if (head) {
+        len = P.acc[e] + (uint32_t)P.k - 1u;
+        my_i = atomic_add_u32(&s_n, 1u);                   // LDS: position inside this workgroup's batch
+        my_o = atomic_add_u64(&s_len, (uint64_t)len);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) {                         // one reservation per workgroup
+        s_ubase = atomic_add_u64(P.n_unitigs, (uint64_t)s_n);
+        s_obase = atomic_add_u64(P.out_cursor, s_len);
+    }
+    __syncthreads();
+    if (!head) return;
+    const uint64_t uid = s_ubase + my_i, off = s_obase + my_o;
     if (uid >= P.unitig_cap || off + len > P.out_cap) { *P.error = 4; P.head_uid[e] = NONE32; return; }
     P.head_uid[e] = (uint32_t)uid;
     P.unitig_off[uid] = off; P.unitig_len[uid] = len; P.unitig_kc[uid] = 0;
@@ -122,10 +142,11 @@ __global__ void k_emit(EmitParams P) {
     // direction d visits this piece in state e; its reverse visits it in e^1; chosen: larger tail
     const uint32_t e = (P.tail[e0] > P.tail[e1]) ? e0 : e1;
     const uint32_t head = P.tail[e ^ 1u] ^ 1u;             // head of d = mirror of the tail of the reverse direction
+    const uint32_t n = P.piece_n[p];
+    if (n == 0) return;                                    // reservation gap
     const uint32_t uid = P.head_uid[head];
     if (uid == NONE32) return;
     const uint32_t koff = P.acc[head] - P.acc[e];          // k-mers before this piece
-    const uint32_t n = P.piece_n[p];
     const uint32_t nb = n + (uint32_t)P.k - 1u;
     const uint8_t* src = P.piece_bases + P.piece_boff[p];
     uint8_t* dst = P.out + P.unitig_off[uid] + koff;
@@ -135,20 +156,26 @@ __global__ void k_emit(EmitParams P) {
     atomic_add_u64(&P.unitig_kc[uid], P.piece_kc[p]);
 }
 
-// ---- fetch helpers: solid k-mers as ASCII (stage-1 parity surface) ----
-struct DecodeParams { const uint64_t* keys; const uint32_t* cnt; uint64_t n; int k, W; uint8_t* out_kmers; uint32_t* out_cnt; uint64_t* n_out; };
+// ---- fetch helpers: solid k-mers as ASCII (stage-1 parity surface); one lane per partition segment ----
+struct DecodeParams { const uint64_t* keys; const uint32_t* cnt; const uint64_t* seg_off; const uint32_t* seg_n; uint64_t n_parts;
+                      int k, W; uint8_t* out_kmers; uint32_t* out_cnt; uint64_t* n_out; uint64_t cap; };
 __global__ void k_decode_solid(DecodeParams P) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
-    const uint32_t c = P.cnt[i];
-    if (c & TRAV_FLAG) return;                             // traveller copies are not part of the k-mer set
-    const uint64_t o = atomic_add_u64(P.n_out, 1ULL);
-    for (int b = 0; b < P.k; ++b) {
-        const int pos = 2 * (P.k - 1 - b);
-        P.out_kmers[o * (uint64_t)(P.k + 1) + b] = (uint8_t)("ACGT"[(P.keys[i * P.W + (pos >> 6)] >> (pos & 63)) & 3u]);
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P.n_parts) return;
+    const uint64_t so = P.seg_off[p];
+    for (uint32_t e = 0; e < P.seg_n[p]; ++e) {
+        const uint64_t i = so + e;
+        const uint32_t c = P.cnt[i];
+        if (c & TRAV_FLAG) continue;                       // traveller copies are not part of the k-mer set
+        const uint64_t o = atomic_add_u64(P.n_out, 1ULL);
+        if (o >= P.cap) continue;
+        for (int b = 0; b < P.k; ++b) {
+            const int pos = 2 * (P.k - 1 - b);
+            P.out_kmers[o * (uint64_t)(P.k + 1) + b] = (uint8_t)("ACGT"[(P.keys[i * P.W + (pos >> 6)] >> (pos & 63)) & 3u]);
+        }
+        P.out_kmers[o * (uint64_t)(P.k + 1) + P.k] = 0;
+        P.out_cnt[o] = c;
     }
-    P.out_kmers[o * (uint64_t)(P.k + 1) + P.k] = 0;
-    P.out_cnt[o] = c;
 }
 
 }  // namespace cdbg

@@ -30,6 +30,11 @@
 
 namespace cdbg {
 
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+#define CDBG_SPH(i) do { if (threadIdx.x == 0) { const uint64_t t_ = wall_clock64(); sph[i] += t_ - st_prev; st_prev = t_; } } while (0)
+#else
+#define CDBG_SPH(i) do { } while (0)
+#endif
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_TILE = 4096;                       // junctions per workgroup
 constexpr int SCAN_PKW = (SCAN_TILE + 16 + 256) / 16 + 11;   // packed words (16 bases each) incl. halo/over-read; EVEN
@@ -72,6 +77,25 @@ CDBG_DEV bool scan_all_valid(const uint32_t* vm, int q, int len) {
     return true;
 }
 
+// write one record (EMIT) or count it (HIST) -- one device atomic either way
+template <int W, bool EMIT>
+CDBG_DEV void scan_emit_record(const ScanParams& P, const uint32_t* pk, int ms, uint32_t meta, uint32_t lpart) {
+    constexpr int RW = RecFmt<W>::RW;
+    if (EMIT) {
+        const uint64_t slot = atomic_add_u64(&P.part_cursor[lpart], 1ULL);
+        uint64_t* dst = P.records + slot * RW;
+        const int bitoff = 2 * (15 + ms);
+#pragma unroll
+        for (int wv = 0; wv < RW; ++wv) {
+            uint64_t x = scan_get64(pk, bitoff + 64 * wv);
+            if (wv == RW - 1) x = (x & ~0xFFFFULL) | meta;
+            dst[RW - 1 - wv] = x;
+        }
+    } else {
+        atomic_add_u32(&P.part_count[lpart], 1u);
+    }
+}
+
 template <int W, bool EMIT>
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     constexpr int RW = RecFmt<W>::RW;
@@ -82,12 +106,16 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     CDBG_SHARED uint32_t kb[SCAN_NKEY];
     CDBG_SHARED uint64_t brk[SCAN_TILE / 64 + 2];
     CDBG_SHARED uint64_t stt[SCAN_TILE / 64 + 2];
-    CDBG_SHARED uint32_t s_members, s_trav;
+    CDBG_SHARED uint32_t s_members, s_trav, s_nrec;
+    constexpr uint32_t LIST_CAP = SCAN_NKEY / 2;
 
     const int tid = threadIdx.x;
     const int k = P.k, m = P.m;
     const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILE;
     const int64_t base = t0 - 16;                     // byte offset of tile-local base index 0
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+    uint64_t sph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t st_prev = wall_clock64();
+#endif
 
     // ---- 1. load 16 bytes per lane-iteration, encode to 2 bit + validity ----
     for (int w = tid; w < SCAN_PKW; w += SCAN_THREADS) {
@@ -108,8 +136,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
         reinterpret_cast<uint16_t*>(vm)[w] = (uint16_t)vbits;
     }
     if (tid < 4) vm[SCAN_PKW / 2 + tid] = 0;           // over-read words of scan_all_valid
-    if (tid == 0) { s_members = 0; s_trav = 0; }
+    if (tid == 0) { s_members = 0; s_trav = 0; s_nrec = 0; }
     __syncthreads();
+    CDBG_SPH(0);
 
     // ---- 2. m-mer ordering keys; index i <-> tile base index q = 15 + i ----
     const int WN = k - m;                              // m-mers per junction
@@ -127,6 +156,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
         ka[i] = key;
     }
     __syncthreads();
+    CDBG_SPH(1);
 
     // ---- 3. sliding-window minimum of width WN by doubling (ping-pong in LDS) ----
     uint32_t* cur = ka; uint32_t* oth = kb;
@@ -152,6 +182,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
         uint32_t* t = cur; cur = oth; oth = t;
     }
     const uint32_t* g = cur;                           // g[jq], jq in [0, TILE+1]; junction jq <-> q = 15 + jq
+    uint32_t* lst = oth;                               // the idle ping-pong buffer stages this tile's records
+    CDBG_SPH(2);
 
     // ---- 4. run structure: brk bit (jq-1) = junction jq does NOT continue the previous run ----
     for (int it = 0; it < SCAN_TILE / SCAN_THREADS; ++it) {
@@ -165,6 +197,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     }
     if (tid == 0) { brk[SCAN_TILE / 64] = ~0ULL; brk[SCAN_TILE / 64 + 1] = ~0ULL; }
     __syncthreads();
+    CDBG_SPH(3);
 
     // ---- 5. one lane per run start: find the run end, apply the boundary rules, emit ----
     const int NMAX = CAPB - k + 1;                     // member k-mers per record
@@ -219,19 +252,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
                 const bool lt = (ce == e) && last_incl && last_trav;
                 if (ft) meta |= 0x100u;
                 if (lt) meta |= 0x200u;
-                if (EMIT) {
-                    const uint64_t slot = atomic_add_u64(&P.part_cursor[lpart], 1ULL);
-                    uint64_t* dst = P.records + slot * RW;
-                    const int bitoff = 2 * (15 + ms);
-#pragma unroll
-                    for (int wv = 0; wv < RW; ++wv) {
-                        uint64_t x = scan_get64(pk, bitoff + 64 * wv);
-                        if (wv == RW - 1) x = (x & ~0xFFFFULL) | meta;
-                        dst[RW - 1 - wv] = x;
-                    }
-                } else {
-                    atomic_add_u32(&P.part_count[lpart], 1u);
-                }
+                // stage the record in LDS; all lanes emit together afterwards, so a tile costs two
+                // rounds of device-atomic latency instead of one per loop iteration
+                const uint32_t li = atomic_add_u32(&s_nrec, 1u);
+                if (li < LIST_CAP) { lst[2 * li] = (uint32_t)ms | (meta << 16); lst[2 * li + 1] = lpart; }
+                else scan_emit_record<W, EMIT>(P, pk, ms, meta, lpart);   // list full (low-complexity tile)
                 n_members += (uint64_t)n;
                 n_trav += (ft ? 1 : 0) + (lt ? 1 : 0);
             }
@@ -239,9 +264,22 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
             c = ce + 1;
         }
     }
+    __syncthreads();
+    CDBG_SPH(4);
+    {
+        const uint32_t nl = s_nrec < LIST_CAP ? s_nrec : LIST_CAP;
+        for (uint32_t i = tid; i < nl; i += SCAN_THREADS)
+            scan_emit_record<W, EMIT>(P, pk, (int)(lst[2 * i] & 0xFFFFu), lst[2 * i] >> 16, lst[2 * i + 1]);
+    }
+    CDBG_SPH(5);
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+    if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) atomic_add_u64(&P.stats[16 + i], sph[i]);
+#endif
     if (!EMIT) {                                        // one device atomic per workgroup, not per lane
-        if (n_members) atomic_add_u32(&s_members, (uint32_t)n_members);
-        if (n_trav) atomic_add_u32(&s_trav, (uint32_t)n_trav);
+        uint32_t nm = (uint32_t)n_members, nt = (uint32_t)n_trav;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { nm += __shfl_xor(nm, d); nt += __shfl_xor(nt, d); }
+        if ((tid & 63) == 0) { if (nm) atomic_add_u32(&s_members, nm); if (nt) atomic_add_u32(&s_trav, nt); }
         __syncthreads();
         if (tid == 0 && s_members) { atomic_add_u64(&P.stats[0], (uint64_t)s_members); atomic_add_u64(&P.stats[1], (uint64_t)s_trav); }
     }

@@ -1,0 +1,235 @@
+// k_scan_fast.h -- stage 1a, instruction-lean variant of k_scan (same records, same rules).
+//
+// Profiling k_scan on MI355X (profiles/) showed the scan was not atomic- or HBM-bound but
+// issue-bound: ~600 instructions per junction.  This variant keeps the tile in LDS but gives
+// every lane 16 CONSECUTIVE positions so that per-position work becomes incremental:
+//   A  encode 16 bases per lane with SIMD-in-register tricks (4 bases per multiply)
+//   B  rolling canonical m-mer + validity run length -> ordering key (one hash per position)
+//   C  window minimum over k-m keys from a register window (no LDS ping-pong, no barriers)
+//   D  validity / run-break bits from a 64-bit validity window, written as 16-bit words
+//   E  run starts are compacted into an LDS list (popcount prefix over the workgroup), then
+//      every lane handles ONE run: end search, boundary (home / traveller) rules, records.
+// Used when k-m <= SCANF_WNMAX and k <= 48 (all W=1 cases, k=55 with m >= 7); k_scan remains
+// the generic path.  Tile-local index q: byte (tile_start - 16 + q); junction jq <-> q = 15+jq.
+#pragma once
+#include "k_scan.h"
+
+namespace cdbg {
+
+constexpr int SCANF_TILE = 4064;                       // junctions per workgroup (254 x 16)
+constexpr int SCANF_WNMAX = 48;                        // largest k-m handled by the register window
+constexpr int SCANF_NQ = 4400;                         // tile-local positions held in LDS
+constexpr int SCANF_PKW = SCANF_NQ / 16 + 5;           // packed words (16 bases each) incl. over-read
+CDBG_DEV int scanf_pad(int q) { return q + (q >> 4); } // 17-word stride: conflict-free 16-per-lane access
+
+// 4 ASCII bases (little-endian in x) -> 8 bits, first base on top; and 4 validity bits (bit j = byte j)
+CDBG_DEV uint32_t scanf_enc4(uint32_t x, uint32_t& vbits) {
+    const uint32_t t = ((x >> 1) ^ (x >> 2)) & 0x03030303u;             // 2-bit code per byte
+    // expected upper-case letter of each code: "ACGT"[code]
+    const uint32_t e = ((t & 0x01010101u) * 2u) + ((t & 0x02020202u) * 3u) + 0x41414141u
+                     + (((t >> 1) & t & 0x01010101u) * 11u);              // 0:A(41) 1:C(43) 2:G(47) 3:T(54)
+    const uint32_t d = e ^ (x & 0xDFDFDFDFu);                              // zero byte <=> valid base
+    const uint32_t z = ~((((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d)) & 0x80808080u;
+    vbits = (((z >> 7) * 0x01020408u) >> 24) & 0xFu;                       // bit j <- byte j
+    return (t * 0x40100401u) >> 24;                                        // b0<<6 | b1<<4 | b2<<2 | b3
+}
+
+template <int W, bool EMIT>
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
+    constexpr int RW = RecFmt<W>::RW;
+    constexpr int CAPB = RecFmt<W>::CAPB;
+    CDBG_SHARED uint32_t pk[SCANF_PKW];
+    CDBG_SHARED uint32_t vm[SCANF_PKW / 2 + 4];
+    CDBG_SHARED uint32_t kg[SCANF_NQ + SCANF_NQ / 16 + 32];   // keys, then g (padded layout)
+    CDBG_SHARED uint32_t brk[SCANF_NQ / 32 + 4];              // bit q: junction q does not continue a run
+    CDBG_SHARED uint32_t stt[SCANF_NQ / 32 + 4];              // bit q: junction q starts a run
+    CDBG_SHARED uint16_t sl[SCANF_TILE + 16];                 // compacted run starts
+    CDBG_SHARED uint32_t s_wsum[SCAN_THREADS / 64], s_nstart, s_members, s_trav;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = P.k, m = P.m, WN = k - m;
+    const int64_t t0 = (int64_t)blockIdx.x * SCANF_TILE;
+    const int64_t base = t0 - 16;
+
+    // ---- A. load + encode ----
+    for (int w = tid; w < SCANF_PKW; w += SCAN_THREADS) {
+        const int64_t off = base + 16 * (int64_t)w;
+        uint32_t packed = 0, vbits = 0;
+        if (off >= 0 && off < (int64_t)P.nbytes_padded) {
+            const uint4 v = *reinterpret_cast<const uint4*>(P.reads + off);
+            uint32_t v0, v1, v2, v3;
+            packed = (scanf_enc4(v.x, v0) << 24) | (scanf_enc4(v.y, v1) << 16) | (scanf_enc4(v.z, v2) << 8) | scanf_enc4(v.w, v3);
+            vbits = v0 | (v1 << 4) | (v2 << 8) | (v3 << 12);
+        }
+        pk[w] = packed;
+        reinterpret_cast<uint16_t*>(vm)[w] = (uint16_t)vbits;
+    }
+    if (tid < 4) vm[SCANF_PKW / 2 + tid] = 0;
+    if (SCANF_PKW & 1) { if (tid == 4) reinterpret_cast<uint16_t*>(vm)[SCANF_PKW] = 0; }
+    if (tid == 0) { s_nstart = 0; s_members = 0; s_trav = 0; }
+    __syncthreads();
+
+    // ---- B. rolling m-mer keys: lane chunk c covers m-mer starts [16c, 16c+16) ----
+    const int nq_keys = 15 + SCANF_TILE + 2 + WN;          // keys needed for q < nq_keys
+    const uint32_t mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+    for (int c = tid; 16 * c < nq_keys; c += SCAN_THREADS) {
+        const uint32_t w0 = pk[c], w1 = pk[c + 1];
+        const uint32_t vv = (uint32_t)reinterpret_cast<const uint16_t*>(vm)[c] | ((uint32_t)reinterpret_cast<const uint16_t*>(vm)[c + 1] << 16);
+        uint32_t fw = 0, rc = 0; int run = 0;
+#pragma unroll
+        for (int p = 0; p < 31; ++p) {                     // base index 16c + p
+            const uint32_t b = ((p < 16 ? w0 : w1) >> (30 - 2 * (p & 15))) & 3u;
+            fw = ((fw << 2) | b) & mmask;
+            rc = (rc >> 2) | ((3u - b) << (2 * (m - 1)));
+            run = ((vv >> p) & 1u) ? run + 1 : 0;
+            const int s = p - (m - 1);                     // m-mer start completed by base p
+            if (s >= 0 && s < 16) kg[scanf_pad(16 * c + s)] = run >= m ? mix32(rc < fw ? rc : fw) : 0xFFFFFFFFu;
+        }
+    }
+    __syncthreads();
+
+    // ---- C. g[q] = min of keys[q .. q+WN-1], 16 junctions per lane from a register window ----
+    // ---- D. validity and run-break bits ----
+    uint32_t gq[16];
+    const int nchunk_g = (15 + SCANF_TILE + 2 + 15) / 16;   // chunks containing junction q <= TILE+16
+    for (int c = tid; c < nchunk_g; c += SCAN_THREADS) {    // (one iteration: nchunk_g <= 256)
+        uint32_t a[16 + SCANF_WNMAX - 1];
+#pragma unroll
+        for (int i = 0; i < 16 + SCANF_WNMAX - 1; ++i) a[i] = (i < 16 + WN - 1) ? kg[scanf_pad(16 * c + i)] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) gq[j] = a[j];
+#pragma unroll
+        for (int w = 1; w < SCANF_WNMAX; ++w) {
+            if (w < WN) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) gq[j] = gq[j] < a[j + w] ? gq[j] : a[j + w];
+            }
+        }
+    }
+    __syncthreads();                                        // every lane has read its keys
+    if (tid < nchunk_g) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) kg[scanf_pad(16 * tid + j)] = gq[j];
+    }
+    __syncthreads();
+    {
+        // validity window: bit i <-> base 16*tid + i - 16 (i.e. starts one chunk earlier, for q-1 tests)
+        const int c = tid;
+        uint32_t brk16 = 0, stt16 = 0;
+        if (c >= 1 && c <= SCANF_TILE / 16) {               // own junctions: q in [16, 16+TILE)
+            const uint16_t* v16 = reinterpret_cast<const uint16_t*>(vm);
+            const uint64_t lo = (uint64_t)v16[c - 1] | ((uint64_t)v16[c] << 16) | ((uint64_t)v16[c + 1] << 32) | ((uint64_t)v16[c + 2] << 48);
+            const uint64_t hi = (uint64_t)v16[c + 3] | ((uint64_t)v16[c + 4] << 16);
+            const uint64_t jm = (1ULL << (k - 1)) - 1ULL;   // k-1 <= 47 bits
+            const uint32_t gprev = kg[scanf_pad(16 * c - 1)];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                // junction q = 16c + j <-> window bit 16 + j; junction q-1 <-> bit 15 + j
+                const uint64_t wq = (lo >> (16 + j)) | (hi << (48 - j));
+                const uint64_t wp = (lo >> (15 + j)) | (hi << (49 - j));
+                const bool v = (wq & jm) == jm;
+                const bool vp = (wp & jm) == jm;
+                const uint32_t gp = j ? gq[j - 1] : gprev;
+                const bool cont = v && vp && gq[j] == gp && !(c == 1 && j == 0);
+                brk16 |= (cont ? 0u : 1u) << j;
+                stt16 |= ((v && !cont) ? 1u : 0u) << j;
+            }
+        } else {
+            brk16 = 0xFFFFu;                                // outside the tile's own junctions: always a break
+        }
+        reinterpret_cast<uint16_t*>(brk)[c] = (uint16_t)brk16;
+        reinterpret_cast<uint16_t*>(stt)[c] = (uint16_t)stt16;
+        if (tid < 24) reinterpret_cast<uint16_t*>(brk)[SCAN_THREADS + tid] = 0xFFFFu;   // sentinels past the tile
+
+        // ---- E1. compact the run starts into sl[] ----
+        const int cnt = __popc(stt16);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int x = __shfl_up(incl, d); if (lane >= d) incl += x; }
+        if (lane == 63) s_wsum[wave] = (uint32_t)incl;
+        __syncthreads();
+        int off = incl - cnt;
+        for (int w = 0; w < wave; ++w) off += (int)s_wsum[w];
+        uint32_t bits = stt16;
+        while (bits) { const int j = __ffs((int)bits) - 1; bits &= bits - 1; sl[off++] = (uint16_t)(16 * c + j); }
+        if (tid == SCAN_THREADS - 1) s_nstart = (uint32_t)off;
+    }
+    __syncthreads();
+
+    // ---- E2. one lane per run ----
+    const int NMAX = CAPB - k + 1;
+    const uint32_t rank_mask = (1u << P.rank_bits) - 1u;
+    const uint64_t km = (1ULL << k) - 1ULL;                 // k <= 48
+    uint32_t n_members = 0, n_trav = 0;
+    const int nstart = (int)s_nstart;
+    for (int i = tid; i < nstart; i += SCAN_THREADS) {
+        const int s = sl[i];                                // run = junctions [s, e] in q space
+        const uint32_t g0 = kg[scanf_pad(s)];
+        const uint32_t part = part_of(g0, P.log_np);
+        if ((part & rank_mask) != (uint32_t)P.rank) continue;
+        const uint32_t lpart = part >> P.rank_bits;
+        int e;
+        {
+            int nb = s + 1;
+            uint32_t wv = brk[nb >> 5] >> (nb & 31);
+            if (wv) e = nb + __ffs((int)wv) - 1;
+            else { int wi = (nb >> 5) + 1; while (brk[wi] == 0) ++wi; e = wi * 32 + __ffs((int)brk[wi]) - 1; }
+            e -= 1;                                         // last junction of the run
+            if (e > 15 + SCANF_TILE) e = 15 + SCANF_TILE;
+        }
+        // validity of the boundary k-mers: k-mer at q-1 (right junction s) and k-mer at e (left junction e)
+        bool first_incl = false, first_trav = false, last_incl = false, last_trav = false;
+        if (scan_all_valid(vm, s - 1, k)) {
+            const uint32_t g2 = kg[scanf_pad(s - 1)];
+            if (g0 < g2) first_incl = true;
+            else if (part_of(g2, P.log_np) != part) { first_incl = true; first_trav = true; }
+        }
+        if (scan_all_valid(vm, e, k)) {
+            const uint32_t g2 = kg[scanf_pad(e + 1)];
+            if (g0 < g2) last_incl = true;
+            else if (part_of(g2, P.log_np) != part) { last_incl = true; last_trav = true; }
+            else if (g0 == g2) last_incl = true;
+        }
+        (void)km;
+        int c = s; bool firstchunk = true;
+        while (c <= e) {
+            const int ms = (firstchunk && first_incl) ? c - 1 : c;
+            int ce = ms + NMAX - 1; if (ce > e) ce = e;
+            const int me = (ce == e && !last_incl) ? e - 1 : ce;
+            const int n = me - ms + 1;
+            if (n > 0) {
+                uint32_t meta = (uint32_t)n;
+                const bool ft = firstchunk && first_incl && first_trav;
+                const bool lt = (ce == e) && last_incl && last_trav;
+                if (ft) meta |= 0x100u;
+                if (lt) meta |= 0x200u;
+                if (EMIT) {
+                    const uint64_t slot = atomic_add_u64(&P.part_cursor[lpart], 1ULL);
+                    uint64_t* dst = P.records + slot * RW;
+                    const int bitoff = 2 * ms;
+#pragma unroll
+                    for (int wv = 0; wv < RW; ++wv) {
+                        uint64_t x = scan_get64(pk, bitoff + 64 * wv);
+                        if (wv == RW - 1) x = (x & ~0xFFFFULL) | meta;
+                        dst[RW - 1 - wv] = x;
+                    }
+                } else {
+                    atomic_add_u32(&P.part_count[lpart], 1u);
+                }
+                n_members += (uint32_t)n;
+                n_trav += (ft ? 1u : 0u) + (lt ? 1u : 0u);
+            }
+            firstchunk = false;
+            c = ce + 1;
+        }
+    }
+    if (!EMIT) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { n_members += __shfl_xor(n_members, d); n_trav += __shfl_xor(n_trav, d); }
+        if (lane == 0) { if (n_members) atomic_add_u32(&s_members, n_members); if (n_trav) atomic_add_u32(&s_trav, n_trav); }
+        __syncthreads();
+        if (tid == 0 && s_members) { atomic_add_u64(&P.stats[0], (uint64_t)s_members); atomic_add_u64(&P.stats[1], (uint64_t)s_trav); }
+    }
+}
+
+}  // namespace cdbg

@@ -129,10 +129,12 @@ struct Kmer {
         Kmer r = rc(k);
         return (r < *this) ? r : *this;
     }
+    // multiply-shift hash: the high half of a 64-bit product depends on every input bit
     CDBG_HD uint32_t hash() const {
-        uint64_t h = 0;
-        for (int i = 0; i < W; ++i) h = mix64(h ^ w[i]);
-        return (uint32_t)(h >> 17);
+        uint64_t a = w[0];
+        for (int i = 1; i < W; ++i) a = (a ^ (a >> 29)) * 0xBF58476D1CE4E5B9ULL + w[i];
+        a ^= a >> 32;
+        return (uint32_t)((a * 0x9E3779B97F4A7C15ULL) >> 32);
     }
 };
 
