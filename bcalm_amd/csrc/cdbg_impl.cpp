@@ -93,7 +93,7 @@ struct cdbg_ctx {
     std::vector<char> host_text;                 // pushed reads awaiting upload
     DBuf<uint8_t> reads; uint64_t nbytes = 0, nbytes_padded = 0;
 
-    DBuf<uint32_t> part_count; DBuf<uint64_t> part_off, part_cursor, records;
+    DBuf<uint32_t> part_count; DBuf<uint64_t> part_off, part_cursor, records, exscan_tmp;
     DBuf<uint64_t> dstats; DBuf<uint32_t> derr;
     DBuf<uint64_t> solid_keys; DBuf<uint32_t> solid_cnt; DBuf<uint64_t> solid_cursor, seg_off; DBuf<uint32_t> seg_n;
     DBuf<uint32_t> big_list, big_count;
@@ -101,6 +101,7 @@ struct cdbg_ctx {
 
     DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
     DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_state, glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;
+    DBuf<uint64_t> glog_keys; DBuf<uint32_t> glog_tag; uint64_t glog_cap = 0, n_glog = 0;
     uint64_t n_pieces = 0, n_piece_bases = 0;
 
     DBuf<uint64_t> unitig_off; DBuf<uint32_t> unitig_len; DBuf<uint64_t> unitig_kc; DBuf<uint8_t> unitig_bases;
@@ -132,7 +133,7 @@ int read_u32(const uint32_t* dptr, uint32_t* out, size_t n = 1) {
 }
 int check_device_error(cdbg_ctx* c, const char* where) {
     uint32_t e = 0; CK(read_u32(c->derr.p, &e));
-    if (e) return fail(CDBG_E_INTERNAL, "%s: device reported error %u (1 solid overflow, 2 scratch sizing, 3 piece overflow, 4 unitig overflow)", where, e);
+    if (e) return fail(CDBG_E_INTERNAL, "%s: device reported error %u (1 solid overflow, 2 scratch sizing, 3 piece overflow, 4 unitig overflow, 5 glue log overflow)", where, e);
     HIPCK(hipGetLastError());
     return CDBG_OK;
 }
@@ -196,7 +197,13 @@ int count_impl(cdbg_ctx* c) {
     Timer t; CK(t.start(s));
     if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, false>), tiles, SCAN_THREADS, s, sp);
     else CDBG_LAUNCH((k_scan<W, false>), tiles, SCAN_THREADS, s, sp);
-    CDBG_LAUNCH(k_exscan, 1, EXSCAN_THREADS, s, (const uint32_t*)c->part_count.p, c->part_off.p, NPL);
+    {
+        const uint64_t nb = (NPL + EXSCAN_BLOCK - 1) / EXSCAN_BLOCK;
+        CK(c->exscan_tmp.alloc(nb + 1, false));
+        CDBG_LAUNCH(k_exscan_sums, nb, EXSCAN_THREADS, s, (const uint32_t*)c->part_count.p, c->exscan_tmp.p, NPL);
+        CDBG_LAUNCH(k_exscan_top, 1, EXSCAN_THREADS, s, c->exscan_tmp.p, nb, c->part_off.p + NPL);
+        CDBG_LAUNCH(k_exscan_apply, nb, EXSCAN_THREADS, s, (const uint32_t*)c->part_count.p, (const uint64_t*)c->exscan_tmp.p, c->part_off.p, NPL);
+    }
     CK(t.stop(&c->st.ms_scan_hist));
     uint64_t n_records = 0; CK(read_u64(c->part_off.p + NPL, &n_records));
     uint64_t hs[2] = {0, 0}; CK(read_u64(c->dstats.p, hs, 2));
@@ -287,6 +294,9 @@ int compact_impl(cdbg_ctx* c) {
     CK(c->glue_state.alloc(c->glue_cap, false));
     CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
     CK(c->cursors.alloc(8, false));
+    // glue log: <= 2 open ends + 1 confirm per junction, one junction per solid traveller at most
+    c->glog_cap = 3 * c->st.n_solid_travellers + (PERSISTENT_GRID + 1) * (uint64_t)GLOG_CHUNK + 64;
+    CK(c->glog_keys.alloc(c->glog_cap * W, false)); CK(c->glog_tag.alloc(c->glog_cap, false));
 
     for (int attempt = 0; attempt < 2; ++attempt) {
         const uint64_t pslack = (PERSISTENT_GRID + 1) * (uint64_t)PIECE_CHUNK, bslack = (PERSISTENT_GRID + 1) * (uint64_t)BASES_CHUNK;
@@ -296,6 +306,7 @@ int compact_impl(cdbg_ctx* c) {
         CK(c->piece_kc.alloc(pcap, false)); CK(c->piece_boff.alloc(pcap, false));
         CK(c->piece_bases.alloc(bcap, false));
         HIPCK(hipMemsetAsync(c->cursors.p, 0, 8 * sizeof(uint64_t), s));
+        HIPCK(hipMemsetAsync(c->glog_tag.p, 0xFF, c->glog_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), s));
         HIPCK(hipMemsetAsync(c->glue_state.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
@@ -312,6 +323,7 @@ int compact_impl(cdbg_ctx* c) {
         kp.piece_cap = pcap; kp.bases_cap = bcap; kp.piece_cursor = c->cursors.p; kp.bases_cursor = c->cursors.p + 1;
         kp.glue_keys = c->glue_keys.p; kp.glue_state = c->glue_state.p; kp.glue_a = c->glue_a.p; kp.glue_b = c->glue_b.p;
         kp.glue_conf = c->glue_conf.p; kp.glue_mask = c->glue_cap - 1;
+        kp.glog_keys = c->glog_keys.p; kp.glog_tag = c->glog_tag.p; kp.glog_cap = c->glog_cap; kp.glog_cursor = c->cursors.p + 4;
         kp.big_list = c->big_list.p; kp.big_count = c->big_count.p; kp.error = c->derr.p; kp.stats = c->dstats.p;
         kp.n_items = (uint32_t)NPL;
         CDBG_LAUNCH((k_compact<W, TS, false>), std::min<uint64_t>(NPL, PERSISTENT_GRID), COMPACT_THREADS, s, kp);
@@ -346,9 +358,12 @@ int compact_impl(cdbg_ctx* c) {
     }
     CK(t.stop(&c->st.ms_compact));
     CK(check_device_error(c, "compact"));
-    uint64_t cur[2]; CK(read_u64(c->cursors.p, cur, 2));
-    c->n_pieces = cur[0]; c->n_piece_bases = cur[1];
+    uint64_t cur[5]; CK(read_u64(c->cursors.p, cur, 5));
+    c->n_pieces = cur[0]; c->n_piece_bases = cur[1]; c->n_glog = cur[4];
     uint64_t ks[4]; CK(read_u64(c->dstats.p, ks, 4));
+#ifdef CDBG_PROFILE_PHASES
+    { uint64_t ph[8]; CK(read_u64(c->dstats.p + 8, ph, 8)); fprintf(stderr, "k_compact phase ticks: seg_n %llu clear+load %llu classify %llu walk1 %llu cycles+reserve %llu walk2+glue %llu\n", (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3], (unsigned long long)ph[4], (unsigned long long)ph[5]); }
+#endif
     c->st.n_pieces = ks[3]; c->st.n_glue_open_ends = ks[0]; c->st.n_cycles = ks[2];
     c->st.ms_total += c->st.ms_compact;
     c->stage = 2;
@@ -371,6 +386,10 @@ int glue_impl(cdbg_ctx* c) {
     HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
     HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
 
+    {   // build the junction table from the glue log (dense lanes => device atomics at throughput)
+        GlueBuildParams bp{ c->glog_keys.p, c->glog_tag.p, c->n_glog, c->glue_keys.p, c->glue_state.p, c->glue_a.p, c->glue_b.p, c->glue_conf.p, c->glue_cap - 1 };
+        if (c->n_glog) CDBG_LAUNCH((k_glue_build<W>), std::min<uint64_t>((c->n_glog + GLUE_THREADS - 1) / GLUE_THREADS, MAX_GRID), GLUE_THREADS, s, bp);
+    }
     GlueResolveParams gp{};
     gp.keys = c->glue_keys.p; gp.state = c->glue_state.p; gp.a = c->glue_a.p; gp.b = c->glue_b.p; gp.conf = c->glue_conf.p;
     gp.cap = c->glue_cap; gp.W = W; gp.link = link.p; gp.stats = c->dstats.p;

@@ -30,6 +30,10 @@ namespace cdbg {
 constexpr int COMPACT_THREADS = 256;
 constexpr uint32_t PIECE_CHUNK = 4096, BASES_CHUNK = 1u << 18;   // per-workgroup reservations (one device atomic each)
 constexpr uint32_t LNK_DEAD = 0, LNK_INTERNAL = 1, LNK_OPEN = 2;
+constexpr uint32_t LNK_CONF = 1u << 30;                 // this end's junction is 1-1 with a traveller: post CONFIRM
+constexpr uint32_t LNK_POSTED = 1u << 31;               // open piece end; low 31 bits = piece-end id
+constexpr uint32_t GLOG_CHUNK = 8192;                   // glue-log records a workgroup reserves per device atomic
+constexpr uint32_t GTAG_EMPTY = 0xFFFFFFFFu, GTAG_CONFIRM = 0xFFFFFFFEu;
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr uint32_t END_LEFT = 0, END_RIGHT = 1;
 
@@ -62,6 +66,8 @@ struct CompactParams {
     uint64_t* piece_cursor; uint64_t* bases_cursor;
     // glue table (HBM)
     uint64_t* glue_keys; uint32_t* glue_state; uint32_t* glue_a; uint32_t* glue_b; uint32_t* glue_conf; uint32_t glue_mask;
+    // glue log: (junction key, tag) records; tag = piece-end id, GTAG_CONFIRM, or GTAG_EMPTY (pre-filled)
+    uint64_t* glog_keys; uint32_t* glog_tag; uint64_t glog_cap; uint64_t* glog_cursor;
     uint32_t* big_list; uint32_t* big_count; uint32_t* error;
     uint64_t* stats;               // [0] open ends posted [1] confirms posted [2] in-bucket cycles [3] pieces written
     // HBM scratch (GLOBAL variant)
@@ -96,19 +102,22 @@ CDBG_DEV int probe_succ(const KTable<W>& T, const Kmer<W>& u, int k, uint32_t& s
 
 template <int W, int TS, bool GLOBAL>
 CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64_t (&acc)[4],
-                             uint64_t& pc_base, uint32_t& pc_left, uint64_t& bc_base, uint32_t& bc_left) {
+                             uint64_t& pc_base, uint32_t& pc_left, uint64_t& bc_base, uint32_t& bc_left,
+                             uint64_t& lc_base, uint32_t& lc_left, uint64_t (&ph)[8], uint64_t& t_prev) {
     CDBG_SHARED uint64_t l_keys[GLOBAL ? 1 : TS * W];
     CDBG_SHARED uint32_t l_state[(GLOBAL || W == 1) ? 1 : TS];
     CDBG_SHARED uint32_t l_cnt[GLOBAL ? 1 : TS];
     CDBG_SHARED uint32_t l_lnk[GLOBAL ? 1 : 2 * TS];
     CDBG_SHARED uint32_t l_aux[GLOBAL ? 1 : 2 * TS];   // [0,cap): visited flags; [cap, 1.5cap): piece starts; [1.5cap, 2cap): entry slots
     CDBG_SHARED uint32_t s_np, s_nb, s_stat[4];
-    CDBG_SHARED uint64_t s_pbase, s_bbase;
+    CDBG_SHARED uint64_t s_pbase, s_bbase, s_lbase;
+    CDBG_SHARED uint32_t s_nopen, s_lw;
 
     const int tid = threadIdx.x;
     const int k = P.k;
     const uint32_t p = P.part_list ? P.part_list[item] : item;
     const uint32_t E = P.seg_n[p];
+    CDBG_PH(0);
     if (E == 0) return;
 
     KTable<W> T; uint32_t *cnt, *lnk, *vis, *pdesc, *slots; uint32_t cap;
@@ -127,7 +136,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
     slots = pdesc + cap / 2;                             // E <= cap/2 entries, <= cap/2 pieces
     const uint32_t pg = (p << P.rank_bits) | (uint32_t)P.rank;     // global partition id of this bucket
 
-    if (tid == 0) { s_np = 0; s_nb = 0; s_stat[0] = s_stat[1] = s_stat[2] = s_stat[3] = 0; }
+    if (tid == 0) { s_np = 0; s_nb = 0; s_nopen = 0; s_lw = 0; s_stat[0] = s_stat[1] = s_stat[2] = s_stat[3] = 0; }
     ktable_clear<W>(T, tid, COMPACT_THREADS);
     for (uint32_t i = tid; i < cap; i += COMPACT_THREADS) vis[i] = 0;
     __syncthreads();
@@ -142,6 +151,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         slots[e] = s;
     }
     __syncthreads();
+    CDBG_PH(1);
 
     // ---- classify both ends of every entry ----
     for (uint32_t it = tid; it < 2 * E; it += COMPACT_THREADS) {
@@ -150,7 +160,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         const Kmer<W> x = ktable_key<W>(T, s);
         const Kmer<W> u = orient_out<W>(x, end, k);
         const Kmer<W> jc = canon_junction<W>(u, k);
-        uint32_t link = LNK_DEAD;
+        uint32_t link = LNK_DEAD; bool conf = false;
         if (part_of(junction_min<W>(jc, k, P.m), P.log_np) != pg) {
             link = LNK_OPEN;                             // junction owned elsewhere: glue decides
         } else {
@@ -162,15 +172,16 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
                     if (home && yhome) link = LNK_INTERNAL | (ye << 2) | (y << 3);
                     else {
                         // 1-1 junction with a traveller on at least one side: confirm it for glue (once)
-                        if (home || (!yhome && s < y)) { glue_post_confirm<W>(GlueTable<W>{ { P.glue_keys, P.glue_state, P.glue_mask }, P.glue_a, P.glue_b, P.glue_conf }, jc); atomic_add_u32(&s_stat[1], 1u); }
+                        if (home || (!yhome && s < y)) { conf = true; atomic_add_u32(&s_stat[1], 1u); }
                         if (home) link = LNK_OPEN;
                     }
                 }
             }
         }
-        if (home) lnk[idx] = link; else lnk[idx] = LNK_DEAD;
+        lnk[idx] = (home ? link : LNK_DEAD) | (conf ? LNK_CONF : 0u);
     }
     __syncthreads();
+    CDBG_PH(2);
 
     // ---- walk 1: every terminal end measures its piece; the smaller terminal id registers it ----
     for (uint32_t it = tid; it < 2 * E; it += COMPACT_THREADS) {
@@ -190,9 +201,12 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
             const uint32_t li = atomic_add_u32(&s_np, 1u);
             pdesc[li] = idx;                             // start terminal (bit 31 clear: linear piece)
             atomic_add_u32(&s_nb, n + (uint32_t)k - 1u);
+            const uint32_t no = ((lnk[idx] & 3u) == LNK_OPEN ? 1u : 0u) + ((lnk[other] & 3u) == LNK_OPEN ? 1u : 0u);
+            if (no) atomic_add_u32(&s_nopen, no);
         }
     }
     __syncthreads();
+    CDBG_PH(3);
     // ---- closed chains entirely inside the bucket (isolated cycles): cut at the smallest slot ----
     for (uint32_t it = tid; it < E; it += COMPACT_THREADS) {
         const uint32_t s = slots[it];
@@ -221,14 +235,32 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         if (s_nb > BASES_CHUNK) bb = atomic_add_u64(P.bases_cursor, (uint64_t)s_nb);
         else { if (s_nb > bc_left) { bc_base = atomic_add_u64(P.bases_cursor, (uint64_t)BASES_CHUNK); bc_left = BASES_CHUNK; }
                bb = bc_base; bc_base += s_nb; bc_left -= s_nb; }
+        const uint32_t nlog = s_stat[1] + s_nopen;       // confirms + open piece ends
+        uint64_t lb;
+        if (nlog > GLOG_CHUNK) lb = atomic_add_u64(P.glog_cursor, (uint64_t)nlog);
+        else { if (nlog > lc_left) { lc_base = atomic_add_u64(P.glog_cursor, (uint64_t)GLOG_CHUNK); lc_left = GLOG_CHUNK; }
+               lb = lc_base; lc_base += nlog; lc_left -= nlog; }
         if (pb + s_np > P.piece_cap || bb + s_nb > P.bases_cap) { *P.error = 3; s_np = 0; }
-        s_pbase = pb; s_bbase = bb; s_nb = 0;
+        if (lb + nlog > P.glog_cap) { *P.error = 5; s_np = 0; }
+        s_pbase = pb; s_bbase = bb; s_lbase = lb; s_nb = 0;
     }
     __syncthreads();
 
-    // ---- walk 2: one lane per piece writes bases, size, abundance and posts its open ends ----
+    CDBG_PH(4);
+    // ---- glue log, part 1: CONFIRM records (dense over all ends; no device atomics) ----
     const uint32_t np = s_np;
-    const GlueTable<W> G{ { P.glue_keys, P.glue_state, P.glue_mask }, P.glue_a, P.glue_b, P.glue_conf };
+    if (np || s_stat[1]) {
+        for (uint32_t it = tid; it < 2 * E; it += COMPACT_THREADS) {
+            const uint32_t s = slots[it >> 1], end = it & 1u;
+            if (!(lnk[s * 2 + end] & LNK_CONF)) continue;
+            const uint64_t o = s_lbase + atomic_add_u32(&s_lw, 1u);
+            const Kmer<W> jc = canon_junction<W>(orient_out<W>(ktable_key<W>(T, s), end, k), k);
+            for (int i = 0; i < W; ++i) P.glog_keys[o * W + i] = jc.w[i];
+            P.glog_tag[o] = GTAG_CONFIRM;
+        }
+    }
+    __syncthreads();
+    // ---- walk 2: one lane per piece writes bases, size, abundance and marks its open ends ----
     for (uint32_t li = tid; li < np; li += COMPACT_THREADS) {
         const uint32_t d = pdesc[li];
         const bool cyclic = d & 0x80000000u;
@@ -259,29 +291,69 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         P.piece_n[pid] = n; P.piece_kc[pid] = kc; P.piece_boff[pid] = boff;
         if (!cyclic) {
             // left end of the piece = start terminal (s0, e0); right end = (cur, ex)
-            if ((lnk[s0 * 2 + e0] & 3u) == LNK_OPEN) {
-                glue_post_end<W>(G, canon_junction<W>(orient_out<W>(ktable_key<W>(T, s0), e0, k), k), (uint32_t)(pid * 2 + 0));
-                atomic_add_u32(&s_stat[0], 1u);
-            }
-            if ((lnk[cur * 2 + ex] & 3u) == LNK_OPEN) {
-                glue_post_end<W>(G, canon_junction<W>(orient_out<W>(ktable_key<W>(T, cur), ex, k), k), (uint32_t)(pid * 2 + 1));
-                atomic_add_u32(&s_stat[0], 1u);
-            }
+            const uint32_t il = s0 * 2 + e0, ir = cur * 2 + ex;
+            const bool ol = (lnk[il] & 3u) == LNK_OPEN, orr = (lnk[ir] & 3u) == LNK_OPEN;
+            if (ol) lnk[il] = LNK_POSTED | (uint32_t)(pid * 2 + 0);
+            if (orr) lnk[ir] = LNK_POSTED | (uint32_t)(pid * 2 + 1);
         }
     }
     __syncthreads();
+    // ---- glue log, part 2: one record per open piece end (dense over all ends) ----
+    if (np) {
+        uint32_t my_open = 0;
+        for (uint32_t it = tid; it < 2 * E; it += COMPACT_THREADS) {
+            const uint32_t s = slots[it >> 1], end = it & 1u;
+            const uint32_t l = lnk[s * 2 + end];
+            if (!(l & LNK_POSTED)) continue;
+            const uint64_t o = s_lbase + atomic_add_u32(&s_lw, 1u);
+            const Kmer<W> jc = canon_junction<W>(orient_out<W>(ktable_key<W>(T, s), end, k), k);
+            for (int i = 0; i < W; ++i) P.glog_keys[o * W + i] = jc.w[i];
+            P.glog_tag[o] = l & 0x7FFFFFFFu;
+            ++my_open;
+        }
+        if (my_open) atomic_add_u32(&s_stat[0], my_open);
+    }
+    __syncthreads();
+    CDBG_PH(5);
     if (tid == 0) for (int i = 0; i < 4; ++i) acc[i] += (uint64_t)s_stat[i];
 }
 
 template <int W, int TS, bool GLOBAL>
 __global__ void __launch_bounds__(COMPACT_THREADS) k_compact(CompactParams P) {
     uint64_t acc[4] = {0, 0, 0, 0};
-    uint64_t pc_base = 0, bc_base = 0; uint32_t pc_left = 0, bc_left = 0;
+    uint64_t pc_base = 0, bc_base = 0, lc_base = 0; uint32_t pc_left = 0, bc_left = 0, lc_left = 0;
+    uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_prev = 0;
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+    t_prev = wall_clock64();
+#endif
     for (uint32_t item = blockIdx.x; item < P.n_items; item += gridDim.x) {
-        compact_bucket<W, TS, GLOBAL>(P, item, acc, pc_base, pc_left, bc_base, bc_left);
+        compact_bucket<W, TS, GLOBAL>(P, item, acc, pc_base, pc_left, bc_base, bc_left, lc_base, lc_left, ph, t_prev);
         __syncthreads();                                 // LDS is reused by the next bucket
     }
     if (threadIdx.x == 0) for (int i = 0; i < 4; ++i) if (acc[i]) atomic_add_u64(&P.stats[i], acc[i]);
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+    if (threadIdx.x == 0) for (int i = 0; i < 8; ++i) if (ph[i]) atomic_add_u64(&P.stats[8 + i], ph[i]);
+#endif
+}
+
+// ---- glue table construction from the log: one lane per record, every lane busy, so the device
+// atomics run at throughput instead of paying their latency inside the per-bucket kernel ----
+struct GlueBuildParams {
+    const uint64_t* glog_keys; const uint32_t* glog_tag; uint64_t n_records;
+    uint64_t* glue_keys; uint32_t* glue_state; uint32_t* glue_a; uint32_t* glue_b; uint32_t* glue_conf; uint32_t glue_mask;
+};
+template <int W>
+__global__ void k_glue_build(GlueBuildParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const GlueTable<W> G{ { P.glue_keys, P.glue_state, P.glue_mask }, P.glue_a, P.glue_b, P.glue_conf };
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n_records; i += stride) {
+        const uint32_t tag = P.glog_tag[i];
+        if (tag == GTAG_EMPTY) continue;
+        Kmer<W> jc;
+        for (int j = 0; j < W; ++j) jc.w[j] = P.glog_keys[i * W + j];
+        if (tag == GTAG_CONFIRM) glue_post_confirm<W>(G, jc);
+        else glue_post_end<W>(G, jc, tag);
+    }
 }
 
 }  // namespace cdbg

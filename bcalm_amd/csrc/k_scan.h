@@ -285,25 +285,54 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     }
 }
 
-// ---- exclusive prefix sum of n uint32 counts into n+1 uint64 offsets (single workgroup) ----
+// ---- exclusive prefix sum of n uint32 counts into n+1 uint64 offsets ----
+// three launches: per-block sums, scan of the block sums (one workgroup), block-local scan + base
 constexpr int EXSCAN_THREADS = 1024;
-__global__ void __launch_bounds__(EXSCAN_THREADS) k_exscan(const uint32_t* cnt, uint64_t* off, uint64_t n) {
-    CDBG_SHARED uint64_t part[EXSCAN_THREADS];
-    const uint64_t tid = threadIdx.x;
-    const uint64_t chunk = (n + EXSCAN_THREADS - 1) / EXSCAN_THREADS;
-    const uint64_t lo = tid * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-    uint64_t s = 0;
-    for (uint64_t i = lo; i < hi; ++i) s += cnt[i];
-    part[tid] = s;
+constexpr int EXSCAN_ITEMS = 4;                          // consecutive counts per lane
+constexpr int EXSCAN_BLOCK = EXSCAN_THREADS * EXSCAN_ITEMS;
+
+// inclusive scan of one value per lane over the workgroup; returns the lane's inclusive value and the block total
+CDBG_DEV uint64_t exscan_block_incl(uint64_t v, uint64_t* wsum /* [EXSCAN_THREADS/64] LDS */, uint64_t& total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t x = __shfl_up(incl, d); if (lane >= d) incl += x; }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    if (tid == 0) {
-        uint64_t acc = 0;
-        for (int i = 0; i < EXSCAN_THREADS; ++i) { const uint64_t v = part[i]; part[i] = acc; acc += v; }
-        off[n] = acc;
+    uint64_t basew = 0, tot = 0;
+    for (int w = 0; w < EXSCAN_THREADS / 64; ++w) { const uint64_t x = wsum[w]; if (w < wave) basew += x; tot += x; }
+    total = tot;
+    __syncthreads();
+    return incl + basew;
+}
+__global__ void __launch_bounds__(EXSCAN_THREADS) k_exscan_sums(const uint32_t* cnt, uint64_t* bsum, uint64_t n) {
+    CDBG_SHARED uint64_t wsum[EXSCAN_THREADS / 64];
+    const uint64_t i0 = (uint64_t)blockIdx.x * EXSCAN_BLOCK + (uint64_t)threadIdx.x * EXSCAN_ITEMS;
+    uint64_t v = 0;
+    for (int j = 0; j < EXSCAN_ITEMS; ++j) if (i0 + j < n) v += cnt[i0 + j];
+    uint64_t total; exscan_block_incl(v, wsum, total);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(EXSCAN_THREADS) k_exscan_top(uint64_t* bsum, uint64_t nb, uint64_t* off_n) {
+    CDBG_SHARED uint64_t wsum[EXSCAN_THREADS / 64];
+    uint64_t carry = 0;
+    for (uint64_t b0 = 0; b0 < nb; b0 += EXSCAN_THREADS) {  // uniform trip count
+        const uint64_t i = b0 + threadIdx.x;
+        const uint64_t v = i < nb ? bsum[i] : 0;
+        uint64_t total; const uint64_t incl = exscan_block_incl(v, wsum, total);
+        if (i < nb) bsum[i] = carry + incl - v;              // exclusive
+        carry += total;
     }
-    __syncthreads();
-    uint64_t acc = part[tid];
-    for (uint64_t i = lo; i < hi; ++i) { off[i] = acc; acc += cnt[i]; }
+    if (threadIdx.x == 0) *off_n = carry;
+}
+__global__ void __launch_bounds__(EXSCAN_THREADS) k_exscan_apply(const uint32_t* cnt, const uint64_t* bsum, uint64_t* off, uint64_t n) {
+    CDBG_SHARED uint64_t wsum[EXSCAN_THREADS / 64];
+    const uint64_t i0 = (uint64_t)blockIdx.x * EXSCAN_BLOCK + (uint64_t)threadIdx.x * EXSCAN_ITEMS;
+    uint32_t c[EXSCAN_ITEMS]; uint64_t v = 0;
+    for (int j = 0; j < EXSCAN_ITEMS; ++j) { c[j] = (i0 + j < n) ? cnt[i0 + j] : 0u; v += c[j]; }
+    uint64_t total; const uint64_t incl = exscan_block_incl(v, wsum, total);
+    uint64_t acc = bsum[blockIdx.x] + incl - v;
+    for (int j = 0; j < EXSCAN_ITEMS; ++j) { if (i0 + j < n) off[i0 + j] = acc; acc += c[j]; }
 }
 __global__ void k_copy_u64(const uint64_t* src, uint64_t* dst, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
