@@ -41,7 +41,8 @@ class Stats(C.Structure):
 
 EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
            "cdbg_generate_reads", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
-           "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats"]
+           "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats",
+           "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end"]
 
 
 def load(path: str | None = None) -> C.CDLL:
@@ -66,6 +67,11 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_num_unitigs.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     lib.cdbg_fetch_unitigs.argtypes = [vp, u64, u64, C.c_char_p, C.POINTER(u64), C.POINTER(u64)]
     lib.cdbg_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.cdbg_exchange_sizes.argtypes = [vp, C.POINTER(u64)]
+    lib.cdbg_exchange_export.argtypes = [vp, i32, vp, u64]
+    lib.cdbg_exchange_begin.argtypes = [vp, u64, u64, u64]
+    lib.cdbg_exchange_add.argtypes = [vp, u64, u64, u64, vp, vp, vp, vp, vp, vp]
+    lib.cdbg_exchange_end.argtypes = [vp]
     return lib
 
 
@@ -143,6 +149,24 @@ class Graph:
 
     def reset(self):
         self._ck(self.lib.cdbg_reset(self._h))
+
+    # ---- multi-GPU exchange (see bcalm_amd/dist.py) ----
+    def exchange_sizes(self):
+        out = (C.c_uint64 * 3)()
+        self._ck(self.lib.cdbg_exchange_sizes(self._h, out))
+        return tuple(out)
+
+    def exchange_export(self, what, dst_ptr, nbytes):
+        self._ck(self.lib.cdbg_exchange_export(self._h, what, C.c_void_p(dst_ptr), nbytes))
+
+    def exchange_begin(self, total_pieces, total_bases, total_glog):
+        self._ck(self.lib.cdbg_exchange_begin(self._h, total_pieces, total_bases, total_glog))
+
+    def exchange_add(self, n_pieces, n_bases, n_glog, ptrs):
+        self._ck(self.lib.cdbg_exchange_add(self._h, n_pieces, n_bases, n_glog, *[C.c_void_p(p) for p in ptrs]))
+
+    def exchange_end(self):
+        self._ck(self.lib.cdbg_exchange_end(self._h))
 
     # ---- results ----
     def stats(self) -> dict:

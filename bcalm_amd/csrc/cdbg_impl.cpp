@@ -60,6 +60,10 @@ struct DBuf {                                   // owned device array
         return CDBG_OK;
     }
     void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; cap = 0; } }
+    void swap(DBuf& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
+    DBuf() = default;
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
     ~DBuf() { release(); }
 };
 
@@ -103,6 +107,10 @@ struct cdbg_ctx {
     DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_state, glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;
     DBuf<uint64_t> glog_keys; DBuf<uint32_t> glog_tag; uint64_t glog_cap = 0, n_glog = 0;
     uint64_t n_pieces = 0, n_piece_bases = 0;
+
+    // multi-GPU merge staging (cdbg_exchange_*)
+    DBuf<uint32_t> mg_n, mg_gtag; DBuf<uint64_t> mg_kc, mg_boff, mg_gkeys; DBuf<uint8_t> mg_bases;
+    uint64_t mg_np = 0, mg_nb = 0, mg_nl = 0, mg_cap_p = 0, mg_cap_b = 0, mg_cap_l = 0; bool mg_open = false;
 
     DBuf<uint64_t> unitig_off; DBuf<uint32_t> unitig_len; DBuf<uint64_t> unitig_kc; DBuf<uint8_t> unitig_bases;
     uint64_t n_unitigs = 0, unitig_total = 0;
@@ -606,6 +614,80 @@ int cdbg_fetch_unitigs(cdbg_ctx* c, uint64_t first, uint64_t n, char* seq_buf, u
     seq_off[n] = w;
     return CDBG_OK;
 }
+// ---- multi-GPU exchange: the pieces and glue records of every rank are gathered (RCCL all-gather
+// driven by the caller through torch.distributed; this library only copies device-to-device into / out
+// of caller-provided device buffers) and merged in rank order, after which cdbg_glue runs on the union ----
+int cdbg_exchange_sizes(cdbg_ctx* c, uint64_t out[3]) {
+    if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
+    out[0] = c->n_pieces; out[1] = c->n_piece_bases; out[2] = c->n_glog;
+    return CDBG_OK;
+}
+int cdbg_exchange_export(cdbg_ctx* c, int what, void* dst_dev, uint64_t nbytes) {
+    if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_export before cdbg_compact");
+    const void* src = nullptr; uint64_t have = 0;
+    switch (what) {
+        case 0: src = c->piece_n.p; have = c->n_pieces * sizeof(uint32_t); break;
+        case 1: src = c->piece_kc.p; have = c->n_pieces * sizeof(uint64_t); break;
+        case 2: src = c->piece_boff.p; have = c->n_pieces * sizeof(uint64_t); break;
+        case 3: src = c->piece_bases.p; have = c->n_piece_bases; break;
+        case 4: src = c->glog_keys.p; have = c->n_glog * (uint64_t)c->W * sizeof(uint64_t); break;
+        case 5: src = c->glog_tag.p; have = c->n_glog * sizeof(uint32_t); break;
+        default: return fail(CDBG_E_PARAM, "unknown export kind %d", what);
+    }
+    if (nbytes < have) return fail(CDBG_E_PARAM, "export buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)have);
+    if (have) HIPCK(hipMemcpyAsync(dst_dev, src, have, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return CDBG_OK;
+}
+int cdbg_exchange_begin(cdbg_ctx* c, uint64_t total_pieces, uint64_t total_bases, uint64_t total_glog) {
+    if (!c) return fail(CDBG_E_PARAM, "null context");
+    if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_begin before cdbg_compact");
+    CK(c->mg_n.alloc(total_pieces, false)); CK(c->mg_kc.alloc(total_pieces, false)); CK(c->mg_boff.alloc(total_pieces, false));
+    CK(c->mg_bases.alloc(total_bases, false));
+    CK(c->mg_gkeys.alloc(total_glog * c->W, false)); CK(c->mg_gtag.alloc(total_glog, false));
+    c->mg_np = c->mg_nb = c->mg_nl = 0; c->mg_cap_p = total_pieces; c->mg_cap_b = total_bases; c->mg_cap_l = total_glog; c->mg_open = true;
+    return CDBG_OK;
+}
+int cdbg_exchange_add(cdbg_ctx* c, uint64_t n_pieces, uint64_t n_bases, uint64_t n_glog, const void* piece_n, const void* piece_kc,
+                      const void* piece_boff, const void* bases, const void* glog_keys, const void* glog_tag) {
+    if (!c) return fail(CDBG_E_PARAM, "null context");
+    if (!c->mg_open) return fail(CDBG_E_STATE, "cdbg_exchange_add without cdbg_exchange_begin");
+    if (c->mg_np + n_pieces > c->mg_cap_p || c->mg_nb + n_bases > c->mg_cap_b || c->mg_nl + n_glog > c->mg_cap_l)
+        return fail(CDBG_E_PARAM, "cdbg_exchange_add exceeds the totals given to cdbg_exchange_begin");
+    if (2 * (c->mg_np + n_pieces) >= 0x7FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 31-bit end ids");
+    if (n_bases) HIPCK(hipMemcpyAsync(c->mg_bases.p + c->mg_nb, bases, n_bases, hipMemcpyDeviceToDevice, c->stream));
+    MergeParams mp{ n_pieces, n_glog, c->mg_np, c->mg_nb, c->mg_nl, c->W,
+                    (const uint32_t*)piece_n, (const uint64_t*)piece_kc, (const uint64_t*)piece_boff, (const uint64_t*)glog_keys, (const uint32_t*)glog_tag,
+                    c->mg_n.p, c->mg_kc.p, c->mg_boff.p, c->mg_gkeys.p, c->mg_gtag.p };
+    const uint64_t work = std::max(n_pieces, n_glog);
+    if (work) CDBG_LAUNCH(k_merge_append, std::min<uint64_t>((work + 255) / 256, MAX_GRID), 256, c->stream, mp);
+    HIPCK(hipStreamSynchronize(c->stream));
+    c->mg_np += n_pieces; c->mg_nb += n_bases; c->mg_nl += n_glog;
+    return CDBG_OK;
+}
+int cdbg_exchange_end(cdbg_ctx* c) {
+    if (!c) return fail(CDBG_E_PARAM, "null context");
+    if (!c->mg_open) return fail(CDBG_E_STATE, "cdbg_exchange_end without cdbg_exchange_begin");
+    c->piece_n.swap(c->mg_n); c->piece_kc.swap(c->mg_kc); c->piece_boff.swap(c->mg_boff);
+    c->piece_bases.swap(c->mg_bases); c->glog_keys.swap(c->mg_gkeys); c->glog_tag.swap(c->mg_gtag);
+    c->n_pieces = c->mg_np; c->n_piece_bases = c->mg_nb; c->n_glog = c->mg_nl; c->glog_cap = c->mg_cap_l;
+    c->mg_open = false;
+    // junction table for the union: at most one junction per glue record
+    const int W = c->W;
+    c->glue_cap = (uint32_t)pow2_at_least(2 * c->n_glog + 64);
+    CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false)); CK(c->glue_state.alloc(c->glue_cap, false));
+    CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
+    HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), c->stream));
+    HIPCK(hipMemsetAsync(c->glue_state.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), c->stream));
+    HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), c->stream));
+    HIPCK(hipMemsetAsync(c->glue_b.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), c->stream));
+    HIPCK(hipMemsetAsync(c->glue_conf.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return CDBG_OK;
+}
+
 int cdbg_stats(cdbg_ctx* c, cdbg_stats_t* out) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
     *out = c->st; return CDBG_OK;

@@ -178,4 +178,26 @@ __global__ void k_decode_solid(DecodeParams P) {
     }
 }
 
+// ---- multi-GPU merge: append one rank's pieces / glue log to the merged arrays, renumbering ----
+struct MergeParams {
+    uint64_t n_pieces, n_glog, piece_base, bases_base, glog_base; int W;
+    const uint32_t* src_n; const uint64_t* src_kc; const uint64_t* src_boff; const uint64_t* src_gkeys; const uint32_t* src_gtag;
+    uint32_t* dst_n; uint64_t* dst_kc; uint64_t* dst_boff; uint64_t* dst_gkeys; uint32_t* dst_gtag;
+};
+__global__ void k_merge_append(MergeParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint64_t i = i0; i < P.n_pieces; i += stride) {
+        P.dst_n[P.piece_base + i] = P.src_n[i];
+        P.dst_kc[P.piece_base + i] = P.src_kc[i];
+        P.dst_boff[P.piece_base + i] = P.src_boff[i] + P.bases_base;
+    }
+    for (uint64_t i = i0; i < P.n_glog; i += stride) {
+        const uint32_t t = P.src_gtag[i];
+        // piece-end ids move with their piece: end = 2 * piece + side
+        P.dst_gtag[P.glog_base + i] = (t == GTAG_EMPTY || t == GTAG_CONFIRM) ? t : t + (uint32_t)(2 * P.piece_base);
+        for (int j = 0; j < P.W; ++j) P.dst_gkeys[(P.glog_base + i) * P.W + j] = P.src_gkeys[i * P.W + j];
+    }
+}
+
 }  // namespace cdbg

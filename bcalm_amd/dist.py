@@ -1,0 +1,47 @@
+"""Multi-GPU glue exchange: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on the GPU box; "gloo" in the CPU tests with the simulator library).
+
+Minimizer partitions are sharded over the ranks (cdbg_params.world_size / rank): every rank scans
+the same resident reads and counts / compacts only the partitions it owns.  What has to cross
+ranks are the glue records: pieces (length, abundance, bases) and the glue log (junction key,
+piece-end id / CONFIRM).  They are gathered with all_gather_into_tensor and merged in rank order
+by libcdbg (cdbg_exchange_*), after which every rank glues the union and holds the complete
+unitig set.  torch only moves bytes here; all compute stays in the HIP library.
+"""
+from __future__ import annotations
+
+import torch
+
+# (export kind, bytes per item given W) in the order cdbg_exchange_add expects them
+_KINDS = [(0, lambda W: 4, 0), (1, lambda W: 8, 0), (2, lambda W: 8, 0), (3, lambda W: 1, 1), (4, lambda W: 8 * W, 2), (5, lambda W: 4, 2)]
+
+
+def exchange_glue(graph, dist, device, W: int):
+    """all-gather every rank's pieces + glue log and merge them into `graph` (stage: compacted)."""
+    world = dist.get_world_size()
+    device = torch.device(device)
+    mine = torch.tensor(graph.exchange_sizes(), dtype=torch.int64, device=device)
+    sizes = torch.empty(world * 3, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, mine)
+    sizes = sizes.view(world, 3).cpu().tolist()
+    gathered = []
+    for kind, bpi, which in _KINDS:
+        item = bpi(W)
+        nbytes = [int(sizes[r][which]) * item for r in range(world)]
+        pad = max(max(nbytes), 16)
+        pad = (pad + 15) // 16 * 16
+        send = torch.empty(pad, dtype=torch.uint8, device=device)
+        graph.exchange_export(kind, send.data_ptr(), pad)
+        recv = torch.empty(world * pad, dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(recv, send)
+        gathered.append((recv, pad))
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)                   # collectives run on torch's stream, libcdbg on its own
+    totals = [sum(int(sizes[r][j]) for r in range(world)) for j in range(3)]
+    graph.exchange_begin(*totals)
+    for r in range(world):
+        ptrs = [recv.data_ptr() + r * pad for recv, pad in gathered]
+        graph.exchange_add(int(sizes[r][0]), int(sizes[r][1]), int(sizes[r][2]), ptrs)
+    graph.exchange_end()
+    return {"pieces": totals[0], "piece_bases": totals[1], "glue_records": totals[2],
+            "bytes_gathered": sum(recv.numel() for recv, _ in gathered)}

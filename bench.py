@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--cfg", type=int, default=3)
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["sharded", "independent"], default="sharded",
+                    help="N>1: sharded = ONE graph, minimizer partitions split over the ranks, glue records exchanged with an RCCL "
+                         "all-gather (strong scaling); independent = one read set per rank, no collective (weak scaling)")
     a = ap.parse_args()
 
     import torch
@@ -98,11 +101,31 @@ def main():
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     lib = bcalm_amd.load()                      # raises without the HIP extension: no fallback
-    # N > 1 (round 1): every rank owns a disjoint read set of the same size and runs the full
-    # path on it (weak scaling, no data-path collective).  The minimizer-sharded single-graph
-    # mode (world_size/rank in cdbg_params + RCCL all-to-all of glue records) is not wired yet.
-    g = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank)
-    g.generate_reads(a.reads, a.read_len, a.cfg + 16 * rank)
+    sharded = world > 1 and a.mode == "sharded"
+    if sharded:
+        # ONE graph over `--reads` reads: every rank holds the reads, owns the minimizer partitions
+        # p with p % world == rank, counts and compacts them, then the glue records (pieces + junction
+        # log) are all-gathered over RCCL/xGMI and every rank glues the union.
+        from bcalm_amd import dist as cdist
+        g = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank, world_size=world, rank=rank)
+        g.generate_reads(a.reads, a.read_len, a.cfg)
+        W = 1 if a.k <= 31 else 2 if a.k <= 63 else 4
+        dev = torch.device("cuda", local_rank)
+
+        def step():
+            g.count()
+            g.compact()
+            info = cdist.exchange_glue(g, dist, dev, W)
+            g.glue()
+            return info
+    else:
+        # N == 1, or --mode independent: every rank runs the full path on its own read set
+        g = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank)
+        g.generate_reads(a.reads, a.read_len, a.cfg + 16 * rank)
+
+        def step():
+            g.run()
+            return None
 
     def sync():
         torch.cuda.synchronize()
@@ -111,14 +134,15 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        g.run()
+        step()
         g.reset()
     sync()
     t0 = time.perf_counter()
     st = None
     acc = {x: 0.0 for x in ("ms_scan_hist", "ms_scan_emit", "ms_count", "ms_compact", "ms_glue", "ms_total")}
+    xinfo = None
     for i in range(a.steps):
-        g.run()
+        xinfo = step()
         st = g.stats()
         for x in acc:
             acc[x] += st[x]
@@ -152,12 +176,15 @@ def main():
             "unit": "kmers/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: synthetic %d x %d bp reads per GPU, k=%d, abundance-min %d, 1%% substitutions, 30x coverage"
-                                   % (a.reads, a.read_len, a.k, a.abundance_min),
+            "config": {"workload": "BASELINE config 3: synthetic %d x %d bp reads %s, k=%d, abundance-min %d, 1%% substitutions, 30x coverage"
+                                   % (a.reads, a.read_len, "in total (one graph)" if sharded else "per GPU", a.k, a.abundance_min),
                        "timing_boundary": "reads resident in HBM (ASCII) -> unitigs + KC resident in HBM; includes the stages' host syncs",
-                       "multi_gpu": "independent read sets per rank (no collective)" if world > 1 else "single GPU",
+                       "multi_gpu": ("single GPU" if world == 1 else
+                                     "sharded: minimizer partitions split over ranks, replicated scan, RCCL all-gather of glue records, glue on the union"
+                                     if sharded else "independent read sets per rank (no collective)"),
+                       "exchange": xinfo,
                        "minimizer_size": st["minimizer_size"], "log2_partitions": st["log2_partitions"]},
             "counts": {x: st[x] for x in ("n_occurrences", "n_distinct", "n_solid", "n_pieces", "n_unitigs", "n_records", "n_big_partitions")},
             "stage_ms": {x: acc[x] / a.steps for x in acc},

@@ -94,6 +94,23 @@ int cdbg_run(cdbg_ctx* ctx);
  * be run again (benchmark steps) without allocator traffic */
 int cdbg_reset(cdbg_ctx* ctx);
 
+/* Multi-GPU (one process per GPU, minimizer partitions sharded by cdbg_params.world_size/rank; every
+ * rank scans the same reads and counts / compacts only its own partitions).  After cdbg_compact the
+ * pieces and glue records of all ranks are gathered -- the caller moves the bytes with an RCCL
+ * all-gather (torch.distributed); this library only copies device-to-device -- and merged in rank order:
+ *   cdbg_exchange_sizes   -> {piece ids, piece base bytes, glue-log records} of this rank
+ *   cdbg_exchange_export  -> copy one array (what: 0 piece_n u32, 1 piece_kc u64, 2 piece_boff u64,
+ *                            3 piece bases u8, 4 glue keys u64 x W, 5 glue tags u32) into dst_dev
+ *   cdbg_exchange_begin / _add (once per rank, in rank order, own data included) / _end
+ * then cdbg_glue runs on the union (every rank obtains the complete unitig set). */
+int cdbg_exchange_sizes(cdbg_ctx* ctx, uint64_t out[3]);
+int cdbg_exchange_export(cdbg_ctx* ctx, int what, void* dst_dev, uint64_t nbytes);
+int cdbg_exchange_begin(cdbg_ctx* ctx, uint64_t total_pieces, uint64_t total_bases, uint64_t total_glog);
+int cdbg_exchange_add(cdbg_ctx* ctx, uint64_t n_pieces, uint64_t n_bases, uint64_t n_glog, const void* piece_n,
+                      const void* piece_kc, const void* piece_boff, const void* bases, const void* glog_keys,
+                      const void* glog_tag);
+int cdbg_exchange_end(cdbg_ctx* ctx);
+
 /* Results.  Solid k-mers: kmers has (k+1)-byte stride, NUL-terminated ASCII, canonical strand. */
 int cdbg_num_solid(cdbg_ctx* ctx, uint64_t* n);
 int cdbg_fetch_solid(cdbg_ctx* ctx, char* kmers, uint32_t* counts, uint64_t capacity, uint64_t* n_written);

@@ -41,7 +41,15 @@ def _worker(rank, world, port, q):
     dist.all_gather_object(gathered, mine)
     full = sorted(x for part in gathered for x in part)
     exp2 = orc.run(shared, 31, 2, want_solid=True)
-    q.put((rank, ok, float(t.item()), int(n.item()), st["n_distinct"], full == exp2["solid"], len(mine)))
+    # (c) single-graph mode: sharded count + compact, all-gather of glue records, glue on the union
+    from bcalm_amd import dist as cdist
+    g = api.Graph(31, 2, lib=lib, log2_partitions=6, world_size=world, rank=rank)
+    g.push_text(shared); g.count(); g.compact()
+    info = cdist.exchange_glue(g, dist, torch.device("cpu"), 1)
+    g.glue()
+    canon2 = oracle_lib.canonical_set(orc, g.unitigs(), 31); g.close()
+    ok_graph = canon2 == exp2["unitigs"] and info["glue_records"] > 0
+    q.put((rank, ok, float(t.item()), int(n.item()), st["n_distinct"], full == exp2["solid"], len(mine), ok_graph))
     dist.destroy_process_group()
 
 
@@ -61,3 +69,4 @@ def test_two_rank_gloo():
     assert res[0][3] == res[1][3] == res[0][4] + res[1][4]    # SUM of distinct k-mers
     assert all(r[5] for r in res), "sharded k-mer sets do not partition the oracle's set"
     assert res[0][6] > 0 and res[1][6] > 0
+    assert all(r[7] for r in res), "sharded single-graph mode (all-gather + merge + glue) differs from the oracle"

@@ -119,3 +119,28 @@ def test_no_device_fallback_symbols(hip):
     import bcalm_amd
     for sym in bcalm_amd.EXPORTS:
         assert hasattr(hip, sym)
+
+
+def test_exchange_path_single_rank_nccl(oracle, hip):
+    """the multi-GPU glue exchange (RCCL all-gather + merge + glue on the union) with a 1-rank
+    'nccl' group: exercises the device-tensor / D2D / merge-kernel path that N>1 uses"""
+    import torch
+    import torch.distributed as dist
+    import bcalm_amd
+    from bcalm_amd import dist as cdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        text = oracle.synth_reads(30000, 150, 3)
+        exp = oracle.run(text, 31, 2)
+        g = bcalm_amd.Graph(31, 2, lib=hip, world_size=1, rank=0)
+        g.push_text(text); g.count(); g.compact()
+        info = cdist.exchange_glue(g, dist, torch.device("cuda", 0), 1)
+        g.glue()
+        canon = oracle_lib.canonical_set(oracle, g.unitigs(), 31)
+        g.close()
+        assert info["glue_records"] > 0
+        assert canon == exp["unitigs"]
+    finally:
+        dist.destroy_process_group()
