@@ -16,6 +16,8 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -97,7 +99,7 @@ struct cdbg_ctx {
     std::vector<char> host_text;                 // pushed reads awaiting upload
     DBuf<uint8_t> reads; uint64_t nbytes = 0, nbytes_padded = 0;
 
-    DBuf<uint32_t> part_count; DBuf<uint64_t> part_off, part_cursor, records, exscan_tmp;
+    DBuf<uint32_t> part_count, spill_part; DBuf<uint64_t> part_off, part_cursor, records, exscan_tmp, spill_recs;
     DBuf<uint64_t> dstats; DBuf<uint32_t> derr;
     DBuf<uint64_t> solid_keys; DBuf<uint32_t> solid_cnt; DBuf<uint64_t> solid_cursor, seg_off; DBuf<uint32_t> seg_n;
     DBuf<uint32_t> big_list, big_count;
@@ -191,43 +193,123 @@ int count_impl(cdbg_ctx* c) {
     CK(c->part_cursor.alloc(NPL, false));
     CK(c->dstats.alloc(32, true));
     CK(c->derr.alloc(4, true));
+    CK(c->cursors.alloc(8, true));
 
     ScanParams sp{};
     sp.reads = c->reads.p; sp.nbytes = c->nbytes; sp.nbytes_padded = c->nbytes_padded;
     sp.k = c->k; sp.m = c->m; sp.log_np = c->log_np; sp.rank_bits = c->rank_bits; sp.rank = c->prm.rank;
     sp.part_count = c->part_count.p; sp.part_cursor = c->part_cursor.p; sp.records = nullptr; sp.stats = c->dstats.p;
+    sp.tile_stride = 1; sp.tile_offset = 0; sp.error = c->derr.p;
     // instruction-lean scan when the window fits registers; generic LDS-doubling scan otherwise
     const bool fast_scan = c->k <= 48 && (c->k - c->m) <= SCANF_WNMAX;
     const uint64_t tiles = fast_scan ? (c->nbytes + SCANF_TILE - 1) / SCANF_TILE : (c->nbytes + SCAN_TILE - 1) / SCAN_TILE;
     c->st.n_launch_scan = tiles;
-
-    // pass 1: histogram of records per partition
-    Timer t; CK(t.start(s));
-    if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, false>), tiles, SCAN_THREADS, s, sp);
-    else CDBG_LAUNCH((k_scan<W, false>), tiles, SCAN_THREADS, s, sp);
-    {
+#define LAUNCH_SCAN(MODE, GRID)                                                                  \
+    do { if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE>), (GRID), SCAN_THREADS, s, sp);          \
+         else CDBG_LAUNCH((k_scan<W, MODE>), (GRID), SCAN_THREADS, s, sp); } while (0)
+    auto exscan = [&](const uint32_t* counts) -> int {       // counts -> part_off (exclusive), part_off[NPL] = total
         const uint64_t nb = (NPL + EXSCAN_BLOCK - 1) / EXSCAN_BLOCK;
         CK(c->exscan_tmp.alloc(nb + 1, false));
-        CDBG_LAUNCH(k_exscan_sums, nb, EXSCAN_THREADS, s, (const uint32_t*)c->part_count.p, c->exscan_tmp.p, NPL);
+        CDBG_LAUNCH(k_exscan_sums, nb, EXSCAN_THREADS, s, counts, c->exscan_tmp.p, NPL);
         CDBG_LAUNCH(k_exscan_top, 1, EXSCAN_THREADS, s, c->exscan_tmp.p, nb, c->part_off.p + NPL);
-        CDBG_LAUNCH(k_exscan_apply, nb, EXSCAN_THREADS, s, (const uint32_t*)c->part_count.p, (const uint64_t*)c->exscan_tmp.p, c->part_off.p, NPL);
+        CDBG_LAUNCH(k_exscan_apply, nb, EXSCAN_THREADS, s, counts, (const uint64_t*)c->exscan_tmp.p, c->part_off.p, NPL);
+        return CDBG_OK;
+    };
+
+    // Record placement.  exact : histogram pass + emit pass at exact offsets (two scans, zero slack).
+    //                    capped: ONE scan into fixed-capacity partition regions sized from a sampled
+    //                            histogram; the rare records that do not fit go to a spill list and their
+    //                            partitions are repaired (gathered contiguously) before counting.
+    bool capped = tiles > 8192;
+    if (const char* e = getenv("CDBG_SCAN_MODE")) { if (!strcmp(e, "exact")) capped = false; else if (!strcmp(e, "capped")) capped = true; }
+    uint64_t n_records = 0, hs[2] = {0, 0};
+    uint32_t part_cap = 0; uint64_t n_spill = 0;
+    std::vector<uint32_t> spill_parts;                       // spilled partitions (sorted), capped mode
+    DBuf<uint64_t> repair_recs, repair_off; DBuf<uint32_t> repair_part;
+    Timer t;
+    if (capped) {
+        CK(t.start(s));
+        const uint64_t stride = std::min<uint64_t>(64, std::max<uint64_t>(1, tiles / 4096));
+        const uint64_t ns = (tiles + stride - 1) / stride;
+        sp.tile_stride = (uint32_t)stride;
+        LAUNCH_SCAN(SCAN_HIST, ns);
+        CK(exscan(c->part_count.p));
+        uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPL, &sample_records));
+        CK(t.stop(&c->st.ms_scan_hist));
+        const double mean = (double)sample_records * (double)tiles / (double)ns / (double)NPL;
+        part_cap = (uint32_t)(mean * 2.5 + 8.0 * std::sqrt(mean + 1.0) + 16.0);
+        part_cap = (part_cap + 7u) & ~7u;
+        if (const char* e = getenv("CDBG_PART_CAP")) part_cap = (uint32_t)std::max(1, atoi(e));   // test knob: force spills
+        const uint64_t spill_cap = std::max<uint64_t>((uint64_t)(mean * (double)NPL / 32.0), 65536);
+        if ((double)part_cap * (double)NPL * RW * 8.0 > 200e9) capped = false;     // would not fit: use the exact layout
+        else {
+            CK(c->records.alloc((uint64_t)part_cap * NPL * RW, false));
+            CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
+            HIPCK(hipMemsetAsync(c->part_count.p, 0, NPL * sizeof(uint32_t), s));
+            HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+            sp.tile_stride = 1; sp.records = c->records.p; sp.part_cap = part_cap; sp.part_fill = c->part_count.p;
+            sp.spill_recs = c->spill_recs.p; sp.spill_part = c->spill_part.p; sp.spill_cursor = c->cursors.p + 6; sp.spill_cap = spill_cap;
+            CK(t.start(s));
+            LAUNCH_SCAN(SCAN_EMIT_CAPPED, tiles);
+            CK(exscan(c->part_count.p));                     // only for the total number of records
+            CK(t.stop(&c->st.ms_scan_emit));
+            CK(read_u64(c->part_off.p + NPL, &n_records));
+            CK(read_u64(c->dstats.p, hs, 2));
+            CK(read_u64(c->cursors.p + 6, &n_spill));
+            uint32_t derr = 0; CK(read_u32(c->derr.p, &derr));
+            if (derr == 6 || n_spill > spill_cap) {          // estimate was off (very skewed input): exact layout instead
+                capped = false; HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t)));
+            } else if (n_spill) {
+                // repair: gather region + spilled records of each spilled partition into one contiguous run
+                std::vector<uint32_t> sp_part(n_spill); CK(read_u32(c->spill_part.p, sp_part.data(), n_spill));
+                std::vector<uint32_t> order(n_spill);
+                for (uint64_t i = 0; i < n_spill; ++i) order[i] = (uint32_t)i;
+                std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sp_part[a] < sp_part[b] || (sp_part[a] == sp_part[b] && a < b); });
+                std::vector<uint64_t> ioff(1, 0), soff(1, 0);
+                for (uint64_t i = 0; i < n_spill;) {
+                    uint64_t j = i; while (j < n_spill && sp_part[order[j]] == sp_part[order[i]]) ++j;
+                    spill_parts.push_back(sp_part[order[i]]);
+                    ioff.push_back(ioff.back() + part_cap + (j - i)); soff.push_back(j);
+                    i = j;
+                }
+                const uint64_t nsp = spill_parts.size();
+                DBuf<uint32_t> d_order; DBuf<uint64_t> d_soff;
+                CK(repair_recs.alloc(ioff.back() * RW, false)); CK(repair_off.alloc(nsp + 1, false)); CK(repair_part.alloc(nsp, false));
+                CK(d_order.alloc(n_spill, false)); CK(d_soff.alloc(nsp + 1, false));
+                HIPCK(hipMemcpy(repair_off.p, ioff.data(), (nsp + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+                HIPCK(hipMemcpy(repair_part.p, spill_parts.data(), nsp * sizeof(uint32_t), hipMemcpyHostToDevice));
+                HIPCK(hipMemcpy(d_order.p, order.data(), n_spill * sizeof(uint32_t), hipMemcpyHostToDevice));
+                HIPCK(hipMemcpy(d_soff.p, soff.data(), (nsp + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+                RepairParams rp{ c->records.p, c->spill_recs.p, d_order.p, d_soff.p, repair_off.p, repair_part.p, part_cap, RW, repair_recs.p };
+                CDBG_LAUNCH(k_repair_gather, nsp, 256, s, rp);
+                HIPCK(hipStreamSynchronize(s));
+            }
+        }
     }
-    CK(t.stop(&c->st.ms_scan_hist));
-    uint64_t n_records = 0; CK(read_u64(c->part_off.p + NPL, &n_records));
-    uint64_t hs[2] = {0, 0}; CK(read_u64(c->dstats.p, hs, 2));
+    if (!capped) {
+        sp.tile_stride = 1; sp.part_cap = 0;
+        HIPCK(hipMemsetAsync(c->part_count.p, 0, NPL * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+        // pass 1: histogram of records per partition
+        CK(t.start(s));
+        LAUNCH_SCAN(SCAN_HIST, tiles);
+        CK(exscan(c->part_count.p));
+        CK(t.stop(&c->st.ms_scan_hist));
+        CK(read_u64(c->part_off.p + NPL, &n_records));
+        CK(read_u64(c->dstats.p, hs, 2));
+        // pass 2: emit records at exact offsets
+        CK(c->records.alloc(std::max<uint64_t>(n_records, 1) * RW, false));
+        CK(t.start(s));
+        CDBG_LAUNCH(k_copy_u64, (NPL + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_cursor.p, NPL);
+        sp.records = c->records.p;
+        LAUNCH_SCAN(SCAN_EMIT, tiles);
+        CK(t.stop(&c->st.ms_scan_emit));
+    }
+#undef LAUNCH_SCAN
 #ifdef CDBG_PROFILE_PHASES
-    { uint64_t ph[6]; CK(read_u64(c->dstats.p + 16, ph, 6)); fprintf(stderr, "k_scan<hist> phase ticks: load %llu keys %llu winmin %llu flags %llu collect %llu emit %llu\n", (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3], (unsigned long long)ph[4], (unsigned long long)ph[5]); }
+    { uint64_t ph[6]; CK(read_u64(c->dstats.p + 16, ph, 6)); fprintf(stderr, "k_scan phase ticks: load %llu keys %llu winmin %llu flags %llu collect %llu emit %llu\n", (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3], (unsigned long long)ph[4], (unsigned long long)ph[5]); }
 #endif
     c->st.n_records = n_records; c->st.n_member_kmers = hs[0];
-
-    // pass 2: emit records at exact offsets
-    CK(c->records.alloc(std::max<uint64_t>(n_records, 1) * RW, false));
-    CK(t.start(s));
-    CDBG_LAUNCH(k_copy_u64, (NPL + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_cursor.p, NPL);
-    sp.records = c->records.p;
-    if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, true>), tiles, SCAN_THREADS, s, sp);
-    else CDBG_LAUNCH((k_scan<W, true>), tiles, SCAN_THREADS, s, sp);
-    CK(t.stop(&c->st.ms_scan_emit));
 
     // count
     const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + (PERSISTENT_GRID + 1) * (uint64_t)COUNT_CHUNK;
@@ -242,6 +324,7 @@ int count_impl(cdbg_ctx* c) {
 
     CountParams cp{};
     cp.records = c->records.p; cp.part_off = c->part_off.p; cp.part_list = nullptr;
+    if (capped) { cp.part_stride = part_cap; cp.part_fill = c->part_count.p; }
     cp.k = c->k; cp.amin = (uint32_t)c->prm.abundance_min;
     cp.solid_keys = c->solid_keys.p; cp.solid_cnt = c->solid_cnt.p; cp.solid_cap = solid_cap; cp.solid_cursor = c->solid_cursor.p;
     cp.seg_off = c->seg_off.p; cp.seg_n = c->seg_n.p; cp.stats = c->dstats.p;
@@ -250,6 +333,12 @@ int count_impl(cdbg_ctx* c) {
     cp.n_items = (uint32_t)NPL; cp.max_passes = 64;
     CDBG_LAUNCH((k_count<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, cp);
     c->st.n_launch_count = NPL;
+    if (!spill_parts.empty()) {                              // spilled partitions: count their gathered copies
+        CountParams rp2 = cp;
+        rp2.records = repair_recs.p; rp2.item_off = repair_off.p; rp2.part_list = repair_part.p; rp2.part_stride = 0;
+        rp2.n_items = (uint32_t)spill_parts.size(); rp2.max_passes = 4096;
+        CDBG_LAUNCH((k_count<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(rp2.n_items, PERSISTENT_GRID), Cfg<W>::NTC, s, rp2);
+    }
     uint32_t nbig = 0;
     HIPCK(hipStreamSynchronize(s));
     CK(read_u32(c->big_count.p, &nbig));
@@ -260,8 +349,10 @@ int count_impl(cdbg_ctx* c) {
         std::vector<uint64_t> offs(nbig + 1, 0);
         const uint64_t nmax = (uint64_t)RecFmt<W>::CAPB - c->k + 1;
         for (uint32_t i = 0; i < nbig; ++i) {
-            uint64_t po[2]; CK(read_u64(c->part_off.p + bl[i], po, 2));
-            const uint64_t occ = (po[1] - po[0]) * nmax;
+            uint64_t nrec_p;
+            if (capped) { uint32_t f = 0; CK(read_u32(c->part_count.p + bl[i], &f)); nrec_p = f; }
+            else { uint64_t po[2]; CK(read_u64(c->part_off.p + bl[i], po, 2)); nrec_p = po[1] - po[0]; }
+            const uint64_t occ = nrec_p * nmax;
             offs[i + 1] = offs[i] + pow2_at_least(2 * occ + 4 * 256);
         }
         CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_state.alloc(offs[nbig], false)); CK(g_cnt.alloc(offs[nbig], false));

@@ -159,7 +159,10 @@ struct RecView {
 
 struct CountParams {
     const uint64_t* records;       // RW words per record
-    const uint64_t* part_off;      // [n_parts + 1] record offsets
+    const uint64_t* part_off;      // [n_parts + 1] record offsets (exact two-pass layout)
+    uint32_t part_stride;          // != 0: capped single-pass layout, partition p = records [p*stride, p*stride + fill[p])
+    const uint32_t* part_fill;     //       records offered to p; fill > stride => spilled, handled by the repair launch
+    const uint64_t* item_off;      // != null: work item i = records [item_off[i], item_off[i+1]) (repair launch)
     const uint32_t* part_list;     // optional: partitions to process (big pass); else blockIdx.x
     int k; uint32_t amin;
     // outputs
@@ -210,7 +213,13 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t p = P.part_list ? P.part_list[item] : item;
-    const uint64_t rec0 = P.part_off[p], rec1 = P.part_off[p + 1];
+    uint64_t rec0, rec1;
+    if (P.item_off) { rec0 = P.item_off[item]; rec1 = P.item_off[item + 1]; }
+    else if (P.part_stride) {
+        const uint32_t f = P.part_fill[p];
+        if (f > P.part_stride) return;                           // spilled: counted by the repair launch
+        rec0 = (uint64_t)p * P.part_stride; rec1 = rec0 + f;
+    } else { rec0 = P.part_off[p]; rec1 = P.part_off[p + 1]; }
     CDBG_PH(0);
     if (rec1 == rec0) { if (tid == 0) { P.seg_off[p] = 0; P.seg_n[p] = 0; } return; }
 
@@ -382,6 +391,21 @@ __global__ void __launch_bounds__(NT) k_count(CountParams P) {
     if (threadIdx.x == 0) for (int i = 0; i < 8; ++i) if (ph[i]) atomic_add_u64(&P.stats[8 + i], ph[i]);
 #endif
     if (threadIdx.x == 0) for (int i = 0; i < 4; ++i) if (acc[i]) atomic_add_u64(&P.stats[i], acc[i]);
+}
+
+// ---- capped-layout repair: gather a spilled partition's region + spill records contiguously ----
+struct RepairParams {
+    const uint64_t* records; const uint64_t* spill_recs; const uint32_t* order; const uint64_t* soff;
+    const uint64_t* item_off; const uint32_t* item_part; uint32_t part_cap; int RW; uint64_t* out;
+};
+__global__ void k_repair_gather(RepairParams P) {
+    const uint32_t it = blockIdx.x;
+    const uint64_t o0 = P.item_off[it] * P.RW, p = P.item_part[it];
+    const uint64_t nreg = (uint64_t)P.part_cap * P.RW;
+    for (uint64_t i = threadIdx.x; i < nreg; i += blockDim.x) P.out[o0 + i] = P.records[p * nreg + i];
+    const uint64_t s0 = P.soff[it], s1 = P.soff[it + 1];
+    for (uint64_t i = threadIdx.x; i < (s1 - s0) * P.RW; i += blockDim.x)
+        P.out[o0 + nreg + i] = P.spill_recs[(uint64_t)P.order[s0 + i / P.RW] * P.RW + i % P.RW];
 }
 
 }  // namespace cdbg

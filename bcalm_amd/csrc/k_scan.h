@@ -56,7 +56,13 @@ struct ScanParams {
     uint64_t* part_cursor;       // EMIT pass: running cursors, pre-loaded with exclusive offsets
     uint64_t* records;           // EMIT pass: RW words per record
     uint64_t* stats;             // [0] member k-mers emitted (incl. travellers), [1] traveller members
+    uint32_t tile_stride, tile_offset;   // tile = blockIdx.x * tile_stride + tile_offset (sampling for the capacity estimate)
+    // SCAN_EMIT_CAPPED (single pass, no histogram): partition p owns records [p*part_cap, (p+1)*part_cap);
+    // part_fill[p] counts the records offered; records beyond the capacity go to the spill list
+    uint32_t part_cap; uint32_t* part_fill;
+    uint64_t* spill_recs; uint32_t* spill_part; uint64_t* spill_cursor; uint64_t spill_cap; uint32_t* error;
 };
+constexpr int SCAN_HIST = 0, SCAN_EMIT = 1, SCAN_EMIT_CAPPED = 2;
 
 CDBG_DEV uint64_t scan_get64(const uint32_t* pk, int bitoff) {
     const int w = bitoff >> 5, sh = bitoff & 31;
@@ -77,26 +83,34 @@ CDBG_DEV bool scan_all_valid(const uint32_t* vm, int q, int len) {
     return true;
 }
 
-// write one record (EMIT) or count it (HIST) -- one device atomic either way
-template <int W, bool EMIT>
-CDBG_DEV void scan_emit_record(const ScanParams& P, const uint32_t* pk, int ms, uint32_t meta, uint32_t lpart) {
+// place one record: count it (HIST), write it at its exact offset (EMIT) or into the partition's
+// fixed-capacity region / the spill list (EMIT_CAPPED) -- one device atomic either way.
+// bitoff = bit offset of the record's first base in the tile's packed 2-bit stream.
+template <int W, int MODE>
+CDBG_DEV void scan_emit_record(const ScanParams& P, const uint32_t* pk, int bitoff, uint32_t meta, uint32_t lpart) {
     constexpr int RW = RecFmt<W>::RW;
-    if (EMIT) {
-        const uint64_t slot = atomic_add_u64(&P.part_cursor[lpart], 1ULL);
-        uint64_t* dst = P.records + slot * RW;
-        const int bitoff = 2 * (15 + ms);
-#pragma unroll
-        for (int wv = 0; wv < RW; ++wv) {
-            uint64_t x = scan_get64(pk, bitoff + 64 * wv);
-            if (wv == RW - 1) x = (x & ~0xFFFFULL) | meta;
-            dst[RW - 1 - wv] = x;
+    if (MODE == SCAN_HIST) { atomic_add_u32(&P.part_count[lpart], 1u); return; }
+    uint64_t* dst;
+    if (MODE == SCAN_EMIT) dst = P.records + atomic_add_u64(&P.part_cursor[lpart], 1ULL) * RW;
+    else {
+        const uint32_t j = atomic_add_u32(&P.part_fill[lpart], 1u);
+        if (j < P.part_cap) dst = P.records + ((uint64_t)lpart * P.part_cap + j) * RW;
+        else {
+            const uint64_t o = atomic_add_u64(P.spill_cursor, 1ULL);
+            if (o >= P.spill_cap) { *P.error = 6; return; }
+            P.spill_part[o] = lpart;
+            dst = P.spill_recs + o * RW;
         }
-    } else {
-        atomic_add_u32(&P.part_count[lpart], 1u);
+    }
+#pragma unroll
+    for (int wv = 0; wv < RW; ++wv) {
+        uint64_t x = scan_get64(pk, bitoff + 64 * wv);
+        if (wv == RW - 1) x = (x & ~0xFFFFULL) | meta;
+        dst[RW - 1 - wv] = x;
     }
 }
 
-template <int W, bool EMIT>
+template <int W, int MODE>
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     constexpr int RW = RecFmt<W>::RW;
     constexpr int CAPB = RecFmt<W>::CAPB;
@@ -111,7 +125,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
 
     const int tid = threadIdx.x;
     const int k = P.k, m = P.m;
-    const int64_t t0 = (int64_t)blockIdx.x * SCAN_TILE;
+    const int64_t t0 = ((int64_t)blockIdx.x * P.tile_stride + P.tile_offset) * SCAN_TILE;
     const int64_t base = t0 - 16;                     // byte offset of tile-local base index 0
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
     uint64_t sph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t st_prev = wall_clock64();
@@ -256,7 +270,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
                 // rounds of device-atomic latency instead of one per loop iteration
                 const uint32_t li = atomic_add_u32(&s_nrec, 1u);
                 if (li < LIST_CAP) { lst[2 * li] = (uint32_t)ms | (meta << 16); lst[2 * li + 1] = lpart; }
-                else scan_emit_record<W, EMIT>(P, pk, ms, meta, lpart);   // list full (low-complexity tile)
+                else scan_emit_record<W, MODE>(P, pk, 2 * (15 + ms), meta, lpart);   // list full (low-complexity tile)
                 n_members += (uint64_t)n;
                 n_trav += (ft ? 1 : 0) + (lt ? 1 : 0);
             }
@@ -269,13 +283,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     {
         const uint32_t nl = s_nrec < LIST_CAP ? s_nrec : LIST_CAP;
         for (uint32_t i = tid; i < nl; i += SCAN_THREADS)
-            scan_emit_record<W, EMIT>(P, pk, (int)(lst[2 * i] & 0xFFFFu), lst[2 * i] >> 16, lst[2 * i + 1]);
+            scan_emit_record<W, MODE>(P, pk, 2 * (15 + (int)(lst[2 * i] & 0xFFFFu)), lst[2 * i] >> 16, lst[2 * i + 1]);
     }
     CDBG_SPH(5);
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
     if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) atomic_add_u64(&P.stats[16 + i], sph[i]);
 #endif
-    if (!EMIT) {                                        // one device atomic per workgroup, not per lane
+    if (MODE != SCAN_EMIT) {                            // one device atomic per workgroup, not per lane
         uint32_t nm = (uint32_t)n_members, nt = (uint32_t)n_trav;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { nm += __shfl_xor(nm, d); nt += __shfl_xor(nt, d); }

@@ -34,7 +34,7 @@ CDBG_DEV uint32_t scanf_enc4(uint32_t x, uint32_t& vbits) {
     return (t * 0x40100401u) >> 24;                                        // b0<<6 | b1<<4 | b2<<2 | b3
 }
 
-template <int W, bool EMIT>
+template <int W, int MODE>
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
     constexpr int RW = RecFmt<W>::RW;
     constexpr int CAPB = RecFmt<W>::CAPB;
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = P.k, m = P.m, WN = k - m;
-    const int64_t t0 = (int64_t)blockIdx.x * SCANF_TILE;
+    const int64_t t0 = ((int64_t)blockIdx.x * P.tile_stride + P.tile_offset) * SCANF_TILE;
     const int64_t base = t0 - 16;
 
     // ---- A. load + encode ----
@@ -203,19 +203,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
                 const bool lt = (ce == e) && last_incl && last_trav;
                 if (ft) meta |= 0x100u;
                 if (lt) meta |= 0x200u;
-                if (EMIT) {
-                    const uint64_t slot = atomic_add_u64(&P.part_cursor[lpart], 1ULL);
-                    uint64_t* dst = P.records + slot * RW;
-                    const int bitoff = 2 * ms;
-#pragma unroll
-                    for (int wv = 0; wv < RW; ++wv) {
-                        uint64_t x = scan_get64(pk, bitoff + 64 * wv);
-                        if (wv == RW - 1) x = (x & ~0xFFFFULL) | meta;
-                        dst[RW - 1 - wv] = x;
-                    }
-                } else {
-                    atomic_add_u32(&P.part_count[lpart], 1u);
-                }
+                scan_emit_record<W, MODE>(P, pk, 2 * ms, meta, lpart);
                 n_members += (uint32_t)n;
                 n_trav += (ft ? 1u : 0u) + (lt ? 1u : 0u);
             }
@@ -223,7 +211,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
             c = ce + 1;
         }
     }
-    if (!EMIT) {
+    if (MODE != SCAN_EMIT) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { n_members += __shfl_xor(n_members, d); n_trav += __shfl_xor(n_trav, d); }
         if (lane == 0) { if (n_members) atomic_add_u32(&s_members, n_members); if (n_trav) atomic_add_u32(&s_trav, n_trav); }

@@ -144,3 +144,13 @@ def test_exchange_path_single_rank_nccl(oracle, hip):
         assert canon == exp["unitigs"]
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("part_cap", [None, "64"])
+def test_capped_single_pass_scan_gpu(oracle, hip, part_cap, monkeypatch):
+    """the large-input scan path (single pass, fixed-capacity partition regions, spill repair)"""
+    monkeypatch.setenv("CDBG_SCAN_MODE", "capped")
+    if part_cap:
+        monkeypatch.setenv("CDBG_PART_CAP", part_cap)
+    text = oracle.synth_reads(40000, 150, 3)
+    assert_parity(oracle, hip, text, 31, 2, log2_partitions=10)

@@ -92,3 +92,15 @@ def test_errors(sim):
     with pytest.raises(api.CdbgError):
         g.glue()                                  # out of order
     g.close()
+
+
+@pytest.mark.parametrize("key", ["rand_a/15/2", "rand_b/31/2", "circ_test3/7/1", "minitip/21/1"])
+@pytest.mark.parametrize("part_cap", [None, "8", "1"])
+def test_capped_single_pass_scan(oracle, sim, key, part_cap, monkeypatch):
+    """single-pass scan into fixed-capacity partition regions (the large-input path), including
+    forced spills + repair (CDBG_PART_CAP) -- same unitigs as the exact two-pass layout"""
+    monkeypatch.setenv("CDBG_SCAN_MODE", "capped")
+    if part_cap:
+        monkeypatch.setenv("CDBG_PART_CAP", part_cap)
+    name, k, amin = _case(key)
+    assert_parity(oracle, sim, oracle_lib.read_input(name), k, amin, log2_partitions=4)
