@@ -312,7 +312,7 @@ int count_impl(cdbg_ctx* c) {
     c->st.n_records = n_records; c->st.n_member_kmers = hs[0];
 
     // count
-    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + (PERSISTENT_GRID + 1) * (uint64_t)COUNT_CHUNK;
+    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + 2 * (PERSISTENT_GRID + 1) * (uint64_t)COUNT_CHUNK;
     CK(c->solid_keys.alloc(solid_cap * W, false));
     CK(c->solid_cnt.alloc(solid_cap, false));
     CK(c->solid_cursor.alloc(4, true));
@@ -362,7 +362,8 @@ int count_impl(cdbg_ctx* c) {
         CountParams bp = cp;
         bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_state = g_state.p; bp.g_cnt = g_cnt.p; bp.big_off = big_off.p;
         bp.n_items = nbig; bp.max_passes = 1;
-        CDBG_LAUNCH((k_count<W, TS, 256, true>), nbig, 256, s, bp);
+        // (grid bounded: every workgroup reserves whole output chunks, the slack is sized for PERSISTENT_GRID)
+        CDBG_LAUNCH((k_count<W, TS, 256, true>), std::min<uint64_t>(nbig, PERSISTENT_GRID), 256, s, bp);
         c->st.n_big_partitions += nbig;
     }
     CK(t.stop(&c->st.ms_count));
@@ -394,11 +395,11 @@ int compact_impl(cdbg_ctx* c) {
     CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
     CK(c->cursors.alloc(8, false));
     // glue log: <= 2 open ends + 1 confirm per junction, one junction per solid traveller at most
-    c->glog_cap = 3 * c->st.n_solid_travellers + (PERSISTENT_GRID + 1) * (uint64_t)GLOG_CHUNK + 64;
+    c->glog_cap = 3 * c->st.n_solid_travellers + 2 * (PERSISTENT_GRID + 1) * (uint64_t)GLOG_CHUNK + 64;
     CK(c->glog_keys.alloc(c->glog_cap * W, false)); CK(c->glog_tag.alloc(c->glog_cap, false));
 
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const uint64_t pslack = (PERSISTENT_GRID + 1) * (uint64_t)PIECE_CHUNK, bslack = (PERSISTENT_GRID + 1) * (uint64_t)BASES_CHUNK;
+        const uint64_t pslack = 2 * (PERSISTENT_GRID + 1) * (uint64_t)PIECE_CHUNK, bslack = 2 * (PERSISTENT_GRID + 1) * (uint64_t)BASES_CHUNK;
         const uint64_t pcap = (attempt == 0 ? std::min<uint64_t>(S, S / 3 + 4096) + 16 : S + 16) + pslack;
         const uint64_t bcap = (attempt == 0 ? S + (pcap - pslack) * (uint64_t)(c->k - 1) + 64 : S * (uint64_t)c->k + 64) + bslack;
         CK(c->piece_n.alloc(pcap, false)); HIPCK(hipMemsetAsync(c->piece_n.p, 0, pcap * sizeof(uint32_t), s));
@@ -430,6 +431,7 @@ int compact_impl(cdbg_ctx* c) {
         HIPCK(hipStreamSynchronize(s));
         uint32_t nbig = 0; CK(read_u32(c->big_count.p, &nbig));
         DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_state, g_cnt, g_lnk, g_aux;
+        if (nbig && getenv("CDBG_DEBUG_SKIP_BIG")) { fprintf(stderr, "debug: skipping %u big buckets\n", nbig); nbig = 0; }
         if (nbig) {                                          // buckets with more entries than fit LDS
             std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list.p, bl.data(), nbig));
             std::sort(bl.begin(), bl.end());
@@ -447,7 +449,7 @@ int compact_impl(cdbg_ctx* c) {
             bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_state = g_state.p; bp.g_cnt = g_cnt.p;
             bp.g_lnk = g_lnk.p; bp.g_aux = g_aux.p; bp.big_off = big_off.p;
             bp.n_items = nbig;
-            CDBG_LAUNCH((k_compact<W, TS, true>), nbig, COMPACT_THREADS, s, bp);
+            CDBG_LAUNCH((k_compact<W, TS, true>), std::min<uint64_t>(nbig, PERSISTENT_GRID), COMPACT_THREADS, s, bp);
             HIPCK(hipStreamSynchronize(s));
         }
         uint32_t e = 0; CK(read_u32(c->derr.p, &e));

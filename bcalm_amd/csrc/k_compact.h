@@ -139,7 +139,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
     if (tid == 0) { s_np = 0; s_nb = 0; s_nopen = 0; s_lw = 0; s_stat[0] = s_stat[1] = s_stat[2] = s_stat[3] = 0; }
     ktable_clear<W>(T, tid, COMPACT_THREADS);
     for (uint32_t i = tid; i < cap; i += COMPACT_THREADS) vis[i] = 0;
-    __syncthreads();
+    block_sync<GLOBAL>();
 
     // ---- load the bucket: home + traveller solid k-mers ----
     const uint64_t so = P.seg_off[p];
@@ -150,7 +150,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         cnt[s] = P.solid_cnt[so + e];
         slots[e] = s;
     }
-    __syncthreads();
+    block_sync<GLOBAL>();
     CDBG_PH(1);
 
     // ---- classify both ends of every entry ----
@@ -180,7 +180,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         }
         lnk[idx] = (home ? link : LNK_DEAD) | (conf ? LNK_CONF : 0u);
     }
-    __syncthreads();
+    block_sync<GLOBAL>();
     CDBG_PH(2);
 
     // ---- walk 1: every terminal end measures its piece; the smaller terminal id registers it ----
@@ -205,7 +205,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
             if (no) atomic_add_u32(&s_nopen, no);
         }
     }
-    __syncthreads();
+    block_sync<GLOBAL>();
     CDBG_PH(3);
     // ---- closed chains entirely inside the bucket (isolated cycles): cut at the smallest slot ----
     for (uint32_t it = tid; it < E; it += COMPACT_THREADS) {
@@ -224,7 +224,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
             atomic_add_u32(&s_stat[2], 1u);
         }
     }
-    __syncthreads();
+    block_sync<GLOBAL>();
     if (tid == 0) {
         s_stat[3] = s_np;                                // pieces really written (ids also cover reservation gaps)
         // sub-allocate piece ids and base bytes from this workgroup's chunks
@@ -241,10 +241,10 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         else { if (nlog > lc_left) { lc_base = atomic_add_u64(P.glog_cursor, (uint64_t)GLOG_CHUNK); lc_left = GLOG_CHUNK; }
                lb = lc_base; lc_base += nlog; lc_left -= nlog; }
         if (pb + s_np > P.piece_cap || bb + s_nb > P.bases_cap) { *P.error = 3; s_np = 0; }
-        if (lb + nlog > P.glog_cap) { *P.error = 5; s_np = 0; }
+        if (lb + nlog > P.glog_cap) { *P.error = 5; s_np = 0; lb = 0; s_stat[1] = 0; }   // never write past the log
         s_pbase = pb; s_bbase = bb; s_lbase = lb; s_nb = 0;
     }
-    __syncthreads();
+    block_sync<GLOBAL>();
 
     CDBG_PH(4);
     // ---- glue log, part 1: CONFIRM records (dense over all ends; no device atomics) ----
@@ -259,7 +259,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
             P.glog_tag[o] = GTAG_CONFIRM;
         }
     }
-    __syncthreads();
+    block_sync<GLOBAL>();
     // ---- walk 2: one lane per piece writes bases, size, abundance and marks its open ends ----
     for (uint32_t li = tid; li < np; li += COMPACT_THREADS) {
         const uint32_t d = pdesc[li];
@@ -297,7 +297,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
             if (orr) lnk[ir] = LNK_POSTED | (uint32_t)(pid * 2 + 1);
         }
     }
-    __syncthreads();
+    block_sync<GLOBAL>();
     // ---- glue log, part 2: one record per open piece end (dense over all ends) ----
     if (np) {
         uint32_t my_open = 0;
@@ -313,7 +313,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         }
         if (my_open) atomic_add_u32(&s_stat[0], my_open);
     }
-    __syncthreads();
+    block_sync<GLOBAL>();
     CDBG_PH(5);
     if (tid == 0) for (int i = 0; i < 4; ++i) acc[i] += (uint64_t)s_stat[i];
 }

@@ -57,6 +57,16 @@ CDBG_DEV Kmer<W> ktable_key(const KTable<W>& t, uint32_t s) {
     for (int i = 0; i < W; ++i) r.w[i] = t.keys[(uint64_t)s * W + i];
     return r;
 }
+// Workgroup barrier for tables that may live in HBM scratch (GLOBAL): the CU's vector L1 is not
+// guaranteed to reflect other waves' global stores / L2 atomics, so drop it after the barrier
+// (agent-scope fence = buffer_inv; MI355X_MICROARCH "inter-workgroup visibility" applies to the
+// stale-line case within a CU as well).  LDS tables need only the barrier.
+template <bool GLOBAL>
+CDBG_DEV void block_sync() {
+    if (GLOBAL) __threadfence();
+    __syncthreads();
+    if (GLOBAL) __threadfence();
+}
 // find-or-insert; returns slot, sets is_new.  GLOBAL selects the fence flavour.
 // Gives up (returns 0xFFFFFFFF) after max_probe occupied slots, so a full table cannot hang a lane.
 template <int W, bool GLOBAL>
@@ -249,7 +259,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                 if (tid == 0) s_fill = 0;
                 ktable_clear<W>(T, tid, NT);
                 for (uint32_t i = tid; i < cap; i += NT) cnt[i] = 0;
-                __syncthreads();
+                block_sync<GLOBAL>();
                 CDBG_PH(1);
                 for (uint64_t b0 = rec0 + (uint64_t)wave * RB; b0 < rec1; b0 += (uint64_t)NW * RB) {   // wave-uniform
                     if (__any((int)ld_volatile_u32(&s_over))) break;
@@ -297,7 +307,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     }
                     CDBG_WAVE_SYNC();                              // map is rewritten by the next batch
                 }
-                __syncthreads();
+                block_sync<GLOBAL>();
                 CDBG_PH(2);
                 if (s_over) { overflow = true; break; }
                 // ---- sweep: statistics + number of solid entries (phase 0) ----
@@ -321,7 +331,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                         if (pk1 & 0xFFFFu) atomic_add_u32(&s_stat[2], pk1 & 0xFFFFu);
                         if (pk1 >> 16) atomic_add_u32(&s_stat[3], pk1 >> 16);
                     }
-                    __syncthreads();
+                    block_sync<GLOBAL>();
                     if (pass == npass - 1 && tid == 0) {          // everything counted: reserve the segment
                         // sub-allocate from this workgroup's chunk: one device atomic per COUNT_CHUNK entries
                         uint64_t b;
@@ -334,7 +344,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                         s_base = b;
                         P.seg_off[p] = b; P.seg_n[p] = s_nsolid;
                     }
-                    if (pass == npass - 1) __syncthreads();
+                    if (pass == npass - 1) block_sync<GLOBAL>();
                     CDBG_PH(3);
                 }
                 // ---- sweep: write solid entries (single pass: right away; multi-pass: phase 1) ----
@@ -351,12 +361,12 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                         }
                     }
                 }
-                __syncthreads();
+                block_sync<GLOBAL>();
                 CDBG_PH(4);
             }
         }
         if (!overflow) break;
-        __syncthreads();
+        block_sync<GLOBAL>();
         if (GLOBAL) { if (tid == 0) *P.error = 2; return; }     // scratch sizing bug: cannot happen by construction
         npass *= 2;
         if (npass > P.max_passes) {                               // hopeless in LDS: defer to the HBM pass
