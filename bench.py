@@ -29,6 +29,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r01_b_pmc_hbm_traffic_per_kernel.csv")
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (bench_micro/pmc_bench.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench;
+    bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 FETCH_SIZE halving corrected as
+    MI355X_MICROARCH.md section HBM prescribes).  None when the profile is absent."""
+    try:
+        import csv
+        for row in csv.reader(open(PMC_TRAFFIC_CSV)):
+            if len(row) == 5 and kernel_key in row[0]:
+                return float(row[4]) * 1e9
+    except Exception:
+        pass
+    return None
 
 
 def alg_bytes(k, st, n_reads, read_len):
@@ -189,7 +205,10 @@ def main():
             "counts": {x: st[x] for x in ("n_occurrences", "n_distinct", "n_solid", "n_pieces", "n_unitigs", "n_records", "n_big_partitions")},
             "stage_ms": {x: acc[x] / a.steps for x in acc},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic({"k_count": "k_count<", "k_compact": "k_compact<", "k_scan<emit>": "k_scan_fast<1, 2>",
+                                                 "k_scan<hist>": "k_scan_fast<1, 0>"}.get(dom, "k_glue_build")),
+                         "traffic_source": "profiles/r01_b_pmc_hbm_traffic_per_kernel.csv (separate rocprofv3 --pmc passes)",
                          "alg_bytes_per_launch": per_kernel[dom], "avg_launch_ms": dom_ms,
                          "pipeline": {"alg_bytes": alg_total, "gpu_ms": gpu_ms,
                                       "achieved": alg_total / (gpu_ms * 1e-3) / 1e9,
