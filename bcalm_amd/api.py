@@ -42,7 +42,7 @@ class Stats(C.Structure):
 EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
            "cdbg_generate_reads", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
            "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats",
-           "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end"]
+           "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end"]
 
 
 def load(path: str | None = None) -> C.CDLL:
@@ -67,6 +67,9 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_num_unitigs.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     lib.cdbg_fetch_unitigs.argtypes = [vp, u64, u64, C.c_char_p, C.POINTER(u64), C.POINTER(u64)]
     lib.cdbg_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.cdbg_link.argtypes = [vp]
+    lib.cdbg_num_links.argtypes = [vp, C.POINTER(u64)]
+    lib.cdbg_fetch_links.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_uint32)]
     lib.cdbg_exchange_sizes.argtypes = [vp, C.POINTER(u64)]
     lib.cdbg_exchange_export.argtypes = [vp, i32, vp, u64]
     lib.cdbg_exchange_begin.argtypes = [vp, u64, u64, u64]
@@ -149,6 +152,27 @@ class Graph:
 
     def reset(self):
         self._ck(self.lib.cdbg_reset(self._h))
+
+    def links(self):
+        """-> per unitig (same order as unitigs()) a list of (from_sign, target_unitig, to_sign)"""
+        self._ck(self.lib.cdbg_link(self._h))
+        n, tb = C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.cdbg_num_unitigs(self._h, C.byref(n), C.byref(tb)))
+        U = n.value
+        nl = C.c_uint64()
+        self._ck(self.lib.cdbg_num_links(self._h, C.byref(nl)))
+        off = (C.c_uint64 * (2 * U + 1))()
+        to = (C.c_uint32 * max(nl.value, 1))()
+        self._ck(self.lib.cdbg_fetch_links(self._h, off, to))
+        out = []
+        for u in range(U):
+            l = []
+            for side, fs in ((1, "+"), (0, "-")):
+                for i in range(off[2 * u + side], off[2 * u + side + 1]):
+                    t = to[i]
+                    l.append((fs, t >> 1, "+" if (t & 1) == 0 else "-"))
+            out.append(l)
+        return out
 
     # ---- multi-GPU exchange (see bcalm_amd/dist.py) ----
     def exchange_sizes(self):

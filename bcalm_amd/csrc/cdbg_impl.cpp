@@ -22,7 +22,7 @@
 #include <string>
 #include <vector>
 
-#include "k_glue.h"
+#include "k_links.h"
 
 using namespace cdbg;
 
@@ -116,6 +116,7 @@ struct cdbg_ctx {
 
     DBuf<uint64_t> unitig_off; DBuf<uint32_t> unitig_len; DBuf<uint64_t> unitig_kc; DBuf<uint8_t> unitig_bases;
     uint64_t n_unitigs = 0, unitig_total = 0;
+    DBuf<uint64_t> link_off; DBuf<uint32_t> link_to; uint64_t n_links = 0; bool linked = false;
 };
 
 namespace {
@@ -557,6 +558,43 @@ int glue_impl(cdbg_ctx* c) {
     return CDBG_OK;
 }
 
+template <int W>
+int link_impl(cdbg_ctx* c) {
+    if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_link before cdbg_glue");
+    hipStream_t s = c->stream;
+    const uint64_t U = c->n_unitigs, NE = 2 * U;
+    if (NE >= 0x3FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many unitigs for 30-bit end slots");
+    const uint32_t cap = (uint32_t)pow2_at_least(4 * U + 64);
+    DBuf<uint64_t> lk_keys; DBuf<uint32_t> lk_state, lk_cnt, lk_ends, end_slot, deg;
+    CK(lk_keys.alloc((uint64_t)cap * W, false)); CK(lk_state.alloc(cap, true)); CK(lk_cnt.alloc((uint64_t)cap * 2, true));
+    CK(lk_ends.alloc((uint64_t)cap * 8, false)); CK(end_slot.alloc(NE, false)); CK(deg.alloc(NE, false));
+    HIPCK(hipMemsetAsync(lk_keys.p, 0xFF, (uint64_t)cap * W * sizeof(uint64_t), s));
+    CK(c->link_off.alloc(NE + 1, true));
+    LinkParams lp{};
+    lp.n_unitigs = U; lp.k = c->k; lp.unitig_off = c->unitig_off.p; lp.unitig_len = c->unitig_len.p; lp.bases = c->unitig_bases.p;
+    lp.lk_keys = lk_keys.p; lp.lk_state = lk_state.p; lp.lk_cnt = lk_cnt.p; lp.lk_ends = lk_ends.p; lp.lk_mask = cap - 1;
+    lp.end_slot = end_slot.p; lp.deg = deg.p;
+    c->n_links = 0;
+    if (NE) {
+        const uint64_t grid = (NE + LINK_THREADS - 1) / LINK_THREADS;
+        CDBG_LAUNCH((k_link_insert<W>), grid, LINK_THREADS, s, lp);
+        CDBG_LAUNCH(k_link_count, grid, LINK_THREADS, s, lp);
+        const uint64_t nb = (NE + EXSCAN_BLOCK - 1) / EXSCAN_BLOCK;
+        CK(c->exscan_tmp.alloc(nb + 1, false));
+        const uint32_t* degp = deg.p;                        // (plain pointer: launch arguments are captured by value)
+        CDBG_LAUNCH(k_exscan_sums, nb, EXSCAN_THREADS, s, degp, c->exscan_tmp.p, NE);
+        CDBG_LAUNCH(k_exscan_top, 1, EXSCAN_THREADS, s, c->exscan_tmp.p, nb, c->link_off.p + NE);
+        CDBG_LAUNCH(k_exscan_apply, nb, EXSCAN_THREADS, s, degp, (const uint64_t*)c->exscan_tmp.p, c->link_off.p, NE);
+        CK(read_u64(c->link_off.p + NE, &c->n_links));
+        CK(c->link_to.alloc(c->n_links, false));
+        lp.link_off = c->link_off.p; lp.link_to = c->link_to.p;
+        CDBG_LAUNCH(k_link_fill, grid, LINK_THREADS, s, lp);
+        HIPCK(hipStreamSynchronize(s));
+    }
+    c->linked = true;
+    return CDBG_OK;
+}
+
 }  // namespace
 
 // =======================================================================================
@@ -648,10 +686,23 @@ int cdbg_count(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context");
 int cdbg_compact(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(compact_impl) }
 int cdbg_glue(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(glue_impl) }
 int cdbg_run(cdbg_ctx* c) { CK(cdbg_count(c)); CK(cdbg_compact(c)); return cdbg_glue(c); }
+int cdbg_link(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(link_impl) }
+int cdbg_num_links(cdbg_ctx* c, uint64_t* n) {
+    if (!c || !n) return fail(CDBG_E_PARAM, "null argument");
+    if (!c->linked) return fail(CDBG_E_STATE, "cdbg_num_links before cdbg_link");
+    *n = c->n_links; return CDBG_OK;
+}
+int cdbg_fetch_links(cdbg_ctx* c, uint64_t* end_off, uint32_t* link_to) {
+    if (!c || !end_off) return fail(CDBG_E_PARAM, "null argument");
+    if (!c->linked) return fail(CDBG_E_STATE, "cdbg_fetch_links before cdbg_link");
+    HIPCK(hipMemcpy(end_off, c->link_off.p, (2 * c->n_unitigs + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (c->n_links && link_to) HIPCK(hipMemcpy(link_to, c->link_to.p, c->n_links * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CDBG_OK;
+}
 int cdbg_reset(cdbg_ctx* c) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
     c->stage = 0; c->st = cdbg_stats_t{};
-    c->n_solid_entries = c->n_pieces = c->n_piece_bases = c->n_unitigs = c->unitig_total = 0;
+    c->n_solid_entries = c->n_pieces = c->n_piece_bases = c->n_unitigs = c->unitig_total = 0; c->linked = false; c->n_links = 0;
     return CDBG_OK;                                  // reads and every device buffer stay resident
 }
 

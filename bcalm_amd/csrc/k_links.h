@@ -1,0 +1,83 @@
+// k_links.h -- edges between unitigs.
+//
+// New MI355X design for what gatb-core's link_tigs does after bglue (the `L:<+/->:<id>:<+/->`
+// tokens of /root/reference/README.md:62-72 and the GFA1 `L` lines of
+// /root/reference/scripts/convertToGFA.py:103-112; edge semantics:
+// /root/reference/bidirected-graphs-in-bcalm2/bidirected-graphs-in-bcalm2.md:39-46,100-103).
+//
+// Only the first and last k-mer of a unitig can have edges to other unitigs, and an edge is a
+// (k-1)-overlap, so this is one more hash-join on junction (k-1)-mers: every unitig END (2 per
+// unitig) is keyed by the canonical (k-1)-mer it reaches when LEAVING the unitig through that end,
+// plus a flag telling on which strand of the key it leaves.  Leaving through end e enters every
+// end e' with the same key and the opposite flag (same flag when the key is its own reverse
+// complement: a palindromic junction, where the edge back into e itself is the self-mirror edge of
+// .md:30).  Link of unitig u:  from-sign '+' = leaving through its last k-mer, '-' = through the
+// reverse complement of its first k-mer;  to-sign '+' = entering v at its first k-mer, '-' = at the
+// reverse complement of its last k-mer.
+#pragma once
+#include "k_glue.h"
+
+namespace cdbg {
+
+constexpr int LINK_THREADS = 256;
+
+template <int W>
+struct LinkTable {
+    KTable<W> t;
+    uint32_t* cnt;        // [cap * 2]  ends seen per flag
+    uint32_t* ends;       // [cap * 8]  up to 4 end ids per flag
+};
+struct LinkParams {
+    uint64_t n_unitigs; int k;
+    const uint64_t* unitig_off; const uint32_t* unitig_len; const uint8_t* bases;
+    uint64_t* lk_keys; uint32_t* lk_state; uint32_t* lk_cnt; uint32_t* lk_ends; uint32_t lk_mask;
+    uint32_t* end_slot;   // [2U] table slot of each end (bit 31 = flag, bit 30 = palindromic key)
+    uint32_t* deg;        // [2U] out-degree of each end
+    const uint64_t* link_off; uint32_t* link_to;   // fill pass
+};
+
+// out-going oriented k-mer of end e of a unitig held as ASCII
+template <int W>
+CDBG_DEV Kmer<W> link_end_kmer(const uint8_t* s, uint32_t len, int k, uint32_t side) {
+    Kmer<W> x = Kmer<W>::zero();
+    const uint8_t* p = side ? s + (len - (uint32_t)k) : s;
+    for (int i = 0; i < k; ++i) x.push_right(k, base_code(p[i]));
+    return side ? x : x.rc(k);
+}
+
+template <int W>
+__global__ void k_link_insert(LinkParams P) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * P.n_unitigs) return;
+    const uint64_t u = e >> 1; const uint32_t side = (uint32_t)(e & 1);
+    const Kmer<W> x = link_end_kmer<W>(P.bases + P.unitig_off[u], P.unitig_len[u], P.k, side);
+    Kmer<W> j = suffix_km1<W>(x, P.k);
+    const Kmer<W> r = j.rc(P.k - 1);
+    const bool pal = (r == j);
+    const uint32_t flag = (!pal && r < j) ? 1u : 0u;
+    const Kmer<W> jc = flag ? r : j;
+    const KTable<W> T{ P.lk_keys, P.lk_state, P.lk_mask };
+    bool nw; const uint32_t s = ktable_insert<W, true>(T, jc, nw);
+    const uint32_t idx = atomic_add_u32(&P.lk_cnt[s * 2 + flag], 1u);
+    if (idx < 4) P.lk_ends[s * 8 + flag * 4 + idx] = (uint32_t)e;
+    P.end_slot[e] = s | (flag << 31) | (pal ? (1u << 30) : 0u);
+}
+__global__ void k_link_count(LinkParams P) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * P.n_unitigs) return;
+    const uint32_t v = P.end_slot[e], s = v & 0x3FFFFFFFu, flag = v >> 31, pal = (v >> 30) & 1u;
+    const uint32_t other = pal ? flag : flag ^ 1u;
+    const uint32_t c = P.lk_cnt[s * 2 + other];
+    P.deg[e] = c < 4 ? c : 4;
+}
+__global__ void k_link_fill(LinkParams P) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * P.n_unitigs) return;
+    const uint32_t v = P.end_slot[e], s = v & 0x3FFFFFFFu, flag = v >> 31, pal = (v >> 30) & 1u;
+    const uint32_t other = pal ? flag : flag ^ 1u;
+    const uint32_t c = P.deg[e];
+    const uint64_t o = P.link_off[e];
+    for (uint32_t i = 0; i < c; ++i) P.link_to[o + i] = P.lk_ends[s * 8 + other * 4 + i];
+}
+
+}  // namespace cdbg

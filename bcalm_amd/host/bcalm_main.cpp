@@ -150,6 +150,11 @@ int main(int argc, char** argv) {
         uint64_t nu = 0, tb = 0; check(cdbg_num_unitigs(ctx, &nu, &tb));
         std::vector<char> seq(tb + 1); std::vector<uint64_t> off(nu + 1), kc(nu ? nu : 1);
         check(cdbg_fetch_unitigs(ctx, 0, nu, seq.data(), off.data(), kc.data()));
+        // edges between unitigs (README.md:72 L: tokens; convertToGFA.py:103-112 GFA L lines)
+        check(cdbg_link(ctx));
+        uint64_t nl = 0; check(cdbg_num_links(ctx, &nl));
+        std::vector<uint64_t> loff(2 * nu + 1); std::vector<uint32_t> lto(nl ? nl : 1);
+        check(cdbg_fetch_links(ctx, loff.data(), lto.data()));
         auto t2 = std::chrono::steady_clock::now();
 
         const std::string fa = prefix + ".unitigs.fa";
@@ -160,10 +165,17 @@ int main(int argc, char** argv) {
         for (uint64_t i = 0; i < nu; ++i) {
             const uint64_t len = off[i + 1] - off[i];
             const double km = (double)kc[i] / (double)(len - (uint64_t)o.k + 1);
-            fprintf(out, ">%llu LN:i:%llu KC:i:%llu km:f:%.1f \n", (unsigned long long)i, (unsigned long long)len, (unsigned long long)kc[i], km);
-            fwrite(seq.data() + off[i], 1, len, out); fputc('\n', out);
+            fprintf(out, ">%llu LN:i:%llu KC:i:%llu km:f:%.1f", (unsigned long long)i, (unsigned long long)len, (unsigned long long)kc[i], km);
             if (gfa) { fprintf(gfa, "S\t%llu\t", (unsigned long long)i); fwrite(seq.data() + off[i], 1, len, gfa);
                        fprintf(gfa, "\tLN:i:%llu\tKC:i:%llu\tkm:f:%.1f\n", (unsigned long long)len, (unsigned long long)kc[i], km); }
+            for (int side = 1; side >= 0; --side)            // '+' links (through the last k-mer) first, then '-'
+                for (uint64_t j = loff[2 * i + side]; j < loff[2 * i + side + 1]; ++j) {
+                    const char fs = side ? '+' : '-', ts = (lto[j] & 1u) ? '-' : '+';
+                    fprintf(out, " L:%c:%u:%c", fs, lto[j] >> 1, ts);
+                    if (gfa) fprintf(gfa, "L\t%llu\t%c\t%u\t%c\t%dM\n", (unsigned long long)i, fs, lto[j] >> 1, ts, o.k - 1);
+                }
+            fputs(" \n", out);
+            fwrite(seq.data() + off[i], 1, len, out); fputc('\n', out);
         }
         fclose(out); if (gfa) fclose(gfa);
         auto t3 = std::chrono::steady_clock::now();

@@ -122,6 +122,16 @@ int cdbg_num_unitigs(cdbg_ctx* ctx, uint64_t* n, uint64_t* total_bases);
 int cdbg_fetch_unitigs(cdbg_ctx* ctx, uint64_t first, uint64_t n, char* seq_buf, uint64_t* seq_off, uint64_t* kc);
 int cdbg_stats(cdbg_ctx* ctx, cdbg_stats_t* out);
 
+/* Edges between unitigs (the `L:<+/->:<id>:<+/->` tokens of /root/reference/README.md:62-72; GFA `L`
+ * lines of scripts/convertToGFA.py:103-112).  After cdbg_glue: cdbg_link builds them on the GPU.
+ * cdbg_fetch_links: end_off[2U+1] offsets per unitig END (end 2u = leaving u through the reverse
+ * complement of its first k-mer, from-sign '-'; end 2u+1 = leaving through its last k-mer, from-sign
+ * '+'); link_to[i] = target end 2v+side: side 0 = enters v at its first k-mer (to-sign '+'),
+ * side 1 = enters the reverse complement of its last k-mer (to-sign '-'). */
+int cdbg_link(cdbg_ctx* ctx);
+int cdbg_num_links(cdbg_ctx* ctx, uint64_t* n);
+int cdbg_fetch_links(cdbg_ctx* ctx, uint64_t* end_off, uint32_t* link_to);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,3 +154,21 @@ def read_fasta_text(path: str) -> str:
     if cur:
         recs.append("".join(cur))
     return "\n".join(recs) + "\n"
+
+
+def links(unitig_seqs, k: int):
+    """Edges between unitigs, by brute force over all pairs of ends (spec:
+    bidirected-graphs-in-bcalm2.md:39-46,100-103; token format README.md:72).
+    -> set of (u, from_sign, v, to_sign): leaving u (as given for '+', reverse-complemented for
+    '-') through its last k-1 bases equals entering v ('+': as given, '-': reverse-complemented)
+    at its first k-1 bases."""
+    out = set()
+    ori = {"+": lambda s: s, "-": revcomp}
+    for u, su in enumerate(unitig_seqs):
+        for fs in "+-":
+            tail = ori[fs](su)[-(k - 1):]
+            for v, sv in enumerate(unitig_seqs):
+                for ts in "+-":
+                    if ori[ts](sv)[:k - 1] == tail:
+                        out.add((u, fs, v, ts))
+    return out

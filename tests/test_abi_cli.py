@@ -72,7 +72,7 @@ def _parse_fa(path):
     lines = open(path).read().split("\n")
     for i in range(0, len(lines) - 1, 2):
         h = lines[i]
-        m = re.match(r">(\d+) LN:i:(\d+) KC:i:(\d+) km:f:(\d+\.\d) ", h)
+        m = re.match(r">(\d+) LN:i:(\d+) KC:i:(\d+) km:f:(\d+\.\d)((?: L:[+-]:\d+:[+-])*) $", h)
         assert m, h
         recs.append((lines[i + 1], int(m.group(2)), int(m.group(3)), float(m.group(4))))
     return recs
@@ -100,7 +100,12 @@ def test_cli_contract(cli, oracle, tmp_path):
     recs = _parse_fa(tmp_path / "xyz.unitigs.fa")
     exp = oracle.run("ACTGATGCAGATGACACTGATGCAGATGAC\nATGACACTGATGCAGATGACAGTAGTGGGG\n", 21, 1)
     assert oracle_lib.canonical_set(oracle, [(s, kc) for s, _, kc, _ in recs], 21) == exp["unitigs"]
-    assert (tmp_path / "xyz.unitigs.gfa").read_text().startswith("H\tVN:Z:1.0\tks:i:21\n")
+    gfa = (tmp_path / "xyz.unitigs.gfa").read_text()
+    assert gfa.startswith("H\tVN:Z:1.0\tks:i:21\n")
+    # L tokens of the FASTA header and GFA L lines agree; overlap is (k-1)M (convertToGFA.py:103-112)
+    fa_links = re.findall(r" L:([+-]):(\d+):([+-])", (tmp_path / "xyz.unitigs.fa").read_text())
+    gfa_links = re.findall(r"^L\t\d+\t([+-])\t(\d+)\t([+-])\t20M$", gfa, flags=re.M)
+    assert sorted(fa_links) == sorted(gfa_links)
 
 
 def test_cli_errors(cli, tmp_path):
