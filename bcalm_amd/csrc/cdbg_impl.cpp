@@ -480,9 +480,8 @@ int glue_impl(cdbg_ctx* c) {
     if (2 * NP >= 0xFFFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 32-bit end ids (%llu)", (unsigned long long)NP);
     const uint32_t NS = (uint32_t)(2 * NP);
     Timer t; CK(t.start(s));
-    DBuf<uint32_t> link, nxt_a, nxt_b, acc_a, acc_b, tail_a, tail_b, minp_a, minp_b, flag, head_uid;
-    CK(link.alloc(NS, false)); CK(nxt_a.alloc(NS, false)); CK(nxt_b.alloc(NS, false)); CK(acc_a.alloc(NS, false)); CK(acc_b.alloc(NS, false));
-    CK(tail_a.alloc(NS, false)); CK(tail_b.alloc(NS, false)); CK(minp_a.alloc(NS, false)); CK(minp_b.alloc(NS, false));
+    DBuf<uint32_t> link, flag, head_uid; DBuf<uint4> st_a, st_b;
+    CK(link.alloc(NS, false)); CK(st_a.alloc(NS, false)); CK(st_b.alloc(NS, false));
     CK(flag.alloc(4, true)); CK(head_uid.alloc(NS, false));
     HIPCK(hipMemsetAsync(link.p, 0xFF, (size_t)std::max<uint32_t>(NS, 1) * sizeof(uint32_t), s));
     HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
@@ -500,29 +499,28 @@ int glue_impl(cdbg_ctx* c) {
     uint64_t n_cycles_cut = 0;
     const uint32_t gridS = (NS + GLUE_THREADS - 1) / GLUE_THREADS;
     RankParams rp{};
-    uint32_t *fa_nxt = nullptr, *fa_acc = nullptr, *fa_tail = nullptr;      // final arrays
+    uint4* fa_st = nullptr;                                  // final state array
     if (NS) {
         int max_rounds = 2; while ((1ull << (max_rounds - 1)) < NS) ++max_rounds;
         for (int pass = 0; pass < 2; ++pass) {
             rp.n_states = NS; rp.link = link.p; rp.piece_n = c->piece_n.p;
-            rp.nxt_a = nxt_a.p; rp.nxt_b = nxt_b.p; rp.acc_a = acc_a.p; rp.acc_b = acc_b.p;
-            rp.tail_a = tail_a.p; rp.tail_b = tail_b.p; rp.minp_a = minp_a.p; rp.minp_b = minp_b.p; rp.changed = flag.p;
+            rp.st_a = st_a.p; rp.st_b = st_b.p; rp.changed = flag.p;
             CDBG_LAUNCH(k_rank_init, gridS, GLUE_THREADS, s, rp);
             bool converged = false;
             for (int r = 0; r < max_rounds; ++r) {
                 HIPCK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), s));
                 CDBG_LAUNCH(k_rank_jump, gridS, GLUE_THREADS, s, rp);
-                std::swap(rp.nxt_a, rp.nxt_b); std::swap(rp.acc_a, rp.acc_b); std::swap(rp.tail_a, rp.tail_b); std::swap(rp.minp_a, rp.minp_b);
+                std::swap(rp.st_a, rp.st_b);
                 HIPCK(hipStreamSynchronize(s));
                 uint32_t ch = 0; CK(read_u32(flag.p, &ch));
                 if (!ch) { converged = true; break; }
             }
-            fa_nxt = rp.nxt_a; fa_acc = rp.acc_a; fa_tail = rp.tail_a;
+            fa_st = rp.st_a;
             if (converged) break;
             if (pass == 1) return fail(CDBG_E_INTERNAL, "list ranking did not converge after cutting cycles");
             // closed chains: cut each at its smallest piece, then rank again
             HIPCK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), s));
-            CutParams cu{ NS, rp.nxt_a, rp.minp_a, link.p, flag.p };
+            CutParams cu{ NS, rp.st_a, link.p, flag.p };
             CDBG_LAUNCH(k_cut_cycles, gridS, GLUE_THREADS, s, cu);
             HIPCK(hipStreamSynchronize(s));
             uint32_t nc = 0; CK(read_u32(flag.p, &nc)); n_cycles_cut += nc;
@@ -536,17 +534,16 @@ int glue_impl(cdbg_ctx* c) {
     HIPCK(hipMemsetAsync(c->cursors.p + 2, 0, 2 * sizeof(uint64_t), s));
     if (NS) {
         HeadParams hp{};
-        hp.n_states = NS; hp.k = c->k; hp.link = link.p; hp.acc = fa_acc; hp.tail = fa_tail; hp.head_uid = head_uid.p;
+        hp.n_states = NS; hp.k = c->k; hp.link = link.p; hp.st = fa_st; hp.head_uid = head_uid.p;
         hp.unitig_off = c->unitig_off.p; hp.unitig_len = c->unitig_len.p; hp.unitig_kc = c->unitig_kc.p;
         hp.unitig_cap = ucap; hp.out_cap = ocap; hp.n_unitigs = c->cursors.p + 2; hp.out_cursor = c->cursors.p + 3; hp.error = c->derr.p;
         CDBG_LAUNCH(k_unitig_heads, gridS, GLUE_THREADS, s, hp);
         EmitParams ep{};
-        ep.n_pieces = (uint32_t)NP; ep.k = c->k; ep.acc = fa_acc; ep.tail = fa_tail; ep.head_uid = head_uid.p;
+        ep.n_pieces = (uint32_t)NP; ep.k = c->k; ep.st = fa_st; ep.head_uid = head_uid.p;
         ep.piece_n = c->piece_n.p; ep.piece_kc = c->piece_kc.p; ep.piece_boff = c->piece_boff.p; ep.piece_bases = c->piece_bases.p;
         ep.unitig_off = c->unitig_off.p; ep.unitig_kc = c->unitig_kc.p; ep.out = c->unitig_bases.p;
         CDBG_LAUNCH(k_emit, (uint32_t)((NP + GLUE_THREADS - 1) / GLUE_THREADS), GLUE_THREADS, s, ep);
     }
-    (void)fa_nxt;
     CK(t.stop(&c->st.ms_glue));
     CK(check_device_error(c, "glue"));
     uint64_t cur[2]; CK(read_u64(c->cursors.p + 2, cur, 2));

@@ -310,6 +310,57 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                 block_sync<GLOBAL>();
                 CDBG_PH(2);
                 if (s_over) { overflow = true; break; }
+                // ---- single pass: ONE sweep.  The segment is reserved for the table's fill (an upper bound
+                // of the solid entries), solid entries are written compactly, the unused tail goes back to the
+                // workgroup's chunk.
+                if (npass == 1) {
+                    if (tid == 0) {
+                        const uint32_t need = s_fill;
+                        uint64_t b;
+                        if (need > COUNT_CHUNK) b = atomic_add_u64(P.solid_cursor, (uint64_t)need);
+                        else {
+                            if (need > chunk_left) { chunk_base = atomic_add_u64(P.solid_cursor, (uint64_t)COUNT_CHUNK); chunk_left = COUNT_CHUNK; }
+                            b = chunk_base; chunk_base += need; chunk_left -= need;
+                        }
+                        if (b + need > P.solid_cap) { *P.error = 1; b = 0; s_over = 2; }
+                        s_base = b;
+                    }
+                    block_sync<GLOBAL>();
+                    const uint64_t obase = s_base; const bool wr_ok = s_over == 0;
+                    uint32_t st_dist = 0, st_occ = 0, st_sh = 0, st_st = 0;
+                    for (uint32_t s = tid; s < cap; s += NT) {
+                        if (!ktable_used<W>(T, s)) continue;
+                        const uint32_t c = cnt[s], n = c & ~TRAV_FLAG; const bool trav = c & TRAV_FLAG;
+                        if (!trav) { ++st_dist; st_occ += n; }
+                        if (n >= P.amin) {
+                            if (trav) ++st_st; else ++st_sh;
+                            if (wr_ok) {
+                                const uint64_t o = obase + atomic_add_u32(&s_wr, 1u);
+                                for (int i = 0; i < W; ++i) P.solid_keys[o * W + i] = T.keys[(uint64_t)s * W + i];
+                                P.solid_cnt[o] = c;
+                            }
+                        }
+                    }
+                    uint32_t pk0 = st_dist, pk1 = st_sh | (st_st << 16);
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) { pk0 += __shfl_xor(pk0, d); pk1 += __shfl_xor(pk1, d); st_occ += __shfl_xor(st_occ, d); }
+                    if (lane == 0) {
+                        if (pk0) atomic_add_u32(&s_stat[0], pk0);
+                        if (st_occ) atomic_add_u32(&s_stat[1], st_occ);
+                        if (pk1 & 0xFFFFu) atomic_add_u32(&s_stat[2], pk1 & 0xFFFFu);
+                        if (pk1 >> 16) atomic_add_u32(&s_stat[3], pk1 >> 16);
+                    }
+                    block_sync<GLOBAL>();
+                    if (tid == 0) {
+                        const uint32_t used = s_wr, need = s_fill;
+                        P.seg_off[p] = obase; P.seg_n[p] = used;
+                        if (need <= COUNT_CHUNK && wr_ok) { chunk_base -= (need - used); chunk_left += (need - used); }   // return the tail
+                    }
+                    CDBG_PH(3);
+                    block_sync<GLOBAL>();
+                    CDBG_PH(4);
+                    continue;
+                }
                 // ---- sweep: statistics + number of solid entries (phase 0) ----
                 if (phase == 0) {
                     uint32_t my_solid = 0, st_dist = 0, st_occ = 0, st_sh = 0, st_st = 0;
@@ -347,8 +398,8 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     if (pass == npass - 1) block_sync<GLOBAL>();
                     CDBG_PH(3);
                 }
-                // ---- sweep: write solid entries (single pass: right away; multi-pass: phase 1) ----
-                if (npass == 1 || phase == 1) {
+                // ---- sweep: write solid entries (multi-pass: phase 1) ----
+                if (phase == 1) {
                     const uint64_t obase = s_base;
                     if (s_nsolid) {
                         for (uint32_t s = tid; s < cap; s += NT) {

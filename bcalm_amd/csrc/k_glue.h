@@ -47,44 +47,42 @@ __global__ void k_glue_resolve(GlueResolveParams P) {
 }
 
 // ---- (2) pointer jumping ----
+// per traversal state one 16-byte record {nxt, acc, tail, minp}: a jump is ONE random 16-byte gather
+// instead of four 4-byte gathers from four arrays
 struct RankParams {
     uint32_t n_states;             // 2 * n_pieces
     const uint32_t* link; const uint32_t* piece_n;
-    uint32_t* nxt_a; uint32_t* nxt_b;      // ping-pong successor
-    uint32_t* acc_a; uint32_t* acc_b;      // k-mers from this state to its current nxt (exclusive of nxt's own)
-    uint32_t* tail_a; uint32_t* tail_b;
-    uint32_t* minp_a; uint32_t* minp_b;    // smallest piece id seen along the jumps (cycle leader election)
+    uint4* st_a; uint4* st_b;      // ping-pong: x = successor state, y = k-mers from this state up to (excluding) x,
+                                   //            z = last state reached, w = smallest piece id seen (cycle leader election)
     uint32_t* changed;
 };
 __global__ void k_rank_init(RankParams P) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.n_states) return;
-    P.nxt_a[e] = P.link[e ^ 1u];
-    P.acc_a[e] = P.piece_n[e >> 1];
-    P.tail_a[e] = e;
-    P.minp_a[e] = e >> 1;
+    uint4 v; v.x = P.link[e ^ 1u]; v.y = P.piece_n[e >> 1]; v.z = e; v.w = e >> 1;
+    P.st_a[e] = v;
 }
-// one doubling round: (nxt, acc, tail, minp) a -> b
+// one doubling round a -> b
 __global__ void k_rank_jump(RankParams P) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.n_states) return;
-    const uint32_t nx = P.nxt_a[e];
-    uint32_t acc = P.acc_a[e], tl = P.tail_a[e], mp = P.minp_a[e], nn = nx;
-    if (nx != NONE32) {
-        acc += P.acc_a[nx]; tl = P.tail_a[nx]; nn = P.nxt_a[nx];
-        const uint32_t m2 = P.minp_a[nx]; mp = m2 < mp ? m2 : mp;
+    uint4 v = P.st_a[e];
+    if (v.x != NONE32) {
+        const uint4 t = P.st_a[v.x];
+        v.y += t.y; v.z = t.z; v.x = t.x; v.w = t.w < v.w ? t.w : v.w;
         *P.changed = 1u;
     }
-    P.nxt_b[e] = nn; P.acc_b[e] = acc; P.tail_b[e] = tl; P.minp_b[e] = mp;
+    P.st_b[e] = v;
 }
 // states still unresolved after ceil(log2(n_states))+1 rounds lie on closed chains:
 // cut the chain at the left end of its smallest piece
-struct CutParams { uint32_t n_states; const uint32_t* nxt; const uint32_t* minp; uint32_t* link; uint32_t* n_cycles; };
+struct CutParams { uint32_t n_states; const uint4* st; uint32_t* link; uint32_t* n_cycles; };
 __global__ void k_cut_cycles(CutParams P) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.n_states) return;
-    if (P.nxt[e] == NONE32) return;
-    if ((e & 1u) || P.minp[e] != (e >> 1)) return;        // only the leader piece's left-end state acts
+    const uint4 v = P.st[e];
+    if (v.x == NONE32) return;
+    if ((e & 1u) || v.w != (e >> 1)) return;              // only the leader piece's left-end state acts
     const uint32_t partner = P.link[e];
     P.link[e] = NONE32;
     if (partner != NONE32) P.link[partner] = NONE32;
@@ -94,7 +92,7 @@ __global__ void k_cut_cycles(CutParams P) {
 // ---- (3) unitig heads: allocate id and output space ----
 struct HeadParams {
     uint32_t n_states; int k;
-    const uint32_t* link; const uint32_t* acc; const uint32_t* tail;
+    const uint32_t* link; const uint4* st;               // st[e].y = k-mers to the tail, st[e].z = tail state
     uint32_t* head_uid;            // per state (valid for head states)
     uint64_t* unitig_off; uint32_t* unitig_len; uint64_t* unitig_kc;
     uint64_t unitig_cap, out_cap;
@@ -107,10 +105,10 @@ __global__ void k_unitig_heads(HeadParams P) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     // head of the chosen direction: no predecessor, and the larger tail of the two directions
     // (piece ids inside unused reservation gaps have piece_n == 0 => acc == 0: not a unitig)
-    const bool head = e < P.n_states && P.link[e] == NONE32 && P.tail[e] > P.tail[e ^ 1u] && P.acc[e] != 0;
+    const bool head = e < P.n_states && P.link[e] == NONE32 && P.st[e].z > P.st[e ^ 1u].z && P.st[e].y != 0;
     uint32_t len = 0, my_i = 0; uint64_t my_o = 0;
     if (head) {
-        len = P.acc[e] + (uint32_t)P.k - 1u;
+        len = P.st[e].y + (uint32_t)P.k - 1u;
         my_i = atomic_add_u32(&s_n, 1u);                   // LDS: position inside this workgroup's batch
         my_o = atomic_add_u64(&s_len, (uint64_t)len);
     }
@@ -130,7 +128,7 @@ __global__ void k_unitig_heads(HeadParams P) {
 // ---- (4) emit: one lane per piece ----
 struct EmitParams {
     uint32_t n_pieces; int k;
-    const uint32_t* acc; const uint32_t* tail; const uint32_t* head_uid;
+    const uint4* st; const uint32_t* head_uid;
     const uint32_t* piece_n; const uint64_t* piece_kc; const uint64_t* piece_boff; const uint8_t* piece_bases;
     const uint64_t* unitig_off; uint64_t* unitig_kc; uint8_t* out;
 };
@@ -140,13 +138,14 @@ __global__ void k_emit(EmitParams P) {
     if (p >= P.n_pieces) return;
     const uint32_t e0 = 2 * p, e1 = 2 * p + 1;
     // direction d visits this piece in state e; its reverse visits it in e^1; chosen: larger tail
-    const uint32_t e = (P.tail[e0] > P.tail[e1]) ? e0 : e1;
-    const uint32_t head = P.tail[e ^ 1u] ^ 1u;             // head of d = mirror of the tail of the reverse direction
+    const uint4 s0 = P.st[e0], s1 = P.st[e1];
+    const uint32_t e = (s0.z > s1.z) ? e0 : e1;
+    const uint32_t head = ((s0.z > s1.z) ? s1.z : s0.z) ^ 1u;             // head of d = mirror of the tail of the reverse direction
     const uint32_t n = P.piece_n[p];
     if (n == 0) return;                                    // reservation gap
     const uint32_t uid = P.head_uid[head];
     if (uid == NONE32) return;
-    const uint32_t koff = P.acc[head] - P.acc[e];          // k-mers before this piece
+    const uint32_t koff = P.st[head].y - ((s0.z > s1.z) ? s0.y : s1.y);   // k-mers before this piece
     const uint32_t nb = n + (uint32_t)P.k - 1u;
     const uint8_t* src = P.piece_bases + P.piece_boff[p];
     uint8_t* dst = P.out + P.unitig_off[uid] + koff;
