@@ -442,7 +442,7 @@ int compact_impl(cdbg_ctx* c) {
                 offs[i + 1] = offs[i] + pow2_at_least(2 * (uint64_t)e + 16);
             }
             CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_state.alloc(offs[nbig], false)); CK(g_cnt.alloc(offs[nbig], false));
-            CK(g_lnk.alloc(2 * offs[nbig], false)); CK(g_aux.alloc(2 * offs[nbig], false));
+            CK(g_lnk.alloc(2 * offs[nbig], false)); CK(g_aux.alloc(3 * offs[nbig], false));
             CK(big_off.alloc(nbig + 1, false));
             HIPCK(hipMemcpy(big_off.p, offs.data(), (nbig + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
             HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));

@@ -28,11 +28,11 @@
 namespace cdbg {
 
 constexpr int COMPACT_THREADS = 256;
-constexpr uint32_t PIECE_CHUNK = 4096, BASES_CHUNK = 1u << 18;   // per-workgroup reservations (one device atomic each)
+constexpr uint32_t PIECE_CHUNK = 1024, BASES_CHUNK = 1u << 16;   // per-workgroup reservations (one device atomic each)
 constexpr uint32_t LNK_DEAD = 0, LNK_INTERNAL = 1, LNK_OPEN = 2;
 constexpr uint32_t LNK_CONF = 1u << 30;                 // this end's junction is 1-1 with a traveller: post CONFIRM
 constexpr uint32_t LNK_POSTED = 1u << 31;               // open piece end; low 31 bits = piece-end id
-constexpr uint32_t GLOG_CHUNK = 8192;                   // glue-log records a workgroup reserves per device atomic
+constexpr uint32_t GLOG_CHUNK = 2048;                   // glue-log records a workgroup reserves per device atomic
 constexpr uint32_t GTAG_EMPTY = 0xFFFFFFFFu, GTAG_CONFIRM = 0xFFFFFFFEu;
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr uint32_t END_LEFT = 0, END_RIGHT = 1;
@@ -108,7 +108,8 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
     CDBG_SHARED uint32_t l_state[(GLOBAL || W == 1) ? 1 : TS];
     CDBG_SHARED uint32_t l_cnt[GLOBAL ? 1 : TS];
     CDBG_SHARED uint32_t l_lnk[GLOBAL ? 1 : 2 * TS];
-    CDBG_SHARED uint32_t l_aux[GLOBAL ? 1 : 2 * TS];   // [0,cap): visited flags; [cap, 1.5cap): piece starts; [1.5cap, 2cap): entry slots
+    // aux words: [0, cap/4) visited bytes | piece starts | entry slots | piece lengths | piece base offsets (cap/2 each)
+    CDBG_SHARED uint32_t l_aux[GLOBAL ? 1 : 2 * TS + TS / 4];
     CDBG_SHARED uint32_t s_np, s_nb, s_stat[4];
     CDBG_SHARED uint64_t s_pbase, s_bbase, s_lbase;
     CDBG_SHARED uint32_t s_nopen, s_lw;
@@ -120,20 +121,20 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
     CDBG_PH(0);
     if (E == 0) return;
 
-    KTable<W> T; uint32_t *cnt, *lnk, *vis, *pdesc, *slots; uint32_t cap;
+    KTable<W> T; uint32_t *cnt, *lnk, *pdesc, *slots, *pn, *pb; uint8_t* vis; uint32_t cap;
     if (GLOBAL) {
         const uint64_t o0 = P.big_off[item]; cap = (uint32_t)(P.big_off[item + 1] - o0);
         T.keys = P.g_keys + o0 * W; T.state = P.g_state + o0; cnt = P.g_cnt + o0;
-        lnk = P.g_lnk + 2 * o0; vis = P.g_aux + 2 * o0; pdesc = vis + cap;
+        lnk = P.g_lnk + 2 * o0; vis = reinterpret_cast<uint8_t*>(P.g_aux + 3 * o0); pdesc = P.g_aux + 3 * o0 + cap / 4;
     } else {
         if (E > (uint32_t)TS / 2) {                      // does not fit LDS: defer to the big pass
             if (tid == 0) { const uint32_t i = atomic_add_u32(P.big_count, 1u); P.big_list[i] = p; }
             return;
         }
-        cap = TS; T.keys = l_keys; T.state = l_state; cnt = l_cnt; lnk = l_lnk; vis = l_aux; pdesc = l_aux + TS;
+        cap = TS; T.keys = l_keys; T.state = l_state; cnt = l_cnt; lnk = l_lnk; vis = reinterpret_cast<uint8_t*>(l_aux); pdesc = l_aux + TS / 4;
     }
     T.mask = cap - 1;
-    slots = pdesc + cap / 2;                             // E <= cap/2 entries, <= cap/2 pieces
+    slots = pdesc + cap / 2; pn = slots + cap / 2; pb = pn + cap / 2;   // E <= cap/2 entries, <= cap/2 pieces
     const uint32_t pg = (p << P.rank_bits) | (uint32_t)P.rank;     // global partition id of this bucket
 
     if (tid == 0) { s_np = 0; s_nb = 0; s_nopen = 0; s_lw = 0; s_stat[0] = s_stat[1] = s_stat[2] = s_stat[3] = 0; }
@@ -147,7 +148,9 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         Kmer<W> x;
         for (int i = 0; i < W; ++i) x.w[i] = P.solid_keys[(so + e) * W + i];
         bool nw; const uint32_t s = ktable_insert<W, GLOBAL>(T, x, nw);
-        cnt[s] = P.solid_cnt[so + e];
+        const uint32_t cv = P.solid_cnt[so + e];
+        cnt[s] = cv;
+        if (cv & TRAV_FLAG) vis[s] = 2;                  // bit 1: traveller (cnt[] is recycled for byte offsets later)
         slots[e] = s;
     }
     block_sync<GLOBAL>();
@@ -200,6 +203,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         if (idx <= other) {
             const uint32_t li = atomic_add_u32(&s_np, 1u);
             pdesc[li] = idx;                             // start terminal (bit 31 clear: linear piece)
+            pn[li] = n;
             atomic_add_u32(&s_nb, n + (uint32_t)k - 1u);
             const uint32_t no = ((lnk[idx] & 3u) == LNK_OPEN ? 1u : 0u) + ((lnk[other] & 3u) == LNK_OPEN ? 1u : 0u);
             if (no) atomic_add_u32(&s_nopen, no);
@@ -220,6 +224,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         if (is_min) {
             const uint32_t li = atomic_add_u32(&s_np, 1u);
             pdesc[li] = (s * 2 + END_LEFT) | 0x80000000u;   // cyclic piece starting at s, walking right
+            pn[li] = n;
             atomic_add_u32(&s_nb, n + (uint32_t)k - 1u);
             atomic_add_u32(&s_stat[2], 1u);
         }
@@ -260,35 +265,25 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         }
     }
     block_sync<GLOBAL>();
-    // ---- walk 2: one lane per piece writes bases, size, abundance and marks its open ends ----
+    // ---- walk 2: one lane per piece walks its chain ONCE more, only to hand every k-mer its byte
+    // offset + strand (stored over the k-mer's count, which is summed here) and to mark open ends;
+    // the bases themselves are written by the dense phases below, one lane per k-mer ----
     for (uint32_t li = tid; li < np; li += COMPACT_THREADS) {
         const uint32_t d = pdesc[li];
         const bool cyclic = d & 0x80000000u;
         const uint32_t start = d & 0x7FFFFFFFu;
-        const uint32_t s0 = start >> 1, e0 = start & 1u;
-        // first pass over the chain for the length (needed to place the bases)
-        uint32_t cur = s0, ex = e0 ^ 1u, n = 1;
-        for (;;) {
-            const uint32_t l = lnk[cur * 2 + ex];
-            if ((l & 3u) != LNK_INTERNAL) break;
-            const uint32_t nx = l >> 3;
-            if (cyclic && nx == s0) break;
-            cur = nx; ex = ((l >> 2) & 1u) ^ 1u; ++n;
-        }
-        const uint32_t nbases = n + (uint32_t)k - 1u;
-        const uint64_t boff = s_bbase + atomic_add_u32(&s_nb, nbases);
-        uint8_t* out = P.piece_bases + boff;
-        uint64_t kc = 0; uint32_t w = 0;
-        cur = s0; ex = e0 ^ 1u;
+        const uint32_t s0 = start >> 1, e0 = start & 1u, n = pn[li];
+        const uint32_t rel = atomic_add_u32(&s_nb, n + (uint32_t)k - 1u);
+        pb[li] = rel;
+        uint64_t kc = 0;
+        uint32_t cur = s0, ex = e0 ^ 1u;
         for (uint32_t t = 0; t < n; ++t) {
-            const Kmer<W> u = orient_out<W>(ktable_key<W>(T, cur), ex, k);
-            if (t == 0) { for (int i = 0; i < k; ++i) out[w++] = (uint8_t)("ACGT"[u.base(k, i)]); }
-            else out[w++] = (uint8_t)("ACGT"[u.base(k, k - 1)]);
             kc += (uint64_t)(cnt[cur] & ~TRAV_FLAG);
+            cnt[cur] = ((rel + (uint32_t)k - 1u + t) << 1) | (ex == END_RIGHT ? 0u : 1u);
             if (t + 1 < n) { const uint32_t l = lnk[cur * 2 + ex]; cur = l >> 3; ex = ((l >> 2) & 1u) ^ 1u; }
         }
         const uint64_t pid = s_pbase + li;
-        P.piece_n[pid] = n; P.piece_kc[pid] = kc; P.piece_boff[pid] = boff;
+        P.piece_n[pid] = n; P.piece_kc[pid] = kc; P.piece_boff[pid] = s_bbase + rel;
         if (!cyclic) {
             // left end of the piece = start terminal (s0, e0); right end = (cur, ex)
             const uint32_t il = s0 * 2 + e0, ir = cur * 2 + ex;
@@ -298,6 +293,29 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         }
     }
     block_sync<GLOBAL>();
+    if (np) {
+        uint8_t* const out = P.piece_bases + s_bbase;
+        // last base of every home k-mer (one lane per k-mer; no reverse complement needed:
+        // the last base of rc(x) is the complement of the first base of x)
+        for (uint32_t it = tid; it < E; it += COMPACT_THREADS) {
+            const uint32_t s = slots[it];
+            if (vis[s] & 2u) continue;                           // traveller copy: belongs to another bucket's piece
+            const uint32_t v = cnt[s];
+            const Kmer<W> x = ktable_key<W>(T, s);
+            const uint32_t b = (v & 1u) ? 3u - x.base(k, 0) : x.base(k, k - 1);
+            out[v >> 1] = (uint8_t)("ACGT"[b]);
+        }
+        // the first k-1 bases of every piece (one lane per base)
+        const uint32_t k1 = (uint32_t)k - 1u;
+        for (uint32_t xx = tid; xx < np * k1; xx += COMPACT_THREADS) {
+            const uint32_t li = xx / k1, i = xx - li * k1;
+            const uint32_t start = pdesc[li] & 0x7FFFFFFFu;
+            const Kmer<W> x = ktable_key<W>(T, start >> 1);
+            const bool fwd = ((start & 1u) ^ 1u) == END_RIGHT;   // leaving through the right end: label as is
+            const uint32_t b = fwd ? x.base(k, (int)i) : 3u - x.base(k, k - 1 - (int)i);
+            out[pb[li] + i] = (uint8_t)("ACGT"[b]);
+        }
+    }
     // ---- glue log, part 2: one record per open piece end (dense over all ends) ----
     if (np) {
         uint32_t my_open = 0;

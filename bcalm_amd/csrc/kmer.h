@@ -106,17 +106,28 @@ struct Kmer {
         w[0] = (w[0] << 2) | (uint64_t)c;
         mask(k);
     }
+    // word `idx` without dynamic indexing of the register array (a runtime index sends w[] to scratch)
+    CDBG_HD uint64_t word(int idx) const {
+        uint64_t r = w[0];
+#pragma unroll
+        for (int j = 1; j < W; ++j) r = (idx == j) ? w[j] : r;
+        return r;
+    }
+    CDBG_HD void or_word(int idx, uint64_t v) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) w[j] |= (idx == j) ? v : 0ULL;
+    }
     // prepend base c on the left (drop the rightmost base)
     CDBG_HD void push_left(int k, uint32_t c) {
         for (int i = 0; i < W - 1; ++i) w[i] = (w[i] >> 2) | (w[i + 1] << 62);
         w[W - 1] >>= 2;
         const int pos = 2 * (k - 1);
-        w[pos >> 6] |= (uint64_t)c << (pos & 63);
+        or_word(pos >> 6, (uint64_t)c << (pos & 63));
     }
     // i-th base counted from the left end of a k-mer
     CDBG_HD uint32_t base(int k, int i) const {
         const int pos = 2 * (k - 1 - i);
-        return (uint32_t)(w[pos >> 6] >> (pos & 63)) & 3u;
+        return (uint32_t)(word(pos >> 6) >> (pos & 63)) & 3u;
     }
     // reverse complement of a k-mer
     CDBG_HD Kmer rc(int k) const {
@@ -148,8 +159,8 @@ CDBG_HD Kmer<W> prefix_km1(const Kmer<W>& x, int /*k*/) { return x.shr(2); }
 template <int W>
 CDBG_HD uint32_t mmer_at(const Kmer<W>& x, int len, int i, int m) {
     const int pos = 2 * (len - m - i);
-    uint64_t v = x.w[pos >> 6] >> (pos & 63);
-    if ((pos & 63) + 2 * m > 64 && (pos >> 6) + 1 < W) v |= x.w[(pos >> 6) + 1] << (64 - (pos & 63));
+    uint64_t v = x.word(pos >> 6) >> (pos & 63);
+    if ((pos & 63) + 2 * m > 64 && (pos >> 6) + 1 < W) v |= x.word((pos >> 6) + 1) << (64 - (pos & 63));
     return (uint32_t)(v & ((m == 16) ? 0xFFFFFFFFULL : ((1ULL << (2 * m)) - 1)));
 }
 // ordering key of an m-mer: bijective hash of its canonical form
