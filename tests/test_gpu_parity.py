@@ -154,3 +154,35 @@ def test_capped_single_pass_scan_gpu(oracle, hip, part_cap, monkeypatch):
         monkeypatch.setenv("CDBG_PART_CAP", part_cap)
     text = oracle.synth_reads(40000, 150, 3)
     assert_parity(oracle, hip, text, 31, 2, log2_partitions=10)
+
+
+def test_config2_genome_shape(oracle, hip):
+    """BASELINE config 2 shape: one 4.64 Mbp sequence (E. coli MG1655 length; the FASTA itself is not
+    available offline, so a seeded synthetic genome with planted direct and inverted repeats stands in),
+    k=31, abundance-min 1: every k-mer distinct -> exercises the multi-pass LDS counting path;
+    bit-exact unitig set vs the oracle."""
+    import bcalm_amd
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    g0 = bytearray(oracle.synth_reads(1, 4_641_652, 2)[:-1])
+    for i in range(7):                                   # 7 x 5 kbp repeats, alternating strands
+        seg = bytes(g0[100_000 + 50_000 * i:105_000 + 50_000 * i])
+        if i & 1:
+            seg = seg.translate(comp)[::-1]
+        pos = 2_000_000 + 300_000 * i
+        g0[pos:pos + 5000] = seg
+    for i in range(20):                                  # 20 x 1.3 kbp repeats
+        seg = bytes(g0[3_000_000 + 7_000 * i:3_001_300 + 7_000 * i])
+        if i % 3 == 0:
+            seg = seg.translate(comp)[::-1]
+        pos = 500_000 + 60_000 * i
+        g0[pos:pos + 1300] = seg
+    text = bytes(g0) + b"\n"
+    exp = oracle.run(text, 31, 1)
+    g = bcalm_amd.Graph(31, 1, lib=hip)
+    g.push_text(text); g.run()
+    st = g.stats()
+    canon = oracle_lib.canonical_set(oracle, g.unitigs(), 31)
+    g.close()
+    assert st["n_distinct"] == exp["stats"]["distinct"] == st["n_solid"]
+    assert canon == exp["unitigs"]
+    assert exp["stats"]["unitigs"] > 50                  # the repeats really branch the graph
