@@ -82,7 +82,10 @@ template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMP
 template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, NTC = 512; };
 template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, NTC = 256; };
 
-constexpr uint64_t PERSISTENT_GRID = 256 * 12;     // persistent workgroups for the per-partition kernels (256 CUs)
+#ifndef CDBG_PGRID
+#define CDBG_PGRID (256 * 12)
+#endif
+constexpr uint64_t PERSISTENT_GRID = CDBG_PGRID;     // persistent workgroups for the per-partition kernels (256 CUs)
 constexpr uint64_t MAX_GRID = 1u << 22;          // workgroups per launch (grid * block must stay < 2^32)
 uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 
@@ -162,7 +165,11 @@ void configure(cdbg_ctx* c) {
     const int ts = W == 1 ? TS_COUNT_1 : W == 2 ? TS_COUNT_2 : TS_COUNT_4;
     // mean k-mer occurrences per partition: ~0.3 distinct per occurrence at sequencing depth fills the
     // LDS table to ~45 %; inputs with more distinct k-mers per occurrence take several LDS passes
-    const uint64_t target_occ = (uint64_t)ts * 3 / 2;
+#ifndef CDBG_OCC_NUM
+#define CDBG_OCC_NUM 3
+#define CDBG_OCC_DEN 2
+#endif
+    const uint64_t target_occ = (uint64_t)ts * CDBG_OCC_NUM / CDBG_OCC_DEN;
     int log_np = c->prm.log2_partitions;
     if (log_np < 0) {
         log_np = 0;

@@ -150,7 +150,10 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         bool nw; const uint32_t s = ktable_insert<W, GLOBAL>(T, x, nw);
         const uint32_t cv = P.solid_cnt[so + e];
         cnt[s] = cv;
-        if (cv & TRAV_FLAG) vis[s] = 2;                  // bit 1: traveller (cnt[] is recycled for byte offsets later)
+        // vis byte: bit 0 visited (walk 1), bit 1 traveller (cnt[] is recycled for byte offsets later),
+        // bit 2 / 3: the junction at the LEFT / RIGHT end of the label is owned by this bucket
+        uint32_t gl, gr; kmer_junction_mins<W>(x, k, P.m, gl, gr);
+        vis[s] = (uint8_t)(((cv & TRAV_FLAG) ? 2u : 0u) | (part_of(gl, P.log_np) == pg ? 4u : 0u) | (part_of(gr, P.log_np) == pg ? 8u : 0u));
         slots[e] = s;
     }
     block_sync<GLOBAL>();
@@ -162,9 +165,8 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         const bool home = !(cnt[s] & TRAV_FLAG);
         const Kmer<W> x = ktable_key<W>(T, s);
         const Kmer<W> u = orient_out<W>(x, end, k);
-        const Kmer<W> jc = canon_junction<W>(u, k);
         uint32_t link = LNK_DEAD; bool conf = false;
-        if (part_of(junction_min<W>(jc, k, P.m), P.log_np) != pg) {
+        if (!((vis[s] >> (2 + end)) & 1u)) {
             link = LNK_OPEN;                             // junction owned elsewhere: glue decides
         } else {
             uint32_t y = 0, ye = 0, z = 0, ze = 0;
@@ -192,12 +194,12 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         if (cnt[s] & TRAV_FLAG) continue;
         if ((lnk[idx] & 3u) == LNK_INTERNAL) continue;   // not a terminal
         uint32_t cur = s, ex = end ^ 1u, n = 1;
-        vis[cur] = 1;
+        vis[cur] = vis[cur] | 1u;
         for (;;) {
             const uint32_t l = lnk[cur * 2 + ex];
             if ((l & 3u) != LNK_INTERNAL) break;
             cur = l >> 3; ex = ((l >> 2) & 1u) ^ 1u; ++n;
-            vis[cur] = 1;
+            vis[cur] = vis[cur] | 1u;
         }
         const uint32_t other = cur * 2 + ex;
         if (idx <= other) {
@@ -214,7 +216,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
     // ---- closed chains entirely inside the bucket (isolated cycles): cut at the smallest slot ----
     for (uint32_t it = tid; it < E; it += COMPACT_THREADS) {
         const uint32_t s = slots[it];
-        if ((cnt[s] & TRAV_FLAG) || vis[s]) continue;
+        if (vis[s] & 3u) continue;                       // traveller, or already part of a piece
         uint32_t cur = s, ex = END_RIGHT, n = 0; bool is_min = true;
         do {
             const uint32_t l = lnk[cur * 2 + ex];

@@ -178,6 +178,25 @@ CDBG_HD uint32_t junction_min(const Kmer<W>& j, int k, int m) {
     }
     return g;
 }
+// minimizer keys of BOTH junctions of k-mer x (left = prefix (k-1)-mer, right = suffix (k-1)-mer) in one
+// rolling pass over its k-m+1 m-mers (canonical m-mers: the strand of x does not matter)
+template <int W>
+CDBG_HD void kmer_junction_mins(const Kmer<W>& x, int k, int m, uint32_t& g_left, uint32_t& g_right) {
+    const uint32_t mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+    uint32_t fw = 0, rc = 0, gl = 0xFFFFFFFFu, gr = 0xFFFFFFFFu;
+    for (int i = 0; i < k; ++i) {
+        const uint32_t b = x.base(k, i);
+        fw = ((fw << 2) | b) & mmask;
+        rc = (rc >> 2) | ((3u - b) << (2 * (m - 1)));
+        const int j = i - (m - 1);                       // m-mer start completed by base i
+        if (j >= 0) {
+            const uint32_t key = mix32(rc < fw ? rc : fw);
+            if (j <= k - 1 - m) gl = key < gl ? key : gl;
+            if (j >= 1) gr = key < gr ? key : gr;
+        }
+    }
+    g_left = gl; g_right = gr;
+}
 // partition of a minimizer key; log_np == 0 -> single partition
 CDBG_HD uint32_t part_of(uint32_t g, int log_np) {
     return log_np ? (uint32_t)((g * 0x9E3779B1u) >> (32 - log_np)) : 0u;

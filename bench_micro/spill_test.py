@@ -1,7 +1,7 @@
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bcalm_amd
-lib = bcalm_amd.load()
+lib = bcalm_amd.load(os.environ.get("CDBG_LIB"))
 n = int(sys.argv[1]); m = int(sys.argv[2])
 g = bcalm_amd.Graph(31, 2, lib=lib, minimizer_size=m)
 g.generate_reads(n, 150, 3)
