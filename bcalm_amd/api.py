@@ -42,7 +42,7 @@ class Stats(C.Structure):
 EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
            "cdbg_generate_reads", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
            "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats",
-           "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end"]
+           "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end"]
 
 
 def load(path: str | None = None) -> C.CDLL:
@@ -67,6 +67,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_num_unitigs.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     lib.cdbg_fetch_unitigs.argtypes = [vp, u64, u64, C.c_char_p, C.POINTER(u64), C.POINTER(u64)]
     lib.cdbg_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.cdbg_fetch_unitig_abundances.argtypes = [vp, u64, u64, C.POINTER(C.c_uint32), C.POINTER(u64)]
     lib.cdbg_link.argtypes = [vp]
     lib.cdbg_num_links.argtypes = [vp, C.POINTER(u64)]
     lib.cdbg_fetch_links.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_uint32)]
@@ -85,10 +86,11 @@ class Graph:
     count() -> compact() -> glue() (or run())."""
 
     def __init__(self, k: int, abundance_min: int = 2, minimizer_size: int = 0, log2_partitions: int = -1,
-                 device_id: int = 0, world_size: int = 1, rank: int = 0, lib: C.CDLL | None = None):
+                 device_id: int = 0, world_size: int = 1, rank: int = 0, lib: C.CDLL | None = None,
+                 all_abundance_counts: bool = False):
         self.lib = lib or load()
         self.k = k
-        p = Params(k, abundance_min, minimizer_size, log2_partitions, device_id, world_size, rank, 0)
+        p = Params(k, abundance_min, minimizer_size, log2_partitions, device_id, world_size, rank, 1 if all_abundance_counts else 0)
         self._h = C.c_void_p()
         self._ck(self.lib.cdbg_create(C.byref(p), C.byref(self._h)))
 
@@ -152,6 +154,18 @@ class Graph:
 
     def reset(self):
         self._ck(self.lib.cdbg_reset(self._h))
+
+    def unitig_abundances(self):
+        """-> per unitig (same order as unitigs()) the list of its k-mers' abundances (ab:Z: vector)"""
+        n, tb = C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.cdbg_num_unitigs(self._h, C.byref(n), C.byref(tb)))
+        n, tb = n.value, tb.value
+        if n == 0:
+            return []
+        ab = (C.c_uint32 * max(tb, 1))()
+        off = (C.c_uint64 * (n + 1))()
+        self._ck(self.lib.cdbg_fetch_unitig_abundances(self._h, 0, n, ab, off))
+        return [list(ab[off[i]:off[i + 1]]) for i in range(n)]
 
     def links(self):
         """-> per unitig (same order as unitigs()) a list of (from_sign, target_unitig, to_sign)"""

@@ -119,6 +119,7 @@ struct cdbg_ctx {
 
     DBuf<uint64_t> unitig_off; DBuf<uint32_t> unitig_len; DBuf<uint64_t> unitig_kc; DBuf<uint8_t> unitig_bases;
     uint64_t n_unitigs = 0, unitig_total = 0;
+    DBuf<uint32_t> piece_ab, unitig_ab;          // -all-abundance-counts
     DBuf<uint64_t> link_off; DBuf<uint32_t> link_to; uint64_t n_links = 0; bool linked = false;
 };
 
@@ -209,7 +210,7 @@ int count_impl(cdbg_ctx* c) {
     sp.part_count = c->part_count.p; sp.part_cursor = c->part_cursor.p; sp.records = nullptr; sp.stats = c->dstats.p;
     sp.tile_stride = 1; sp.tile_offset = 0; sp.error = c->derr.p;
     // instruction-lean scan when the window fits registers; generic LDS-doubling scan otherwise
-    const bool fast_scan = c->k <= 48 && (c->k - c->m) <= SCANF_WNMAX;
+    const bool fast_scan = c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX;
     const uint64_t tiles = fast_scan ? (c->nbytes + SCANF_TILE - 1) / SCANF_TILE : (c->nbytes + SCAN_TILE - 1) / SCAN_TILE;
     c->st.n_launch_scan = tiles;
 #define LAUNCH_SCAN(MODE, GRID)                                                                  \
@@ -413,6 +414,7 @@ int compact_impl(cdbg_ctx* c) {
         CK(c->piece_n.alloc(pcap, false)); HIPCK(hipMemsetAsync(c->piece_n.p, 0, pcap * sizeof(uint32_t), s));
         CK(c->piece_kc.alloc(pcap, false)); CK(c->piece_boff.alloc(pcap, false));
         CK(c->piece_bases.alloc(bcap, false));
+        if (c->prm.all_abundance_counts) CK(c->piece_ab.alloc(bcap, false));
         HIPCK(hipMemsetAsync(c->cursors.p, 0, 8 * sizeof(uint64_t), s));
         HIPCK(hipMemsetAsync(c->glog_tag.p, 0xFF, c->glog_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), s));
@@ -428,6 +430,7 @@ int compact_impl(cdbg_ctx* c) {
         kp.solid_keys = c->solid_keys.p; kp.solid_cnt = c->solid_cnt.p; kp.seg_off = c->seg_off.p; kp.seg_n = c->seg_n.p;
         kp.part_list = nullptr; kp.k = c->k; kp.m = c->m; kp.log_np = c->log_np; kp.rank_bits = c->rank_bits; kp.rank = c->prm.rank;
         kp.piece_n = c->piece_n.p; kp.piece_kc = c->piece_kc.p; kp.piece_boff = c->piece_boff.p; kp.piece_bases = c->piece_bases.p;
+        kp.piece_ab = c->prm.all_abundance_counts ? c->piece_ab.p : nullptr;
         kp.piece_cap = pcap; kp.bases_cap = bcap; kp.piece_cursor = c->cursors.p; kp.bases_cursor = c->cursors.p + 1;
         kp.glue_keys = c->glue_keys.p; kp.glue_state = c->glue_state.p; kp.glue_a = c->glue_a.p; kp.glue_b = c->glue_b.p;
         kp.glue_conf = c->glue_conf.p; kp.glue_mask = c->glue_cap - 1;
@@ -439,7 +442,6 @@ int compact_impl(cdbg_ctx* c) {
         HIPCK(hipStreamSynchronize(s));
         uint32_t nbig = 0; CK(read_u32(c->big_count.p, &nbig));
         DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_state, g_cnt, g_lnk, g_aux;
-        if (nbig && getenv("CDBG_DEBUG_SKIP_BIG")) { fprintf(stderr, "debug: skipping %u big buckets\n", nbig); nbig = 0; }
         if (nbig) {                                          // buckets with more entries than fit LDS
             std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list.p, bl.data(), nbig));
             std::sort(bl.begin(), bl.end());
@@ -538,6 +540,7 @@ int glue_impl(cdbg_ctx* c) {
     const uint64_t ocap = std::max<uint64_t>(c->n_piece_bases, 1);
     CK(c->unitig_off.alloc(ucap, false)); CK(c->unitig_len.alloc(ucap, false)); CK(c->unitig_kc.alloc(ucap, false));
     CK(c->unitig_bases.alloc(ocap, false));
+    if (c->prm.all_abundance_counts) CK(c->unitig_ab.alloc(ocap, false));
     HIPCK(hipMemsetAsync(c->cursors.p + 2, 0, 2 * sizeof(uint64_t), s));
     if (NS) {
         HeadParams hp{};
@@ -549,6 +552,7 @@ int glue_impl(cdbg_ctx* c) {
         ep.n_pieces = (uint32_t)NP; ep.k = c->k; ep.st = fa_st; ep.head_uid = head_uid.p;
         ep.piece_n = c->piece_n.p; ep.piece_kc = c->piece_kc.p; ep.piece_boff = c->piece_boff.p; ep.piece_bases = c->piece_bases.p;
         ep.unitig_off = c->unitig_off.p; ep.unitig_kc = c->unitig_kc.p; ep.out = c->unitig_bases.p;
+        ep.piece_ab = c->prm.all_abundance_counts ? c->piece_ab.p : nullptr; ep.unitig_ab = c->unitig_ab.p;
         CDBG_LAUNCH(k_emit, (uint32_t)((NP + GLUE_THREADS - 1) / GLUE_THREADS), GLUE_THREADS, s, ep);
     }
     CK(t.stop(&c->st.ms_glue));
@@ -614,7 +618,6 @@ int cdbg_create(const cdbg_params* p, cdbg_ctx** out) {
     if (p->k < 3 || p->k > 127) return fail(CDBG_E_PARAM, "kmer-size %d out of range (3..127)", p->k);
     if ((p->k & 1) == 0) return fail(CDBG_E_PARAM, "kmer-size %d is even: only odd k is supported (a k-mer must differ from its reverse complement)", p->k);
     if (p->abundance_min < 1) return fail(CDBG_E_PARAM, "abundance-min must be >= 1");
-    if (p->all_abundance_counts) return fail(CDBG_E_PARAM, "-all-abundance-counts is not implemented yet");
     const int ws = p->world_size <= 0 ? 1 : p->world_size;
     if (ws & (ws - 1)) return fail(CDBG_E_PARAM, "world_size must be a power of two");
     if (p->rank < 0 || p->rank >= ws) return fail(CDBG_E_PARAM, "rank out of range");
@@ -767,6 +770,7 @@ int cdbg_fetch_unitigs(cdbg_ctx* c, uint64_t first, uint64_t n, char* seq_buf, u
 // of caller-provided device buffers) and merged in rank order, after which cdbg_glue runs on the union ----
 int cdbg_exchange_sizes(cdbg_ctx* c, uint64_t out[3]) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    if (c->prm.all_abundance_counts) return fail(CDBG_E_PARAM, "-all-abundance-counts is single-GPU only in this version");
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
     out[0] = c->n_pieces; out[1] = c->n_piece_bases; out[2] = c->n_glog;
     return CDBG_OK;
@@ -836,6 +840,26 @@ int cdbg_exchange_end(cdbg_ctx* c) {
     return CDBG_OK;
 }
 
+int cdbg_fetch_unitig_abundances(cdbg_ctx* c, uint64_t first, uint64_t n, uint32_t* ab, uint64_t* ab_off) {
+    if (!c || !ab || !ab_off) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_fetch_unitig_abundances before cdbg_glue");
+    if (!c->prm.all_abundance_counts) return fail(CDBG_E_STATE, "context was created without all_abundance_counts");
+    if (first + n > c->n_unitigs) return fail(CDBG_E_PARAM, "unitig range out of bounds");
+    if (!n) { ab_off[0] = 0; return CDBG_OK; }
+    std::vector<uint64_t> off(n); std::vector<uint32_t> len(n);
+    HIPCK(hipMemcpy(off.data(), c->unitig_off.p + first, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(len.data(), c->unitig_len.p + first, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> arena(c->unitig_total);
+    HIPCK(hipMemcpy(arena.data(), c->unitig_ab.p, c->unitig_total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        ab_off[i] = w;
+        const uint32_t nk = len[i] - (uint32_t)c->k + 1u;
+        memcpy(ab + w, arena.data() + off[i] + (c->k - 1), nk * sizeof(uint32_t)); w += nk;
+    }
+    ab_off[n] = w;
+    return CDBG_OK;
+}
 int cdbg_stats(cdbg_ctx* c, cdbg_stats_t* out) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
     *out = c->st; return CDBG_OK;

@@ -62,6 +62,7 @@ struct CompactParams {
     int k, m, log_np, rank_bits, rank;
     // pieces
     uint32_t* piece_n; uint64_t* piece_kc; uint64_t* piece_boff; uint8_t* piece_bases;
+    uint32_t* piece_ab;            // optional (-all-abundance-counts): abundance of the k-mer ending at each base offset
     uint64_t piece_cap, bases_cap;
     uint64_t* piece_cursor; uint64_t* bases_cursor;
     // glue table (HBM)
@@ -280,7 +281,9 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         uint64_t kc = 0;
         uint32_t cur = s0, ex = e0 ^ 1u;
         for (uint32_t t = 0; t < n; ++t) {
-            kc += (uint64_t)(cnt[cur] & ~TRAV_FLAG);
+            const uint32_t ab = cnt[cur] & ~TRAV_FLAG;
+            kc += (uint64_t)ab;
+            if (P.piece_ab) P.piece_ab[s_bbase + rel + (uint32_t)k - 1u + t] = ab;
             cnt[cur] = ((rel + (uint32_t)k - 1u + t) << 1) | (ex == END_RIGHT ? 0u : 1u);
             if (t + 1 < n) { const uint32_t l = lnk[cur * 2 + ex]; cur = l >> 3; ex = ((l >> 2) & 1u) ^ 1u; }
         }

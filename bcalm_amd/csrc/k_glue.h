@@ -131,6 +131,7 @@ struct EmitParams {
     const uint4* st; const uint32_t* head_uid;
     const uint32_t* piece_n; const uint64_t* piece_kc; const uint64_t* piece_boff; const uint8_t* piece_bases;
     const uint64_t* unitig_off; uint64_t* unitig_kc; uint8_t* out;
+    const uint32_t* piece_ab; uint32_t* unitig_ab;   // optional per-k-mer abundances, indexed like the bases (k-mer ending at that base)
 };
 CDBG_DEV uint8_t comp_ascii(uint8_t c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; }
 __global__ void k_emit(EmitParams P) {
@@ -152,6 +153,12 @@ __global__ void k_emit(EmitParams P) {
     const uint32_t skip = koff ? (uint32_t)P.k - 1u : 0u;  // the overlap was written by the previous piece
     if ((e & 1u) == END_LEFT) { for (uint32_t i = skip; i < nb; ++i) dst[i] = src[i]; }
     else { for (uint32_t i = skip; i < nb; ++i) dst[i] = comp_ascii(src[nb - 1 - i]); }
+    if (P.piece_ab) {                                      // -all-abundance-counts: k-mer t of the piece -> k-mer koff+t (or mirrored)
+        const uint32_t* sa = P.piece_ab + P.piece_boff[p] + (P.k - 1);
+        uint32_t* da = P.unitig_ab + P.unitig_off[uid] + koff + (P.k - 1);
+        if ((e & 1u) == END_LEFT) { for (uint32_t t = 0; t < n; ++t) da[t] = sa[t]; }
+        else { for (uint32_t t = 0; t < n; ++t) da[t] = sa[n - 1 - t]; }
+    }
     atomic_add_u64(&P.unitig_kc[uid], P.piece_kc[p]);
 }
 

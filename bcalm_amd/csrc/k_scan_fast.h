@@ -9,8 +9,8 @@
 //   D  validity / run-break bits from a 64-bit validity window, written as 16-bit words
 //   E  run starts are compacted into an LDS list (popcount prefix over the workgroup), then
 //      every lane handles ONE run: end search, boundary (home / traveller) rules, records.
-// Used when k-m <= SCANF_WNMAX and k <= 48 (all W=1 cases, k=55 with m >= 7); k_scan remains
-// the generic path.  Tile-local index q: byte (tile_start - 16 + q); junction jq <-> q = 15+jq.
+// Used when k-m <= SCANF_WNMAX and k <= 63 (all W=1 cases, W=2 with m >= k-48); k_scan remains
+// the generic path (k > 63, or a longer minimizer window).  Tile-local index q: byte (tile_start - 16 + q); junction jq <-> q = 15+jq.
 #pragma once
 #include "k_scan.h"
 
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
             const uint16_t* v16 = reinterpret_cast<const uint16_t*>(vm);
             const uint64_t lo = (uint64_t)v16[c - 1] | ((uint64_t)v16[c] << 16) | ((uint64_t)v16[c + 1] << 32) | ((uint64_t)v16[c + 2] << 48);
             const uint64_t hi = (uint64_t)v16[c + 3] | ((uint64_t)v16[c + 4] << 16);
-            const uint64_t jm = (1ULL << (k - 1)) - 1ULL;   // k-1 <= 47 bits
+            const uint64_t jm = (1ULL << (k - 1)) - 1ULL;   // k-1 <= 62 bits; wq/wp below hold 64 valid bits
             const uint32_t gprev = kg[scanf_pad(16 * c - 1)];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -159,7 +159,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
     // ---- E2. one lane per run ----
     const int NMAX = CAPB - k + 1;
     const uint32_t rank_mask = (1u << P.rank_bits) - 1u;
-    const uint64_t km = (1ULL << k) - 1ULL;                 // k <= 48
     uint32_t n_members = 0, n_trav = 0;
     const int nstart = (int)s_nstart;
     for (int i = tid; i < nstart; i += SCAN_THREADS) {
@@ -190,7 +189,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
             else if (part_of(g2, P.log_np) != part) { last_incl = true; last_trav = true; }
             else if (g0 == g2) last_incl = true;
         }
-        (void)km;
         int c = s; bool firstchunk = true;
         while (c <= e) {
             const int ms = (firstchunk && first_incl) ? c - 1 : c;

@@ -30,7 +30,7 @@ namespace {
 struct Options {
     std::string in, out;
     int k = 31, amin = 2, m = 0, device = 0, log_np = -1;
-    bool gfa = false, verbose = false;
+    bool gfa = false, verbose = false, all_ab = false;
 };
 
 [[noreturn]] void usage_error(const std::string& msg) { throw std::runtime_error(msg); }
@@ -51,6 +51,7 @@ Options parse(int argc, char** argv) {
         else if (a == "-device") o.device = atoi(need("-device"));
         else if (a == "-log2-partitions") o.log_np = atoi(need("-log2-partitions"));
         else if (a == "-gfa") o.gfa = true;
+        else if (a == "-all-abundance-counts") o.all_ab = true;        // README.md:74-80
         else if (a == "-verbose") { o.verbose = true; if (i + 1 < argc && argv[i + 1][0] != '-') ++i; }
         else if (a == "-nb-cores" || a == "-max-memory" || a == "-max-disk" || a == "-out-tmp" || a == "-out-dir" ||
                  a == "-repartition-type" || a == "-minimizer-type" || a == "-histo-max" || a == "-solidity-kind")
@@ -133,7 +134,7 @@ int main(int argc, char** argv) {
         auto t0 = std::chrono::steady_clock::now();
 
         cdbg_params p{}; p.k = o.k; p.abundance_min = o.amin; p.minimizer_size = o.m; p.log2_partitions = o.log_np;
-        p.device_id = o.device; p.world_size = 1; p.rank = 0;
+        p.device_id = o.device; p.world_size = 1; p.rank = 0; p.all_abundance_counts = o.all_ab ? 1 : 0;
         cdbg_ctx* ctx = nullptr;
         check(cdbg_create(&p, &ctx));
         uint64_t n_seq = 0, n_bases = 0;
@@ -150,6 +151,8 @@ int main(int argc, char** argv) {
         uint64_t nu = 0, tb = 0; check(cdbg_num_unitigs(ctx, &nu, &tb));
         std::vector<char> seq(tb + 1); std::vector<uint64_t> off(nu + 1), kc(nu ? nu : 1);
         check(cdbg_fetch_unitigs(ctx, 0, nu, seq.data(), off.data(), kc.data()));
+        std::vector<uint32_t> ab; std::vector<uint64_t> aboff;
+        if (o.all_ab) { ab.resize(tb + 1); aboff.resize(nu + 1); check(cdbg_fetch_unitig_abundances(ctx, 0, nu, ab.data(), aboff.data())); }
         // edges between unitigs (README.md:72 L: tokens; convertToGFA.py:103-112 GFA L lines)
         check(cdbg_link(ctx));
         uint64_t nl = 0; check(cdbg_num_links(ctx, &nl));
@@ -165,6 +168,10 @@ int main(int argc, char** argv) {
         for (uint64_t i = 0; i < nu; ++i) {
             const uint64_t len = off[i + 1] - off[i];
             const double km = (double)kc[i] / (double)(len - (uint64_t)o.k + 1);
+            if (o.all_ab) {                                  // ><id> LN:i:<length> ab:Z:<abundance_0> ... (README.md:76)
+                fprintf(out, ">%llu LN:i:%llu ab:Z:", (unsigned long long)i, (unsigned long long)len);
+                for (uint64_t j = aboff[i]; j < aboff[i + 1]; ++j) fprintf(out, j == aboff[i] ? "%u" : " %u", ab[j]);
+            } else
             fprintf(out, ">%llu LN:i:%llu KC:i:%llu km:f:%.1f", (unsigned long long)i, (unsigned long long)len, (unsigned long long)kc[i], km);
             if (gfa) { fprintf(gfa, "S\t%llu\t", (unsigned long long)i); fwrite(seq.data() + off[i], 1, len, gfa);
                        fprintf(gfa, "\tLN:i:%llu\tKC:i:%llu\tkm:f:%.1f\n", (unsigned long long)len, (unsigned long long)kc[i], km); }

@@ -37,7 +37,7 @@ typedef struct cdbg_params {
     int device_id;            /* HIP device ordinal */
     int world_size;           /* GPUs sharing the minimizer space (power of two); 1 = single GPU */
     int rank;                 /* this context owns partitions p with p % world_size == rank */
-    int all_abundance_counts; /* reserved for -all-abundance-counts (README.md:74-80); must be 0 */
+    int all_abundance_counts; /* -all-abundance-counts (README.md:74-80): keep the abundance of every k-mer of every unitig */
 } cdbg_params;
 
 typedef struct cdbg_stats_t {
@@ -120,6 +120,10 @@ int cdbg_fetch_solid(cdbg_ctx* ctx, char* kmers, uint32_t* counts, uint64_t capa
  * unspecified, as in the reference (README.md:84-87). */
 int cdbg_num_unitigs(cdbg_ctx* ctx, uint64_t* n, uint64_t* total_bases);
 int cdbg_fetch_unitigs(cdbg_ctx* ctx, uint64_t first, uint64_t n, char* seq_buf, uint64_t* seq_off, uint64_t* kc);
+/* per-k-mer abundances of unitigs [first, first+n) (contexts created with all_abundance_counts = 1):
+ * ab_off[n+1] offsets into ab; unitig i has LN-k+1 values in the orientation of its sequence
+ * (the `ab:Z:` vector of /root/reference/README.md:74-80) */
+int cdbg_fetch_unitig_abundances(cdbg_ctx* ctx, uint64_t first, uint64_t n, uint32_t* ab, uint64_t* ab_off);
 int cdbg_stats(cdbg_ctx* ctx, cdbg_stats_t* out);
 
 /* Edges between unitigs (the `L:<+/->:<id>:<+/->` tokens of /root/reference/README.md:62-72; GFA `L`
