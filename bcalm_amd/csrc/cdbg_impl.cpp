@@ -796,9 +796,12 @@ int cdbg_exchange_export(cdbg_ctx* c, int what, void* dst_dev, uint64_t nbytes) 
 int cdbg_exchange_begin(cdbg_ctx* c, uint64_t total_pieces, uint64_t total_bases, uint64_t total_glog) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_begin before cdbg_compact");
-    CK(c->mg_n.alloc(total_pieces, false)); CK(c->mg_kc.alloc(total_pieces, false)); CK(c->mg_boff.alloc(total_pieces, false));
-    CK(c->mg_bases.alloc(total_bases, false));
-    CK(c->mg_gkeys.alloc(total_glog * c->W, false)); CK(c->mg_gtag.alloc(total_glog, false));
+    // the merged arrays are swapped with the context's own in cdbg_exchange_end: give them at least the same
+    // capacity, so that a re-run after cdbg_reset finds arrays that are large enough and never reallocates
+    CK(c->mg_n.alloc(std::max<size_t>(total_pieces, c->piece_n.cap), false)); CK(c->mg_kc.alloc(std::max<size_t>(total_pieces, c->piece_kc.cap), false));
+    CK(c->mg_boff.alloc(std::max<size_t>(total_pieces, c->piece_boff.cap), false));
+    CK(c->mg_bases.alloc(std::max<size_t>(total_bases, c->piece_bases.cap), false));
+    CK(c->mg_gkeys.alloc(std::max<size_t>(total_glog * c->W, c->glog_keys.cap), false)); CK(c->mg_gtag.alloc(std::max<size_t>(total_glog, c->glog_tag.cap), false));
     c->mg_np = c->mg_nb = c->mg_nl = 0; c->mg_cap_p = total_pieces; c->mg_cap_b = total_bases; c->mg_cap_l = total_glog; c->mg_open = true;
     return CDBG_OK;
 }
@@ -826,9 +829,10 @@ int cdbg_exchange_end(cdbg_ctx* c) {
     c->piece_bases.swap(c->mg_bases); c->glog_keys.swap(c->mg_gkeys); c->glog_tag.swap(c->mg_gtag);
     c->n_pieces = c->mg_np; c->n_piece_bases = c->mg_nb; c->n_glog = c->mg_nl; c->glog_cap = c->mg_cap_l;
     c->mg_open = false;
-    // junction table for the union: at most one junction per glue record
+    // junction table for the union: at most one junction per glue record (typically 2-3 records per
+    // junction, so 1.25 x records keeps the load factor below one half in practice and below 0.8 always)
     const int W = c->W;
-    c->glue_cap = (uint32_t)pow2_at_least(2 * c->n_glog + 64);
+    c->glue_cap = (uint32_t)pow2_at_least(c->n_glog + c->n_glog / 4 + 64);
     CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false)); CK(c->glue_state.alloc(c->glue_cap, false));
     CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
     HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), c->stream));

@@ -31,6 +31,7 @@ struct Options {
     std::string in, out;
     int k = 31, amin = 2, m = 0, device = 0, log_np = -1;
     bool gfa = false, verbose = false, all_ab = false;
+    std::string solid_out;
 };
 
 [[noreturn]] void usage_error(const std::string& msg) { throw std::runtime_error(msg); }
@@ -52,6 +53,7 @@ Options parse(int argc, char** argv) {
         else if (a == "-log2-partitions") o.log_np = atoi(need("-log2-partitions"));
         else if (a == "-gfa") o.gfa = true;
         else if (a == "-all-abundance-counts") o.all_ab = true;        // README.md:74-80
+        else if (a == "-solid-kmers-out") o.solid_out = need("-solid-kmers-out");   // hidden in the reference (bcalm_1.cpp:37)
         else if (a == "-verbose") { o.verbose = true; if (i + 1 < argc && argv[i + 1][0] != '-') ++i; }
         else if (a == "-nb-cores" || a == "-max-memory" || a == "-max-disk" || a == "-out-tmp" || a == "-out-dir" ||
                  a == "-repartition-type" || a == "-minimizer-type" || a == "-histo-max" || a == "-solidity-kind")
@@ -145,6 +147,15 @@ int main(int argc, char** argv) {
         } else read_sequences(o.in, ctx, n_seq, n_bases);
         auto t1 = std::chrono::steady_clock::now();
         check(cdbg_count(ctx));
+        if (!o.solid_out.empty()) {                          // solid k-mer dump: "<canonical k-mer> <abundance>" per line
+            uint64_t ns = 0, got = 0; check(cdbg_num_solid(ctx, &ns));
+            std::vector<char> km((ns + 1) * (size_t)(o.k + 1)); std::vector<uint32_t> cnt(ns + 1);
+            check(cdbg_fetch_solid(ctx, km.data(), cnt.data(), ns, &got));
+            FILE* sf = fopen(o.solid_out.c_str(), "w");
+            if (!sf) usage_error("cannot write " + o.solid_out);
+            for (uint64_t i = 0; i < got; ++i) fprintf(sf, "%s %u\n", km.data() + i * (size_t)(o.k + 1), cnt[i]);
+            fclose(sf);
+        }
         check(cdbg_compact(ctx));
         check(cdbg_glue(ctx));
         cdbg_stats_t st; check(cdbg_stats(ctx, &st));

@@ -98,7 +98,15 @@ def main():
     ap.add_argument("--mode", choices=["sharded", "independent"], default="sharded",
                     help="N>1: sharded = ONE graph, minimizer partitions split over the ranks, glue records exchanged with an RCCL "
                          "all-gather (strong scaling); independent = one read set per rank, no collective (weak scaling)")
+    ap.add_argument("--force-dist", action="store_true", help="run the sharded (collective) code path even with one rank (testing)")
     a = ap.parse_args()
+
+    # the one JSON line must be the only thing on stdout: RCCL / HIP runtime banners written to fd 1 by native
+    # code go to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    json_out = os.fdopen(json_fd, "w")
 
     import torch
     import bcalm_amd
@@ -107,17 +115,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     lib = bcalm_amd.load()                      # raises without the HIP extension: no fallback
-    sharded = world > 1 and a.mode == "sharded"
+    sharded = (world > 1 or a.force_dist) and a.mode == "sharded"
     if sharded:
         # ONE graph over `--reads` reads: every rank holds the reads, owns the minimizer partitions
         # p with p % world == rank, counts and compacts them, then the glue records (pieces + junction
@@ -216,7 +225,7 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.k, a.abundance_min, a.read_len, a.cfg, a.cpu_sample_reads)
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n"); json_out.flush()
     g.close()
     if dist is not None:
         dist.barrier()

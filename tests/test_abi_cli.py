@@ -4,6 +4,7 @@ include/cdbg.h declares, fails loudly without a device (no CPU fallback), and th
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -106,6 +107,19 @@ def test_cli_contract(cli, oracle, tmp_path):
     fa_links = re.findall(r" L:([+-]):(\d+):([+-])", (tmp_path / "xyz.unitigs.fa").read_text())
     gfa_links = re.findall(r"^L\t\d+\t([+-])\t(\d+)\t([+-])\t20M$", gfa, flags=re.M)
     assert sorted(fa_links) == sorted(gfa_links)
+
+
+def test_cli_solid_kmers_out(cli, oracle, tmp_path):
+    """-solid-kmers-out (hidden option of the reference, bcalm_1.cpp:37): canonical k-mer + abundance per line"""
+    inp = os.path.join(ROOT, "tests", "golden", "inputs", "minitip.fa")
+    r = subprocess.run([cli, "-in", inp, "-kmer-size", "21", "-abundance-min", "2", "-solid-kmers-out", "solid.txt"],
+                       cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    got = sorted((a, int(b)) for a, b in (l.split() for l in (tmp_path / "solid.txt").read_text().splitlines()))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py
+    exp = oracle_py.solid_kmers(oracle_py.read_fasta_text(inp), 21, 2)
+    assert got == exp and len(got) == 20
 
 
 def test_cli_errors(cli, tmp_path):
