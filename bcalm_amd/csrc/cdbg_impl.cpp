@@ -86,6 +86,20 @@ template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMP
 #define CDBG_PGRID (256 * 12)
 #endif
 constexpr uint64_t PERSISTENT_GRID = CDBG_PGRID;     // persistent workgroups for the per-partition kernels (256 CUs)
+// workgroups of `kern` that are resident at once on the whole device: the grid of a persistent kernel whose
+// workgroups stride over equal work items must be exactly this (a partial extra generation would run alone)
+template <class K>
+uint64_t resident_grid(K kern, int threads, uint64_t fallback) {
+#ifndef CDBG_HOSTSIM
+    int occ = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, 0) == hipSuccess && occ > 0 && cus > 0)
+        return (uint64_t)occ * (uint64_t)cus;
+#else
+    (void)kern; (void)threads;
+#endif
+    return fallback;
+}
 constexpr uint64_t MAX_GRID = 1u << 22;          // workgroups per launch (grid * block must stay < 2^32)
 uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 
@@ -214,8 +228,10 @@ int count_impl(cdbg_ctx* c) {
     const uint64_t tiles = fast_scan ? (c->nbytes + SCANF_TILE - 1) / SCANF_TILE : (c->nbytes + SCAN_TILE - 1) / SCAN_TILE;
     c->st.n_launch_scan = tiles;
 #define LAUNCH_SCAN(MODE, GRID)                                                                  \
-    do { if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE>), (GRID), SCAN_THREADS, s, sp);          \
-         else CDBG_LAUNCH((k_scan<W, MODE>), (GRID), SCAN_THREADS, s, sp); } while (0)
+    do { sp.n_tiles = (GRID);                                                                    \
+         if (fast_scan && W == 1 && c->k - c->m == 15) CDBG_LAUNCH((k_scan_fast<W, MODE, W == 1 ? 15 : 0>), std::min<uint64_t>((GRID), resident_grid(k_scan_fast<W, MODE, W == 1 ? 15 : 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp); \
+         else if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE, 0>), std::min<uint64_t>((GRID), resident_grid(k_scan_fast<W, MODE, 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);  \
+         else CDBG_LAUNCH((k_scan<W, MODE>), std::min<uint64_t>((GRID), resident_grid(k_scan<W, MODE>, SCAN_THREADS, SCAN_GRID)), SCAN_THREADS, s, sp); } while (0)
     auto exscan = [&](const uint32_t* counts) -> int {       // counts -> part_off (exclusive), part_off[NPL] = total
         const uint64_t nb = (NPL + EXSCAN_BLOCK - 1) / EXSCAN_BLOCK;
         CK(c->exscan_tmp.alloc(nb + 1, false));

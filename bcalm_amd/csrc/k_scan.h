@@ -36,6 +36,7 @@ namespace cdbg {
 #define CDBG_SPH(i) do { } while (0)
 #endif
 constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_GRID = 256 * 2;                     // fallback grid of the persistent launch
 constexpr int SCAN_TILE = 4096;                       // junctions per workgroup
 constexpr int SCAN_PKW = (SCAN_TILE + 16 + 256) / 16 + 11;   // packed words (16 bases each) incl. halo/over-read; EVEN
 static_assert(SCAN_PKW % 2 == 0, "validity halves must fill whole 32-bit words");
@@ -56,6 +57,7 @@ struct ScanParams {
     uint64_t* part_cursor;       // EMIT pass: running cursors, pre-loaded with exclusive offsets
     uint64_t* records;           // EMIT pass: RW words per record
     uint64_t* stats;             // [0] member k-mers emitted (incl. travellers), [1] traveller members
+    uint64_t n_tiles;            // tiles of this launch (k_scan_fast: persistent workgroups stride over them)
     uint32_t tile_stride, tile_offset;   // tile = blockIdx.x * tile_stride + tile_offset (sampling for the capacity estimate)
     // SCAN_EMIT_CAPPED (single pass, no histogram): partition p owns records [p*part_cap, (p+1)*part_cap);
     // part_fill[p] counts the records offered; records beyond the capacity go to the spill list
@@ -125,11 +127,15 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
 
     const int tid = threadIdx.x;
     const int k = P.k, m = P.m;
-    const int64_t t0 = ((int64_t)blockIdx.x * P.tile_stride + P.tile_offset) * SCAN_TILE;
-    const int64_t base = t0 - 16;                     // byte offset of tile-local base index 0
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
     uint64_t sph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t st_prev = wall_clock64();
 #endif
+    uint64_t n_members = 0, n_trav = 0;
+    if (tid == 0) { s_members = 0; s_trav = 0; }
+    // persistent workgroups stride over the tiles (a workgroup launch per ~30 us tile costs more than the tile)
+    for (uint64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+    const int64_t t0 = ((int64_t)tile * P.tile_stride + P.tile_offset) * SCAN_TILE;
+    const int64_t base = t0 - 16;                     // byte offset of tile-local base index 0
 
     // ---- 1. load 16 bytes per lane-iteration, encode to 2 bit + validity ----
     for (int w = tid; w < SCAN_PKW; w += SCAN_THREADS) {
@@ -150,7 +156,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
         reinterpret_cast<uint16_t*>(vm)[w] = (uint16_t)vbits;
     }
     if (tid < 4) vm[SCAN_PKW / 2 + tid] = 0;           // over-read words of scan_all_valid
-    if (tid == 0) { s_members = 0; s_trav = 0; s_nrec = 0; }
+    if (tid == 0) s_nrec = 0;
     __syncthreads();
     CDBG_SPH(0);
 
@@ -216,7 +222,6 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     // ---- 5. one lane per run start: find the run end, apply the boundary rules, emit ----
     const int NMAX = CAPB - k + 1;                     // member k-mers per record
     const uint32_t rank_mask = (1u << P.rank_bits) - 1u;
-    uint64_t n_members = 0, n_trav = 0;
     for (int it = 0; it < SCAN_TILE / SCAN_THREADS; ++it) {
         const int jq = 1 + it * SCAN_THREADS + tid;
         const int bit = jq - 1;
@@ -285,7 +290,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
         for (uint32_t i = tid; i < nl; i += SCAN_THREADS)
             scan_emit_record<W, MODE>(P, pk, 2 * (15 + (int)(lst[2 * i] & 0xFFFFu)), lst[2 * i] >> 16, lst[2 * i + 1]);
     }
+    __syncthreads();                                    // the next tile reuses the LDS arrays
     CDBG_SPH(5);
+    }
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
     if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) atomic_add_u64(&P.stats[16 + i], sph[i]);
 #endif

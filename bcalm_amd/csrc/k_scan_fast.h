@@ -17,6 +17,7 @@
 namespace cdbg {
 
 constexpr int SCANF_TILE = 4064;                       // junctions per workgroup (254 x 16)
+constexpr int SCANF_GRID = 256 * 5;                       // fallback grid of the persistent launch (cdbg_impl.cpp asks the runtime)
 constexpr int SCANF_WNMAX = 48;                        // largest k-m handled by the register window
 constexpr int SCANF_NQ = 4400;                         // tile-local positions held in LDS
 constexpr int SCANF_PKW = SCANF_NQ / 16 + 5;           // packed words (16 bases each) incl. over-read
@@ -34,7 +35,7 @@ CDBG_DEV uint32_t scanf_enc4(uint32_t x, uint32_t& vbits) {
     return (t * 0x40100401u) >> 24;                                        // b0<<6 | b1<<4 | b2<<2 | b3
 }
 
-template <int W, int MODE>
+template <int W, int MODE, int WNT>
 __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
     constexpr int RW = RecFmt<W>::RW;
     constexpr int CAPB = RecFmt<W>::CAPB;
@@ -48,7 +49,14 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = P.k, m = P.m, WN = k - m;
-    const int64_t t0 = ((int64_t)blockIdx.x * P.tile_stride + P.tile_offset) * SCANF_TILE;
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+    uint64_t sph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t st_prev = wall_clock64();
+#endif
+    uint32_t n_members = 0, n_trav = 0;
+    if (tid == 0) { s_members = 0; s_trav = 0; }
+    // persistent workgroups: a tile lives ~30 us, far too short to pay a workgroup launch for each
+    for (uint64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+    const int64_t t0 = ((int64_t)tile * P.tile_stride + P.tile_offset) * SCANF_TILE;
     const int64_t base = t0 - 16;
 
     // ---- A. load + encode ----
@@ -66,43 +74,64 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
     }
     if (tid < 4) vm[SCANF_PKW / 2 + tid] = 0;
     if (SCANF_PKW & 1) { if (tid == 4) reinterpret_cast<uint16_t*>(vm)[SCANF_PKW] = 0; }
-    if (tid == 0) { s_nstart = 0; s_members = 0; s_trav = 0; }
+    if (tid == 0) s_nstart = 0;
     __syncthreads();
+    CDBG_SPH(0);
 
     // ---- B. rolling m-mer keys: lane chunk c covers m-mer starts [16c, 16c+16) ----
     const int nq_keys = 15 + SCANF_TILE + 2 + WN;          // keys needed for q < nq_keys
     const uint32_t mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
     for (int c = tid; 16 * c < nq_keys; c += SCAN_THREADS) {
+        // the 31 bases 16c .. 16c+30 as one 64-bit string X (first base on top) and its reverse complement
+        // RX: the m-mer starting at base s is a bit field of X, its reverse complement a bit field of RX
         const uint32_t w0 = pk[c], w1 = pk[c + 1];
         const uint32_t vv = (uint32_t)reinterpret_cast<const uint16_t*>(vm)[c] | ((uint32_t)reinterpret_cast<const uint16_t*>(vm)[c + 1] << 16);
-        uint32_t fw = 0, rc = 0; int run = 0;
+        uint32_t xv = vv;                                  // bit s <- bases s .. s+m-1 all valid (AND by doubling)
+        { int len = 1; while (2 * len <= m) { xv &= xv >> len; len *= 2; } xv &= xv >> (m - len); }
+        const uint64_t X = ((uint64_t)w0 << 32) | w1;
+        const uint64_t RX = ~(((uint64_t)rev2_32(w1) << 32) | rev2_32(w0));
+        const int fsh = 64 - 2 * m;
+        uint32_t* dst = kg + 17 * c;                       // scanf_pad(16c + s) = 17c + s for s < 16
 #pragma unroll
-        for (int p = 0; p < 31; ++p) {                     // base index 16c + p
-            const uint32_t b = ((p < 16 ? w0 : w1) >> (30 - 2 * (p & 15))) & 3u;
-            fw = ((fw << 2) | b) & mmask;
-            rc = (rc >> 2) | ((3u - b) << (2 * (m - 1)));
-            run = ((vv >> p) & 1u) ? run + 1 : 0;
-            const int s = p - (m - 1);                     // m-mer start completed by base p
-            if (s >= 0 && s < 16) kg[scanf_pad(16 * c + s)] = run >= m ? mix32(rc < fw ? rc : fw) : 0xFFFFFFFFu;
+        for (int s = 0; s < 16; ++s) {
+            const uint32_t fw = (uint32_t)(X >> (fsh - 2 * s)) & mmask;
+            const uint32_t rc = (uint32_t)(RX >> (2 * s)) & mmask;
+            dst[s] = mix32(rc < fw ? rc : fw) | (((xv >> s) & 1u) - 1u);      // invalid m-mer -> 0xFFFFFFFF
         }
     }
     __syncthreads();
+    CDBG_SPH(1);
 
     // ---- C. g[q] = min of keys[q .. q+WN-1], 16 junctions per lane from a register window ----
     // ---- D. validity and run-break bits ----
     uint32_t gq[16];
     const int nchunk_g = (15 + SCANF_TILE + 2 + 15) / 16;   // chunks containing junction q <= TILE+16
     for (int c = tid; c < nchunk_g; c += SCAN_THREADS) {    // (one iteration: nchunk_g <= 256)
-        uint32_t a[16 + SCANF_WNMAX - 1];
+        if (WNT == 15) {
+            // window of exactly 15 keys (k = 31, m = 16): g[j] = min(a[j..14]) min min(a[15..j+14]), i.e. a
+            // suffix minimum of the first 15 keys and a prefix minimum of the next 15: 42 min instead of 224
+            uint32_t a[30];
 #pragma unroll
-        for (int i = 0; i < 16 + SCANF_WNMAX - 1; ++i) a[i] = (i < 16 + WN - 1) ? kg[scanf_pad(16 * c + i)] : 0xFFFFFFFFu;
+            for (int i = 0; i < 30; ++i) a[i] = kg[17 * c + i + (i >> 4)];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) gq[j] = a[j];
+            for (int i = 13; i >= 0; --i) a[i] = a[i] < a[i + 1] ? a[i] : a[i + 1];
 #pragma unroll
-        for (int w = 1; w < SCANF_WNMAX; ++w) {
-            if (w < WN) {
+            for (int i = 16; i < 30; ++i) a[i] = a[i] < a[i - 1] ? a[i] : a[i - 1];
+            gq[0] = a[0]; gq[15] = a[29];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) gq[j] = gq[j] < a[j + w] ? gq[j] : a[j + w];
+            for (int j = 1; j < 15; ++j) gq[j] = a[j] < a[j + 14] ? a[j] : a[j + 14];
+        } else {
+            uint32_t a[16 + SCANF_WNMAX - 1];
+#pragma unroll
+            for (int i = 0; i < 16 + SCANF_WNMAX - 1; ++i) a[i] = (i < 16 + WN - 1) ? kg[scanf_pad(16 * c + i)] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) gq[j] = a[j];
+#pragma unroll
+            for (int w = 1; w < SCANF_WNMAX; ++w) {
+                if (w < WN) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) gq[j] = gq[j] < a[j + w] ? gq[j] : a[j + w];
+                }
             }
         }
     }
@@ -112,6 +141,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
         for (int j = 0; j < 16; ++j) kg[scanf_pad(16 * tid + j)] = gq[j];
     }
     __syncthreads();
+    CDBG_SPH(2);
     {
         // validity window: bit i <-> base 16*tid + i - 16 (i.e. starts one chunk earlier, for q-1 tests)
         const int c = tid;
@@ -120,20 +150,19 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
             const uint16_t* v16 = reinterpret_cast<const uint16_t*>(vm);
             const uint64_t lo = (uint64_t)v16[c - 1] | ((uint64_t)v16[c] << 16) | ((uint64_t)v16[c + 1] << 32) | ((uint64_t)v16[c + 2] << 48);
             const uint64_t hi = (uint64_t)v16[c + 3] | ((uint64_t)v16[c + 4] << 16);
-            const uint64_t jm = (1ULL << (k - 1)) - 1ULL;   // k-1 <= 62 bits; wq/wp below hold 64 valid bits
+            // bit t of Y <- the k-1 bases starting at window bit 15+t are all valid (AND by doubling): bit j+1 is
+            // junction q = 16c+j, bit j is junction q-1
+            unsigned __int128 Y = (((unsigned __int128)hi << 64) | lo) >> 15;
+            { const int K1 = k - 1; int len = 1; while (2 * len <= K1) { Y &= Y >> len; len *= 2; } Y &= Y >> (K1 - len); }
+            const uint32_t vj = (uint32_t)(Y >> 1) & 0xFFFFu, vp = (uint32_t)Y & 0xFFFFu;
             const uint32_t gprev = kg[scanf_pad(16 * c - 1)];
+            uint32_t eq = gq[0] == gprev ? 1u : 0u;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                // junction q = 16c + j <-> window bit 16 + j; junction q-1 <-> bit 15 + j
-                const uint64_t wq = (lo >> (16 + j)) | (hi << (48 - j));
-                const uint64_t wp = (lo >> (15 + j)) | (hi << (49 - j));
-                const bool v = (wq & jm) == jm;
-                const bool vp = (wp & jm) == jm;
-                const uint32_t gp = j ? gq[j - 1] : gprev;
-                const bool cont = v && vp && gq[j] == gp && !(c == 1 && j == 0);
-                brk16 |= (cont ? 0u : 1u) << j;
-                stt16 |= ((v && !cont) ? 1u : 0u) << j;
-            }
+            for (int j = 1; j < 16; ++j) eq |= (gq[j] == gq[j - 1] ? 1u : 0u) << j;
+            uint32_t cont = vj & vp & eq;
+            if (c == 1) cont &= ~1u;                        // the tile's first junction never continues a run
+            brk16 = ~cont & 0xFFFFu;
+            stt16 = vj & ~cont;
         } else {
             brk16 = 0xFFFFu;                                // outside the tile's own junctions: always a break
         }
@@ -155,11 +184,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
         if (tid == SCAN_THREADS - 1) s_nstart = (uint32_t)off;
     }
     __syncthreads();
+    CDBG_SPH(3);
 
     // ---- E2. one lane per run ----
     const int NMAX = CAPB - k + 1;
     const uint32_t rank_mask = (1u << P.rank_bits) - 1u;
-    uint32_t n_members = 0, n_trav = 0;
     const int nstart = (int)s_nstart;
     for (int i = tid; i < nstart; i += SCAN_THREADS) {
         const int s = sl[i];                                // run = junctions [s, e] in q space
@@ -209,6 +238,12 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
             c = ce + 1;
         }
     }
+    __syncthreads();                                        // the next tile reuses the LDS arrays
+    CDBG_SPH(4);
+    }
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+    if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) atomic_add_u64(&P.stats[16 + i], sph[i]);
+#endif
     if (MODE != SCAN_EMIT) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { n_members += __shfl_xor(n_members, d); n_trav += __shfl_xor(n_trav, d); }

@@ -79,13 +79,21 @@ struct Kmer {
             else w[i] &= (~0ULL) >> (64 - (bits - lo));
         }
     }
+    // w[idx], or 0 when idx is outside [0, W): select chain, because a runtime index into w[] sends the
+    // array to scratch memory (even for W == 1)
+    CDBG_HD uint64_t word_z(int idx) const {
+        uint64_t r = 0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) r = (idx == j) ? w[j] : r;
+        return r;
+    }
     // logical shifts of the whole W-word integer by s bits, 0 <= s < 64*W
     CDBG_HD Kmer shr(int s) const {
         Kmer r;
         const int ws = s >> 6, bs = s & 63;
+#pragma unroll
         for (int i = 0; i < W; ++i) {
-            uint64_t lo = (i + ws < W) ? w[i + ws] : 0;
-            uint64_t hi = (i + ws + 1 < W) ? w[i + ws + 1] : 0;
+            const uint64_t lo = word_z(i + ws), hi = word_z(i + ws + 1);
             r.w[i] = bs ? ((lo >> bs) | (hi << (64 - bs))) : lo;
         }
         return r;
@@ -93,9 +101,9 @@ struct Kmer {
     CDBG_HD Kmer shl(int s) const {
         Kmer r;
         const int ws = s >> 6, bs = s & 63;
+#pragma unroll
         for (int i = W - 1; i >= 0; --i) {
-            uint64_t hi = (i - ws >= 0) ? w[i - ws] : 0;
-            uint64_t lo = (i - ws - 1 >= 0) ? w[i - ws - 1] : 0;
+            const uint64_t hi = word_z(i - ws), lo = word_z(i - ws - 1);
             r.w[i] = bs ? ((hi << bs) | (lo >> (64 - bs))) : hi;
         }
         return r;

@@ -104,3 +104,27 @@ def test_capped_single_pass_scan(oracle, sim, key, part_cap, monkeypatch):
         monkeypatch.setenv("CDBG_PART_CAP", part_cap)
     name, k, amin = _case(key)
     assert_parity(oracle, sim, oracle_lib.read_input(name), k, amin, log2_partitions=4)
+
+
+@pytest.mark.parametrize("k,m", [(31, 16), (21, 6), (25, 10), (31, 10), (17, 16), (55, 16), (63, 16), (33, 15), (45, 12), (63, 8), (71, 16), (127, 16)])
+def test_scan_window_variants(oracle, sim, k, m):
+    """every (k, m) shape of the register-window scan: the 15-key specialisation (k-m == 15, with and without a
+    full 32-bit m-mer mask), shorter and longer windows, two-word k-mers; reads with N, lower case, reads
+    shorter than k and shorter than m, runs of invalid bytes next to tile and 16-base chunk borders"""
+    rng = random.Random(1000 * k + m)
+    g = "".join(rng.choice("ACGT") for _ in range(2500))
+    g = g[:900] + g[200:420] + g[900:1500] + g[1000:1100][::-1].translate(str.maketrans("ACGT", "TGCA")) + g[1500:]
+    reads = []
+    for i in range(160):
+        L = rng.choice([3, 10, k - 1, k, k + 1, 40, 90, 150, 151, 260])
+        s = rng.randrange(0, len(g) - L)
+        r = g[s:s + L]
+        if rng.random() < 0.5:
+            r = r[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        if rng.random() < 0.25 and L > 20:
+            p = rng.randrange(0, L); r = r[:p] + rng.choice(["N", "NN", "n", "X" * 17]) + r[p + 1:]
+        if rng.random() < 0.2:
+            r = r.lower()
+        reads.append(r)
+    text = "\n".join(reads) + "\n"
+    assert_parity(oracle, sim, text, k, rng.choice([1, 2]), log2_partitions=rng.choice([0, 4, 7]), minimizer_size=m)
