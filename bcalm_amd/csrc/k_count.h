@@ -25,8 +25,6 @@ namespace cdbg {
 // per-wave member map entries (records of a batch x members per record).  Kept small on purpose: with
 // 416 B per wave the W=1 kernel stays under 53 KB of LDS = 3 workgroups (24 waves) per CU, which
 // measured 13 % faster than 64-record batches at 2 workgroups per CU.
-template <int W> struct CountMap { static constexpr int CAP = W == 1 ? 416 : W == 2 ? 1408 : 976; };
-constexpr int COUNT_MAP_DOC = 416;                       // per-wave member map entries (records of a batch x members)
 constexpr uint32_t COUNT_CHUNK = 32768;                // solid entries a workgroup reserves per device atomic
 constexpr uint32_t TRAV_FLAG = 0x80000000u;          // in a count word: this entry is a traveller copy
 constexpr uint32_t ST_EMPTY = 0u, ST_BUSY = 1u;      // slot states for multi-word keys (W > 1)
@@ -79,13 +77,18 @@ CDBG_DEV uint32_t ktable_insert(const KTable<W>& t, const Kmer<W>& key, bool& is
     uint32_t s = h & t.mask;
     is_new = false;
     if (W == 1) {
-        for (uint32_t probes = 0; probes < max_probe; ++probes) {
-            const uint64_t old = atomic_cas_u64(&t.keys[s], ~0ULL, key.w[0]);
-            if (old == ~0ULL) { is_new = true; return s; }
-            if (old == key.w[0]) return s;
-            s = (s + 1) & t.mask;
-        }
-        return 0xFFFFFFFFu;
+        // single-exit loop (one compare-and-swap, a few selects, one back edge): the early-return form costs twice
+        // the instructions per probe once the compiler has structurised and unrolled its three exits
+        uint32_t probes = 0; bool hit; uint64_t old;
+#pragma clang loop unroll(disable)
+        do {
+            old = atomic_cas_u64(&t.keys[s], ~0ULL, key.w[0]);
+            hit = (old == ~0ULL) | (old == key.w[0]);
+            s = hit ? s : ((s + 1) & t.mask);
+            ++probes;
+        } while (!hit && probes < max_probe);
+        is_new = old == ~0ULL;
+        return hit ? s : 0xFFFFFFFFu;
     } else {
         const uint32_t tag = (h >> 1) | 0x80000000u;
         for (uint32_t probes = 0; probes < max_probe;) {
@@ -112,25 +115,31 @@ template <int W>
 CDBG_DEV uint32_t ktable_find(const KTable<W>& t, const Kmer<W>& key) {
     const uint32_t h = key.hash();
     uint32_t s = h & t.mask;
+    // single-exit loops (see ktable_insert)
     if (W == 1) {
-        for (;;) {
-            const uint64_t v = t.keys[s];
-            if (v == key.w[0]) return s;
-            if (v == ~0ULL) return 0xFFFFFFFFu;
-            s = (s + 1) & t.mask;
-        }
+        uint64_t v; bool stop;
+#pragma clang loop unroll(disable)
+        do {
+            v = t.keys[s];
+            stop = (v == key.w[0]) | (v == ~0ULL);
+            s = stop ? s : ((s + 1) & t.mask);
+        } while (!stop);
+        return v == key.w[0] ? s : 0xFFFFFFFFu;
     } else {
         const uint32_t tag = (h >> 1) | 0x80000000u;
-        for (;;) {
+        bool found = false, stop;
+#pragma clang loop unroll(disable)
+        do {
             const uint32_t st = t.state[s];
-            if (st == ST_EMPTY) return 0xFFFFFFFFu;
             if (st == tag) {
                 bool eq = true;
                 for (int i = 0; i < W; ++i) eq &= (t.keys[(uint64_t)s * W + i] == key.w[i]);
-                if (eq) return s;
+                found = eq;
             }
-            s = (s + 1) & t.mask;
-        }
+            stop = found | (st == ST_EMPTY);
+            s = stop ? s : ((s + 1) & t.mask);
+        } while (!stop);
+        return found ? s : 0xFFFFFFFFu;
     }
 }
 
@@ -197,11 +206,12 @@ struct CountParams {
 // ---------------------------------------------------------------------------
 // One partition, processed by the whole workgroup.
 //
-// Insert phase, member-parallel: each wave loads a batch of records (one per lane), builds
-// a prefix sum of their member counts with wave shuffles and a member->record map in LDS,
-// then every lane extracts ONE k-mer per step (funnel shift of the record fetched from the
-// owning lane with ds_bpermute), so all 64 lanes insert on every step regardless of how
-// many k-mers each record holds.
+// Insert phase, member-parallel: each wave loads a batch of 64 records (one per lane) and
+// builds a prefix sum of their member counts with wave shuffles; then every lane takes ONE
+// member k-mer per step: it finds the owning record by a 6-step binary search over the
+// lanes' prefix sums (ds_bpermute), fetches that record from its lane (ds_bpermute) and
+// extracts the k-mer with a funnel shift, so all 64 lanes insert on every step regardless
+// of how many k-mers each record holds.
 //
 // npass == 1: build the table once, sweep for statistics + solid count, reserve the
 // output segment, sweep again to write it.
@@ -220,8 +230,6 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
     CDBG_SHARED uint64_t l_keys[GLOBAL ? 1 : TS * W];
     CDBG_SHARED uint32_t l_state[(GLOBAL || W == 1) ? 1 : TS];
     CDBG_SHARED uint32_t l_cnt[GLOBAL ? 1 : TS];
-    constexpr int COUNT_MAP = CountMap<W>::CAP;
-    CDBG_SHARED uint8_t l_map[NW][COUNT_MAP];
     CDBG_SHARED uint32_t s_fill, s_over, s_nsolid, s_wr;
     CDBG_SHARED uint64_t s_base;
     CDBG_SHARED uint32_t s_stat[4];
@@ -248,9 +256,6 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
     T.mask = cap - 1;
     const uint32_t maxfill = cap - cap / 4;                       // load limit; inserts also give up after 64 probes
     const int k = P.k;
-    const int nmax = RecFmt<W>::CAPB - k + 1;                      // members per record
-    int RB = 64; while (RB * nmax > COUNT_MAP) RB >>= 1;           // records per wave batch (map capacity)
-    uint8_t* map = l_map[wave];
 
     uint32_t npass = GLOBAL ? 1u : start_np;
     for (;;) {                                                    // attempts with npass, 2 npass, ...
@@ -266,9 +271,12 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                 for (uint32_t i = tid; i < cap; i += NT) cnt[i] = 0;
                 block_sync<GLOBAL>();
                 CDBG_PH(1);
-                for (uint64_t b0 = rec0 + (uint64_t)wave * RB; b0 < rec1; b0 += (uint64_t)NW * RB) {   // wave-uniform
+                // the partition's records are split evenly over the waves; a wave takes its share 64 records at a time
+                const uint64_t per_wave = (rec1 - rec0 + NW - 1) / NW;
+                const uint64_t w0 = rec0 + (uint64_t)wave * per_wave, w1 = (w0 + per_wave < rec1) ? w0 + per_wave : rec1;
+                for (uint64_t b0 = w0; b0 < w1; b0 += 64) {      // wave-uniform
                     if (__any((int)ld_volatile_u32(&s_over))) break;
-                    const int nrec = (int)((rec1 - b0) < (uint64_t)RB ? (rec1 - b0) : (uint64_t)RB);
+                    const int nrec = (int)((w1 - b0) < 64 ? (w1 - b0) : 64);
                     RecView<W> R; int n = 0;
 #pragma unroll
                     for (int i = 0; i < RW; ++i) R.r[i] = 0;
@@ -280,18 +288,23 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     int incl = n;                                  // inclusive prefix sum over the wave
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-                    const int excl = incl - n;
+                    const int excl = incl - n;                     // lanes past the batch: excl == total
                     const int total = __shfl(incl, 63);
-                    for (int j = 0; j < n; ++j) map[excl + j] = (uint8_t)lane;
-                    CDBG_WAVE_SYNC();
                     for (int g0 = 0; g0 < total; g0 += 64) {       // wave-uniform trip count
                         const int g = g0 + lane;
                         const bool active = g < total;
-                        const int ri = active ? (int)map[g] : 0;
+                        // owning record of member g: the last lane whose first member is <= g (binary search over
+                        // the lanes' prefix sums with ds_bpermute; no member->record map, so a batch is 64 records)
+                        int ri = 0, ex = 0;
+#pragma unroll
+                        for (int step = 32; step >= 1; step >>= 1) {
+                            const int cand = ri + step;
+                            const int e = __shfl(excl, cand & 63);
+                            if (e <= g) { ri = cand; ex = e; }     // ri stays a multiple of 2*step, so cand <= 63
+                        }
                         RecView<W> Q;
 #pragma unroll
                         for (int i = 0; i < RW; ++i) Q.r[i] = __shfl(R.r[i], ri);
-                        const int ex = __shfl(excl, ri);
                         if (active) {
                             const int t = g - ex, qn = Q.n();
                             const Kmer<W> fw = Q.kmer(t, k);
@@ -310,7 +323,6 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                             }
                         }
                     }
-                    CDBG_WAVE_SYNC();                              // map is rewritten by the next batch
                 }
                 block_sync<GLOBAL>();
                 CDBG_PH(2);
