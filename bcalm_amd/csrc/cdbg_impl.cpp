@@ -505,9 +505,9 @@ int glue_impl(cdbg_ctx* c) {
     if (2 * NP >= 0xFFFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 32-bit end ids (%llu)", (unsigned long long)NP);
     const uint32_t NS = (uint32_t)(2 * NP);
     Timer t; CK(t.start(s));
-    DBuf<uint32_t> link, flag, head_uid; DBuf<uint4> st_a, st_b;
+    DBuf<uint32_t> link, flag; DBuf<uint4> st_a, st_b;
     CK(link.alloc(NS, false)); CK(st_a.alloc(NS, false)); CK(st_b.alloc(NS, false));
-    CK(flag.alloc(4, true)); CK(head_uid.alloc(NS, false));
+    CK(flag.alloc(4, true));
     HIPCK(hipMemsetAsync(link.p, 0xFF, (size_t)std::max<uint32_t>(NS, 1) * sizeof(uint32_t), s));
     HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
     HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
@@ -519,7 +519,7 @@ int glue_impl(cdbg_ctx* c) {
     GlueResolveParams gp{};
     gp.keys = c->glue_keys.p; gp.state = c->glue_state.p; gp.a = c->glue_a.p; gp.b = c->glue_b.p; gp.conf = c->glue_conf.p;
     gp.cap = c->glue_cap; gp.W = W; gp.link = link.p; gp.stats = c->dstats.p;
-    CDBG_LAUNCH(k_glue_resolve, (c->glue_cap + GLUE_THREADS - 1) / GLUE_THREADS, GLUE_THREADS, s, gp);
+    CDBG_LAUNCH(k_glue_resolve, std::min<uint64_t>((c->glue_cap + GLUE_THREADS - 1) / GLUE_THREADS, GLUE_RESOLVE_GRID), GLUE_THREADS, s, gp);
 
     uint64_t n_cycles_cut = 0;
     const uint32_t gridS = (NS + GLUE_THREADS - 1) / GLUE_THREADS;
@@ -560,14 +560,14 @@ int glue_impl(cdbg_ctx* c) {
     HIPCK(hipMemsetAsync(c->cursors.p + 2, 0, 2 * sizeof(uint64_t), s));
     if (NS) {
         HeadParams hp{};
-        hp.n_states = NS; hp.k = c->k; hp.link = link.p; hp.st = fa_st; hp.head_uid = head_uid.p;
+        hp.n_states = NS; hp.k = c->k; hp.link = link.p; hp.st = fa_st; hp.hinfo = (fa_st == st_a.p) ? st_b.p : st_a.p;
         hp.unitig_off = c->unitig_off.p; hp.unitig_len = c->unitig_len.p; hp.unitig_kc = c->unitig_kc.p;
         hp.unitig_cap = ucap; hp.out_cap = ocap; hp.n_unitigs = c->cursors.p + 2; hp.out_cursor = c->cursors.p + 3; hp.error = c->derr.p;
-        CDBG_LAUNCH(k_unitig_heads, gridS, GLUE_THREADS, s, hp);
+        CDBG_LAUNCH(k_unitig_heads, (NS + HEADS_PER_WG - 1) / HEADS_PER_WG, GLUE_THREADS, s, hp);
         EmitParams ep{};
-        ep.n_pieces = (uint32_t)NP; ep.k = c->k; ep.st = fa_st; ep.head_uid = head_uid.p;
+        ep.n_pieces = (uint32_t)NP; ep.k = c->k; ep.st = fa_st; ep.hinfo = hp.hinfo;
         ep.piece_n = c->piece_n.p; ep.piece_kc = c->piece_kc.p; ep.piece_boff = c->piece_boff.p; ep.piece_bases = c->piece_bases.p;
-        ep.unitig_off = c->unitig_off.p; ep.unitig_kc = c->unitig_kc.p; ep.out = c->unitig_bases.p;
+        ep.unitig_kc = c->unitig_kc.p; ep.out = c->unitig_bases.p;
         ep.piece_ab = c->prm.all_abundance_counts ? c->piece_ab.p : nullptr; ep.unitig_ab = c->unitig_ab.p;
         CDBG_LAUNCH(k_emit, (uint32_t)((NP + GLUE_THREADS - 1) / GLUE_THREADS), GLUE_THREADS, s, ep);
     }

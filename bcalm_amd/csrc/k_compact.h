@@ -91,9 +91,14 @@ CDBG_DEV Kmer<W> canon_junction(const Kmer<W>& u_out, int k) {
 template <int W>
 CDBG_DEV int probe_succ(const KTable<W>& T, const Kmer<W>& u, int k, uint32_t& slot, uint32_t& enter_end) {
     int n = 0;
+    // the four successors u[1:]+c share everything but one base: v = (u << 2) | c, and its reverse complement is
+    // comp(c) in front of rc(u) without its last base -- one rc() for the four probes
+    Kmer<W> vb = u; vb.push_right(k, 0);
+    const Kmer<W> rb = u.rc(k).shr(2);
+    const int pos = 2 * (k - 1);
     for (uint32_t c = 0; c < 4; ++c) {
-        Kmer<W> v = u; v.push_right(k, c);
-        const Kmer<W> r = v.rc(k);
+        Kmer<W> v = vb; v.w[0] |= (uint64_t)c;
+        Kmer<W> r = rb; r.or_word(pos >> 6, (uint64_t)(3u - c) << (pos & 63));
         const bool fwd = !(r < v);                       // v is the canonical label
         const uint32_t f = ktable_find<W>(T, fwd ? v : r);
         if (f != NONE32) { ++n; slot = f; enter_end = fwd ? END_LEFT : END_RIGHT; }

@@ -29,21 +29,24 @@ struct GlueResolveParams {
     uint32_t* link;                // [2 * n_pieces], NONE32 = no partner
     uint64_t* stats;               // [0] junctions joined
 };
+// grid-stride, no LDS and no barrier: a workgroup that only lives for 256 table slots costs more to launch
+// than to run (the table has 2^28 slots); joined junctions are counted per lane, then one atomic per wave
+constexpr uint32_t GLUE_RESOLVE_GRID = 8192;
 __global__ void k_glue_resolve(GlueResolveParams P) {
-    CDBG_SHARED uint32_t s_joined;
-    if (threadIdx.x == 0) s_joined = 0;
-    __syncthreads();
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < P.cap && P.conf[s]) {
+    uint32_t joined = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < P.cap; s += stride) {
+        if (!P.conf[s]) continue;
         const uint32_t a = P.a[s], b = P.b[s];
         if (a != 0 && b != 0) {
             P.link[a - 1] = b - 1;
             P.link[b - 1] = a - 1;
-            atomic_add_u32(&s_joined, 1u);
+            ++joined;
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_joined) atomic_add_u64(&P.stats[0], (uint64_t)s_joined);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) joined += __shfl_xor(joined, d);
+    if ((threadIdx.x & 63) == 0 && joined) atomic_add_u64(&P.stats[0], (uint64_t)joined);
 }
 
 // ---- (2) pointer jumping ----
@@ -93,44 +96,73 @@ __global__ void k_cut_cycles(CutParams P) {
 struct HeadParams {
     uint32_t n_states; int k;
     const uint32_t* link; const uint4* st;               // st[e].y = k-mers to the tail, st[e].z = tail state
-    uint32_t* head_uid;            // per state (valid for head states)
+    uint4* hinfo;                  // per state, written for head states only: {unitig id, k-mers of the unitig, output offset lo, hi}
+                                   // (the spare ping-pong buffer of the ranking: one 16-byte gather for k_emit)
     uint64_t* unitig_off; uint32_t* unitig_len; uint64_t* unitig_kc;
     uint64_t unitig_cap, out_cap;
     uint64_t* n_unitigs; uint64_t* out_cursor; uint32_t* error;
 };
+// One workgroup per HEADS_PER_WG consecutive states (HEADS_ITEMS per lane): the heads of the workgroup get
+// consecutive unitig ids and output space from ONE device reservation; positions inside the batch come from a
+// workgroup-wide exclusive scan of the per-lane (count, length) sums -- no per-head atomics.
+constexpr int HEADS_ITEMS = 8;
+constexpr int HEADS_PER_WG = GLUE_THREADS * HEADS_ITEMS;
 __global__ void k_unitig_heads(HeadParams P) {
-    CDBG_SHARED uint32_t s_n; CDBG_SHARED uint64_t s_len, s_ubase, s_obase;
-    if (threadIdx.x == 0) { s_n = 0; s_len = 0; }
-    __syncthreads();
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    CDBG_SHARED uint32_t s_wn[GLUE_THREADS / 64]; CDBG_SHARED uint64_t s_wl[GLUE_THREADS / 64];
+    CDBG_SHARED uint64_t s_ubase, s_obase;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * HEADS_PER_WG;
     // head of the chosen direction: no predecessor, and the larger tail of the two directions
     // (piece ids inside unused reservation gaps have piece_n == 0 => acc == 0: not a unitig)
-    const bool head = e < P.n_states && P.link[e] == NONE32 && P.st[e].z > P.st[e ^ 1u].z && P.st[e].y != 0;
-    uint32_t len = 0, my_i = 0; uint64_t my_o = 0;
-    if (head) {
-        len = P.st[e].y + (uint32_t)P.k - 1u;
-        my_i = atomic_add_u32(&s_n, 1u);                   // LDS: position inside this workgroup's batch
-        my_o = atomic_add_u64(&s_len, (uint64_t)len);
+    uint32_t len[HEADS_ITEMS]; uint32_t cnt = 0; uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < HEADS_ITEMS; ++i) {
+        const uint64_t e = base + (uint64_t)i * GLUE_THREADS + tid;
+        len[i] = 0;
+        if (e < P.n_states && P.link[e] == NONE32) {
+            const uint4 v = P.st[e];
+            if (v.y != 0 && v.z > P.st[e ^ 1u].z) { len[i] = v.y + (uint32_t)P.k - 1u; ++cnt; sum += len[i]; }
+        }
+    }
+    // exclusive scan of (cnt, sum) over the workgroup: wave shuffles, then the wave totals through LDS
+    uint32_t icnt = cnt; uint64_t isum = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t c = __shfl_up(icnt, d); const uint64_t l = __shfl_up(isum, d);
+        if (lane >= d) { icnt += c; isum += l; }
+    }
+    if (lane == 63) { s_wn[wave] = icnt; s_wl[wave] = isum; }
+    __syncthreads();
+    uint32_t my_i = icnt - cnt, tot_n = 0; uint64_t my_o = isum - sum, tot_l = 0;
+    for (int w = 0; w < GLUE_THREADS / 64; ++w) {
+        if (w < wave) { my_i += s_wn[w]; my_o += s_wl[w]; }
+        tot_n += s_wn[w]; tot_l += s_wl[w];
+    }
+    if (tid == 0 && tot_n) {                               // one reservation per workgroup
+        s_ubase = atomic_add_u64(P.n_unitigs, (uint64_t)tot_n);
+        s_obase = atomic_add_u64(P.out_cursor, tot_l);
     }
     __syncthreads();
-    if (threadIdx.x == 0 && s_n) {                         // one reservation per workgroup
-        s_ubase = atomic_add_u64(P.n_unitigs, (uint64_t)s_n);
-        s_obase = atomic_add_u64(P.out_cursor, s_len);
+    if (!cnt) return;
+    uint64_t uid = s_ubase + my_i, off = s_obase + my_o;
+#pragma unroll
+    for (int i = 0; i < HEADS_ITEMS; ++i) {
+        if (!len[i]) continue;
+        const uint64_t e = base + (uint64_t)i * GLUE_THREADS + tid;
+        uint4 h; h.x = NONE32; h.y = len[i] - ((uint32_t)P.k - 1u); h.z = (uint32_t)off; h.w = (uint32_t)(off >> 32);
+        if (uid >= P.unitig_cap || off + len[i] > P.out_cap) *P.error = 4;
+        else { h.x = (uint32_t)uid; P.unitig_off[uid] = off; P.unitig_len[uid] = len[i]; P.unitig_kc[uid] = 0; }
+        P.hinfo[e] = h;
+        ++uid; off += len[i];
     }
-    __syncthreads();
-    if (!head) return;
-    const uint64_t uid = s_ubase + my_i, off = s_obase + my_o;
-    if (uid >= P.unitig_cap || off + len > P.out_cap) { *P.error = 4; P.head_uid[e] = NONE32; return; }
-    P.head_uid[e] = (uint32_t)uid;
-    P.unitig_off[uid] = off; P.unitig_len[uid] = len; P.unitig_kc[uid] = 0;
 }
 
 // ---- (4) emit: one lane per piece ----
 struct EmitParams {
     uint32_t n_pieces; int k;
-    const uint4* st; const uint32_t* head_uid;
+    const uint4* st; const uint4* hinfo;
     const uint32_t* piece_n; const uint64_t* piece_kc; const uint64_t* piece_boff; const uint8_t* piece_bases;
-    const uint64_t* unitig_off; uint64_t* unitig_kc; uint8_t* out;
+    uint64_t* unitig_kc; uint8_t* out;
     const uint32_t* piece_ab; uint32_t* unitig_ab;   // optional per-k-mer abundances, indexed like the bases (k-mer ending at that base)
 };
 CDBG_DEV uint8_t comp_ascii(uint8_t c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; }
@@ -144,18 +176,20 @@ __global__ void k_emit(EmitParams P) {
     const uint32_t head = ((s0.z > s1.z) ? s1.z : s0.z) ^ 1u;             // head of d = mirror of the tail of the reverse direction
     const uint32_t n = P.piece_n[p];
     if (n == 0) return;                                    // reservation gap
-    const uint32_t uid = P.head_uid[head];
+    const uint4 h = P.hinfo[head];                          // ONE gather: unitig id, its k-mer count, its output offset
+    const uint32_t uid = h.x;
     if (uid == NONE32) return;
-    const uint32_t koff = P.st[head].y - ((s0.z > s1.z) ? s0.y : s1.y);   // k-mers before this piece
+    const uint32_t koff = h.y - ((s0.z > s1.z) ? s0.y : s1.y);             // k-mers before this piece
     const uint32_t nb = n + (uint32_t)P.k - 1u;
     const uint8_t* src = P.piece_bases + P.piece_boff[p];
-    uint8_t* dst = P.out + P.unitig_off[uid] + koff;
+    const uint64_t uoff = (uint64_t)h.z | ((uint64_t)h.w << 32);
+    uint8_t* dst = P.out + uoff + koff;
     const uint32_t skip = koff ? (uint32_t)P.k - 1u : 0u;  // the overlap was written by the previous piece
     if ((e & 1u) == END_LEFT) { for (uint32_t i = skip; i < nb; ++i) dst[i] = src[i]; }
     else { for (uint32_t i = skip; i < nb; ++i) dst[i] = comp_ascii(src[nb - 1 - i]); }
     if (P.piece_ab) {                                      // -all-abundance-counts: k-mer t of the piece -> k-mer koff+t (or mirrored)
         const uint32_t* sa = P.piece_ab + P.piece_boff[p] + (P.k - 1);
-        uint32_t* da = P.unitig_ab + P.unitig_off[uid] + koff + (P.k - 1);
+        uint32_t* da = P.unitig_ab + uoff + koff + (P.k - 1);
         if ((e & 1u) == END_LEFT) { for (uint32_t t = 0; t < n; ++t) da[t] = sa[t]; }
         else { for (uint32_t t = 0; t < n; ++t) da[t] = sa[n - 1 - t]; }
     }
