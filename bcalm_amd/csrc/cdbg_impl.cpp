@@ -76,7 +76,10 @@ struct DBuf {                                   // owned device array
 #define CDBG_NTC1 512
 #endif
 constexpr int TS_COUNT_1 = CDBG_TSC1, TS_COUNT_2 = 2048, TS_COUNT_4 = 1024;      // LDS table slots per W
-constexpr int TS_COMPACT_1 = 1024, TS_COMPACT_2 = 1024, TS_COMPACT_4 = 512;
+#ifndef CDBG_TSK1
+#define CDBG_TSK1 1024
+#endif
+constexpr int TS_COMPACT_1 = CDBG_TSK1, TS_COMPACT_2 = 1024, TS_COMPACT_4 = 512;
 template <int W> struct Cfg;
 template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1, NTC = CDBG_NTC1; };
 template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, NTC = 512; };

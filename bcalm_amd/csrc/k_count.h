@@ -223,13 +223,17 @@ struct CountParams {
 // ---------------------------------------------------------------------------
 template <int W, int TS, int NT, bool GLOBAL>
 CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_t (&acc)[4],
-                              uint32_t& start_np, uint32_t& strikes, uint64_t& chunk_base, uint32_t& chunk_left,
+                              uint32_t& start_np, uint32_t& strikes, bool& clean, uint64_t& chunk_base, uint32_t& chunk_left,
                               uint64_t (&ph)[8], uint64_t& t_prev) {
     constexpr int RW = RecFmt<W>::RW;
     constexpr int NW = NT / 64;
     CDBG_SHARED uint64_t l_keys[GLOBAL ? 1 : TS * W];
     CDBG_SHARED uint32_t l_state[(GLOBAL || W == 1) ? 1 : TS];
     CDBG_SHARED uint32_t l_cnt[GLOBAL ? 1 : TS];
+    // slots that received a new key, in insertion order: the single-pass sweep visits (and resets) only these
+    // instead of all TS slots, most of which are empty at the usual ~20-45 % load
+    constexpr uint32_t LIST_CAP = GLOBAL ? 1 : TS / 2;
+    CDBG_SHARED uint16_t l_used[LIST_CAP];
     CDBG_SHARED uint32_t s_fill, s_over, s_nsolid, s_wr;
     CDBG_SHARED uint64_t s_base;
     CDBG_SHARED uint32_t s_stat[4];
@@ -267,8 +271,11 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
             for (uint32_t pass = 0; pass < npass; ++pass) {
                 // ---- build the table of this pass ----
                 if (tid == 0) s_fill = 0;
-                ktable_clear<W>(T, tid, NT);
-                for (uint32_t i = tid; i < cap; i += NT) cnt[i] = 0;
+                if (!clean) {                                     // (the list sweep of the previous partition left it clean)
+                    ktable_clear<W>(T, tid, NT);
+                    for (uint32_t i = tid; i < cap; i += NT) cnt[i] = 0;
+                }
+                clean = false;
                 block_sync<GLOBAL>();
                 CDBG_PH(1);
                 // the partition's records are split evenly over the waves; a wave takes its share 64 records at a time
@@ -315,7 +322,11 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                                 const uint32_t s = ktable_insert<W, GLOBAL>(T, can, is_new, 64u);
                                 if (s == 0xFFFFFFFFu) s_over = 1;   // table (nearly) full: this pass is void
                                 else {
-                                    if (is_new) { if (atomic_add_u32(&s_fill, 1u) >= maxfill) s_over = 1; }
+                                    if (is_new) {
+                                        const uint32_t fi = atomic_add_u32(&s_fill, 1u);
+                                        if (fi >= maxfill) s_over = 1;
+                                        if (!GLOBAL && fi < LIST_CAP) l_used[fi] = (uint16_t)s;
+                                    }
                                     const bool trav = (t == 0 && Q.first_trav()) || (t == qn - 1 && Q.last_trav());
                                     atomic_add_u32(&cnt[s], 1u);
                                     if (trav) atomic_or_u32(&cnt[s], TRAV_FLAG);
@@ -345,19 +356,27 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     block_sync<GLOBAL>();
                     const uint64_t obase = s_base; const bool wr_ok = s_over == 0;
                     uint32_t st_dist = 0, st_occ = 0, st_sh = 0, st_st = 0;
-                    for (uint32_t s = tid; s < cap; s += NT) {
-                        if (!ktable_used<W>(T, s)) continue;
+                    const uint32_t nfill = s_fill;
+                    const bool by_list = !GLOBAL && nfill <= LIST_CAP;
+                    for (uint32_t i = tid; i < (by_list ? nfill : cap); i += NT) {
+                        const uint32_t s = by_list ? (uint32_t)l_used[i] : i;
+                        if (!by_list && !ktable_used<W>(T, s)) continue;
                         const uint32_t c = cnt[s], n = c & ~TRAV_FLAG; const bool trav = c & TRAV_FLAG;
                         if (!trav) { ++st_dist; st_occ += n; }
                         if (n >= P.amin) {
                             if (trav) ++st_st; else ++st_sh;
                             if (wr_ok) {
                                 const uint64_t o = obase + atomic_add_u32(&s_wr, 1u);
-                                for (int i = 0; i < W; ++i) P.solid_keys[o * W + i] = T.keys[(uint64_t)s * W + i];
+                                for (int i2 = 0; i2 < W; ++i2) P.solid_keys[o * W + i2] = T.keys[(uint64_t)s * W + i2];
                                 P.solid_cnt[o] = c;
                             }
                         }
+                        if (by_list) {                             // hand the slot back empty
+                            if (W == 1) T.keys[s] = ~0ULL; else T.state[s] = ST_EMPTY;
+                            cnt[s] = 0;
+                        }
                     }
+                    clean = by_list;
                     uint32_t pk0 = st_dist, pk1 = st_sh | (st_st << 16);
 #pragma unroll
                     for (int d = 32; d >= 1; d >>= 1) { pk0 += __shfl_xor(pk0, d); pk1 += __shfl_xor(pk1, d); st_occ += __shfl_xor(st_occ, d); }
@@ -454,14 +473,14 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
 template <int W, int TS, int NT, bool GLOBAL>
 __global__ void __launch_bounds__(NT) k_count(CountParams P) {
     uint64_t acc[4] = {0, 0, 0, 0};
-    uint32_t start_np = 1, strikes = 0;
+    uint32_t start_np = 1, strikes = 0; bool clean = false;
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_prev = 0;
     uint64_t chunk_base = 0; uint32_t chunk_left = 0;
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
     t_prev = wall_clock64();
 #endif
     for (uint32_t item = blockIdx.x; item < P.n_items; item += gridDim.x) {
-        count_partition<W, TS, NT, GLOBAL>(P, item, acc, start_np, strikes, chunk_base, chunk_left, ph, t_prev);
+        count_partition<W, TS, NT, GLOBAL>(P, item, acc, start_np, strikes, clean, chunk_base, chunk_left, ph, t_prev);
         __syncthreads();                                 // LDS is reused by the next partition
         CDBG_PH(5);
     }
