@@ -42,7 +42,7 @@ class Stats(C.Structure):
 EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
            "cdbg_generate_reads", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
            "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats",
-           "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end"]
+           "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end", "cdbg_glue_join", "cdbg_glue_links_export", "cdbg_glue_links_import"]
 
 
 def load(path: str | None = None) -> C.CDLL:
@@ -76,6 +76,9 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_exchange_begin.argtypes = [vp, u64, u64, u64]
     lib.cdbg_exchange_add.argtypes = [vp, u64, u64, u64, vp, vp, vp, vp, vp, vp]
     lib.cdbg_exchange_end.argtypes = [vp]
+    lib.cdbg_glue_join.argtypes = [vp, C.POINTER(u64)]
+    lib.cdbg_glue_links_export.argtypes = [vp, vp, u64]
+    lib.cdbg_glue_links_import.argtypes = [vp, vp, u64]
     return lib
 
 
@@ -205,6 +208,18 @@ class Graph:
 
     def exchange_end(self):
         self._ck(self.lib.cdbg_exchange_end(self._h))
+
+    def glue_join(self):
+        """sharded junction join; -> number of piece ends (length of the int32 link array)"""
+        n = C.c_uint64()
+        self._ck(self.lib.cdbg_glue_join(self._h, C.byref(n)))
+        return n.value
+
+    def glue_links_export(self, dst_ptr, nbytes):
+        self._ck(self.lib.cdbg_glue_links_export(self._h, C.c_void_p(dst_ptr), nbytes))
+
+    def glue_links_import(self, src_ptr, nbytes):
+        self._ck(self.lib.cdbg_glue_links_import(self._h, C.c_void_p(src_ptr), nbytes))
 
     # ---- results ----
     def stats(self) -> dict:

@@ -133,6 +133,8 @@ struct cdbg_ctx {
     // multi-GPU merge staging (cdbg_exchange_*)
     DBuf<uint32_t> mg_n, mg_gtag; DBuf<uint64_t> mg_kc, mg_boff, mg_gkeys; DBuf<uint8_t> mg_bases;
     uint64_t mg_np = 0, mg_nb = 0, mg_nl = 0, mg_cap_p = 0, mg_cap_b = 0, mg_cap_l = 0; bool mg_open = false;
+    // junction join result (cdbg_glue_join / first half of cdbg_glue): partner end of every piece end
+    DBuf<uint32_t> link; bool joined = false; uint64_t n_join_local = 0;
 
     DBuf<uint64_t> unitig_off; DBuf<uint32_t> unitig_len; DBuf<uint64_t> unitig_kc; DBuf<uint8_t> unitig_bases;
     uint64_t n_unitigs = 0, unitig_total = 0;
@@ -496,33 +498,68 @@ int compact_impl(cdbg_ctx* c) {
 #endif
     c->st.n_pieces = ks[3]; c->st.n_glue_open_ends = ks[0]; c->st.n_cycles = ks[2];
     c->st.ms_total += c->st.ms_compact;
-    c->stage = 2;
+    c->stage = 2; c->joined = false;
+    return CDBG_OK;
+}
+
+// Glue, first half: hash-join the piece ends on their junction (k-1)-mers -> link[end] = partner end.
+// sharded (multi-GPU, after cdbg_exchange_*): this rank joins only the junctions whose key hash selects it --
+// 1/world of the device atomics -- and leaves the other ends at NONE; the caller combines the link arrays of all
+// ranks with an element-wise MAX all-reduce (every end is set by exactly one rank) before cdbg_glue.
+template <int W>
+int glue_join_impl(cdbg_ctx* c, bool sharded) {
+    if (c->stage < 2) return fail(CDBG_E_STATE, "cdbg_glue before cdbg_compact");
+    hipStream_t s = c->stream;
+    const uint64_t NP = c->n_pieces;
+    if (2 * NP >= 0x7FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 31-bit end ids (%llu)", (unsigned long long)NP);
+    const uint32_t NS = (uint32_t)(2 * NP);
+    Timer t; CK(t.start(s));
+    CK(c->link.alloc(NS, false));
+    HIPCK(hipMemsetAsync(c->link.p, 0xFF, (size_t)std::max<uint32_t>(NS, 1) * sizeof(uint32_t), s));
+    HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+    HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
+    const uint32_t world = sharded ? (uint32_t)c->prm.world_size : 1u;
+    if (world > 1) {                                         // a table for this rank's share of the junctions
+        c->glue_cap = (uint32_t)pow2_at_least((c->n_glog + c->n_glog / 4) / world + (c->n_glog >> 6) + 1024);
+        CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false)); CK(c->glue_state.alloc(c->glue_cap, false));
+        CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
+        HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), s));
+        HIPCK(hipMemsetAsync(c->glue_state.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->glue_b.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->glue_conf.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
+    }
+    {   // build the junction table from the glue log (dense lanes => device atomics at throughput)
+        GlueBuildParams bp{ c->glog_keys.p, c->glog_tag.p, c->n_glog, c->glue_keys.p, c->glue_state.p, c->glue_a.p, c->glue_b.p, c->glue_conf.p, c->glue_cap - 1,
+                            world - 1, world > 1 ? (uint32_t)c->prm.rank : 0u };
+        if (c->n_glog) CDBG_LAUNCH((k_glue_build<W>), std::min<uint64_t>((c->n_glog + GLUE_THREADS - 1) / GLUE_THREADS, MAX_GRID), GLUE_THREADS, s, bp);
+    }
+    GlueResolveParams gp{};
+    gp.keys = c->glue_keys.p; gp.state = c->glue_state.p; gp.a = c->glue_a.p; gp.b = c->glue_b.p; gp.conf = c->glue_conf.p;
+    gp.cap = c->glue_cap; gp.W = W; gp.link = c->link.p; gp.stats = c->dstats.p;
+    CDBG_LAUNCH(k_glue_resolve, std::min<uint64_t>((c->glue_cap + GLUE_THREADS - 1) / GLUE_THREADS, GLUE_RESOLVE_GRID), GLUE_THREADS, s, gp);
+    float ms = 0; CK(t.stop(&ms));
+    CK(check_device_error(c, "glue join"));
+    uint64_t gs = 0; CK(read_u64(c->dstats.p, &gs));
+    c->n_join_local = gs; c->st.ms_glue = ms; c->joined = true;
     return CDBG_OK;
 }
 
 template <int W>
 int glue_impl(cdbg_ctx* c) {
     if (c->stage < 2) return fail(CDBG_E_STATE, "cdbg_glue before cdbg_compact");
+    if (!c->joined) CK(glue_join_impl<W>(c, false));         // (cdbg_glue_join ran it already in the sharded flow)
     hipStream_t s = c->stream;
     const uint64_t NP = c->n_pieces;
-    if (2 * NP >= 0xFFFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 32-bit end ids (%llu)", (unsigned long long)NP);
     const uint32_t NS = (uint32_t)(2 * NP);
+    const float ms_join = c->st.ms_glue;
     Timer t; CK(t.start(s));
-    DBuf<uint32_t> link, flag; DBuf<uint4> st_a, st_b;
-    CK(link.alloc(NS, false)); CK(st_a.alloc(NS, false)); CK(st_b.alloc(NS, false));
+    DBuf<uint32_t> flag; DBuf<uint4> st_a, st_b;
+    CK(st_a.alloc(NS, false)); CK(st_b.alloc(NS, false));
     CK(flag.alloc(4, true));
-    HIPCK(hipMemsetAsync(link.p, 0xFF, (size_t)std::max<uint32_t>(NS, 1) * sizeof(uint32_t), s));
     HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
     HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
-
-    {   // build the junction table from the glue log (dense lanes => device atomics at throughput)
-        GlueBuildParams bp{ c->glog_keys.p, c->glog_tag.p, c->n_glog, c->glue_keys.p, c->glue_state.p, c->glue_a.p, c->glue_b.p, c->glue_conf.p, c->glue_cap - 1 };
-        if (c->n_glog) CDBG_LAUNCH((k_glue_build<W>), std::min<uint64_t>((c->n_glog + GLUE_THREADS - 1) / GLUE_THREADS, MAX_GRID), GLUE_THREADS, s, bp);
-    }
-    GlueResolveParams gp{};
-    gp.keys = c->glue_keys.p; gp.state = c->glue_state.p; gp.a = c->glue_a.p; gp.b = c->glue_b.p; gp.conf = c->glue_conf.p;
-    gp.cap = c->glue_cap; gp.W = W; gp.link = link.p; gp.stats = c->dstats.p;
-    CDBG_LAUNCH(k_glue_resolve, std::min<uint64_t>((c->glue_cap + GLUE_THREADS - 1) / GLUE_THREADS, GLUE_RESOLVE_GRID), GLUE_THREADS, s, gp);
+    uint32_t* const link_p = c->link.p;
 
     uint64_t n_cycles_cut = 0;
     const uint32_t gridS = (NS + GLUE_THREADS - 1) / GLUE_THREADS;
@@ -531,7 +568,7 @@ int glue_impl(cdbg_ctx* c) {
     if (NS) {
         int max_rounds = 2; while ((1ull << (max_rounds - 1)) < NS) ++max_rounds;
         for (int pass = 0; pass < 2; ++pass) {
-            rp.n_states = NS; rp.link = link.p; rp.piece_n = c->piece_n.p;
+            rp.n_states = NS; rp.link = link_p; rp.piece_n = c->piece_n.p;
             rp.st_a = st_a.p; rp.st_b = st_b.p; rp.changed = flag.p;
             CDBG_LAUNCH(k_rank_init, gridS, GLUE_THREADS, s, rp);
             bool converged = false;
@@ -548,7 +585,7 @@ int glue_impl(cdbg_ctx* c) {
             if (pass == 1) return fail(CDBG_E_INTERNAL, "list ranking did not converge after cutting cycles");
             // closed chains: cut each at its smallest piece, then rank again
             HIPCK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), s));
-            CutParams cu{ NS, rp.st_a, link.p, flag.p };
+            CutParams cu{ NS, rp.st_a, link_p, flag.p };
             CDBG_LAUNCH(k_cut_cycles, gridS, GLUE_THREADS, s, cu);
             HIPCK(hipStreamSynchronize(s));
             uint32_t nc = 0; CK(read_u32(flag.p, &nc)); n_cycles_cut += nc;
@@ -563,7 +600,7 @@ int glue_impl(cdbg_ctx* c) {
     HIPCK(hipMemsetAsync(c->cursors.p + 2, 0, 2 * sizeof(uint64_t), s));
     if (NS) {
         HeadParams hp{};
-        hp.n_states = NS; hp.k = c->k; hp.link = link.p; hp.st = fa_st; hp.hinfo = (fa_st == st_a.p) ? st_b.p : st_a.p;
+        hp.n_states = NS; hp.k = c->k; hp.link = link_p; hp.st = fa_st; hp.hinfo = (fa_st == st_a.p) ? st_b.p : st_a.p;
         hp.unitig_off = c->unitig_off.p; hp.unitig_len = c->unitig_len.p; hp.unitig_kc = c->unitig_kc.p;
         hp.unitig_cap = ucap; hp.out_cap = ocap; hp.n_unitigs = c->cursors.p + 2; hp.out_cursor = c->cursors.p + 3; hp.error = c->derr.p;
         CDBG_LAUNCH(k_unitig_heads, (NS + HEADS_PER_WG - 1) / HEADS_PER_WG, GLUE_THREADS, s, hp);
@@ -574,12 +611,13 @@ int glue_impl(cdbg_ctx* c) {
         ep.piece_ab = c->prm.all_abundance_counts ? c->piece_ab.p : nullptr; ep.unitig_ab = c->unitig_ab.p;
         CDBG_LAUNCH(k_emit, (uint32_t)((NP + GLUE_THREADS - 1) / GLUE_THREADS), GLUE_THREADS, s, ep);
     }
-    CK(t.stop(&c->st.ms_glue));
+    float ms_fin = 0; CK(t.stop(&ms_fin));
+    c->st.ms_glue = ms_join + ms_fin;
     CK(check_device_error(c, "glue"));
     uint64_t cur[2]; CK(read_u64(c->cursors.p + 2, cur, 2));
     c->n_unitigs = cur[0]; c->unitig_total = cur[1];
-    uint64_t gs = 0; CK(read_u64(c->dstats.p, &gs));
-    c->st.n_glue_joined = gs; c->st.n_unitigs = c->n_unitigs; c->st.unitig_bases = c->unitig_total; c->st.n_cycles += n_cycles_cut;
+    c->joined = false;
+    c->st.n_glue_joined = c->n_join_local; c->st.n_unitigs = c->n_unitigs; c->st.unitig_bases = c->unitig_total; c->st.n_cycles += n_cycles_cut;
     c->st.ms_total += c->st.ms_glue;
     c->stage = 3;
     return CDBG_OK;
@@ -711,6 +749,35 @@ int cdbg_read_text(cdbg_ctx* c, uint64_t first_byte, uint64_t nbytes, char* out)
 int cdbg_count(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); if (c->stage != 0) return fail(CDBG_E_STATE, "cdbg_count called twice"); DISPATCH_W(count_impl) }
 int cdbg_compact(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(compact_impl) }
 int cdbg_glue(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(glue_impl) }
+// ---- multi-GPU: sharded junction join.  After cdbg_exchange_end every rank holds the union of the glue records;
+// instead of every rank joining all of them, cdbg_glue_join joins this rank's share of the junctions, the caller
+// MAX-all-reduces the int32 link arrays (cdbg_glue_links_export / _import) and cdbg_glue then ranks and emits ----
+int cdbg_glue_join(cdbg_ctx* c, uint64_t* n_ends) {
+    if (!c || !n_ends) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_glue_join needs a compacted, not yet glued context");
+    int rc;
+    switch (c->W) { case 1: rc = glue_join_impl<1>(c, true); break; case 2: rc = glue_join_impl<2>(c, true); break; default: rc = glue_join_impl<4>(c, true); }
+    if (rc == CDBG_OK) *n_ends = 2 * c->n_pieces;
+    return rc;
+}
+int cdbg_glue_links_export(cdbg_ctx* c, void* dst_dev, uint64_t nbytes) {
+    if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
+    if (!c->joined) return fail(CDBG_E_STATE, "cdbg_glue_links_export before cdbg_glue_join");
+    const uint64_t have = 2 * c->n_pieces * sizeof(uint32_t);
+    if (nbytes < have) return fail(CDBG_E_PARAM, "link buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)have);
+    if (have) HIPCK(hipMemcpyAsync(dst_dev, c->link.p, have, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return CDBG_OK;
+}
+int cdbg_glue_links_import(cdbg_ctx* c, const void* src_dev, uint64_t nbytes) {
+    if (!c || !src_dev) return fail(CDBG_E_PARAM, "null argument");
+    if (!c->joined) return fail(CDBG_E_STATE, "cdbg_glue_links_import before cdbg_glue_join");
+    const uint64_t have = 2 * c->n_pieces * sizeof(uint32_t);
+    if (nbytes < have) return fail(CDBG_E_PARAM, "link buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)have);
+    if (have) HIPCK(hipMemcpyAsync(c->link.p, src_dev, have, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return CDBG_OK;
+}
 int cdbg_run(cdbg_ctx* c) { CK(cdbg_count(c)); CK(cdbg_compact(c)); return cdbg_glue(c); }
 int cdbg_link(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(link_impl) }
 int cdbg_num_links(cdbg_ctx* c, uint64_t* n) {
@@ -728,7 +795,7 @@ int cdbg_fetch_links(cdbg_ctx* c, uint64_t* end_off, uint32_t* link_to) {
 int cdbg_reset(cdbg_ctx* c) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
     c->stage = 0; c->st = cdbg_stats_t{};
-    c->n_solid_entries = c->n_pieces = c->n_piece_bases = c->n_unitigs = c->unitig_total = 0; c->linked = false; c->n_links = 0;
+    c->n_solid_entries = c->n_pieces = c->n_piece_bases = c->n_unitigs = c->unitig_total = 0; c->linked = false; c->n_links = 0; c->joined = false;
     return CDBG_OK;                                  // reads and every device buffer stay resident
 }
 

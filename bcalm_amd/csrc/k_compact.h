@@ -369,6 +369,7 @@ __global__ void __launch_bounds__(COMPACT_THREADS) k_compact(CompactParams P) {
 struct GlueBuildParams {
     const uint64_t* glog_keys; const uint32_t* glog_tag; uint64_t n_records;
     uint64_t* glue_keys; uint32_t* glue_state; uint32_t* glue_a; uint32_t* glue_b; uint32_t* glue_conf; uint32_t glue_mask;
+    uint32_t shard_mask, shard_rank;   // multi-GPU sharded join: this rank takes the junctions with (mix32(hash) & mask) == rank; mask 0 = all
 };
 template <int W>
 __global__ void k_glue_build(GlueBuildParams P) {
@@ -379,6 +380,7 @@ __global__ void k_glue_build(GlueBuildParams P) {
         if (tag == GTAG_EMPTY) continue;
         Kmer<W> jc;
         for (int j = 0; j < W; ++j) jc.w[j] = P.glog_keys[i * W + j];
+        if (P.shard_mask && (mix32(jc.hash()) & P.shard_mask) != P.shard_rank) continue;
         if (tag == GTAG_CONFIRM) glue_post_confirm<W>(G, jc);
         else glue_post_end<W>(G, jc, tag);
     }

@@ -5,8 +5,10 @@ Minimizer partitions are sharded over the ranks (cdbg_params.world_size / rank):
 the same resident reads and counts / compacts only the partitions it owns.  What has to cross
 ranks are the glue records: pieces (length, abundance, bases) and the glue log (junction key,
 piece-end id / CONFIRM).  They are gathered with all_gather_into_tensor and merged in rank order
-by libcdbg (cdbg_exchange_*), after which every rank glues the union and holds the complete
-unitig set.  torch only moves bytes here; all compute stays in the HIP library.
+by libcdbg (cdbg_exchange_*).  The junction hash-join over the union is sharded by key hash
+(cdbg_glue_join) and its result, one partner id per piece end, is combined with a MAX all-reduce;
+every rank then ranks the chains and emits, and holds the complete unitig set.  torch only moves
+bytes here; all compute stays in the HIP library.
 """
 from __future__ import annotations
 
@@ -16,7 +18,7 @@ import torch
 _KINDS = [(0, lambda W: 4, 0), (1, lambda W: 8, 0), (2, lambda W: 8, 0), (3, lambda W: 1, 1), (4, lambda W: 8 * W, 2), (5, lambda W: 4, 2)]
 
 
-def exchange_glue(graph, dist, device, W: int):
+def exchange_glue(graph, dist, device, W: int, sharded_join: bool = True):
     """all-gather every rank's pieces + glue log and merge them into `graph` (stage: compacted)."""
     world = dist.get_world_size()
     device = torch.device(device)
@@ -43,5 +45,18 @@ def exchange_glue(graph, dist, device, W: int):
         ptrs = [recv.data_ptr() + r * pad for recv, pad in gathered]
         graph.exchange_add(int(sizes[r][0]), int(sizes[r][1]), int(sizes[r][2]), ptrs)
     graph.exchange_end()
-    return {"pieces": totals[0], "piece_bases": totals[1], "glue_records": totals[2],
+    info = {"pieces": totals[0], "piece_bases": totals[1], "glue_records": totals[2],
             "bytes_gathered": sum(recv.numel() for recv, _ in gathered)}
+    del gathered
+    if sharded_join and world > 1:
+        # every rank hash-joins 1/world of the junctions; the link arrays (one int32 per piece end, -1 = not
+        # joined by this rank) are combined with ONE all-reduce(MAX): each end is set by exactly one rank
+        n = graph.glue_join()
+        links = torch.empty(max(n, 1), dtype=torch.int32, device=device)
+        graph.glue_links_export(links.data_ptr(), n * 4)
+        dist.all_reduce(links, op=dist.ReduceOp.MAX)
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        graph.glue_links_import(links.data_ptr(), n * 4)
+        info["link_bytes_reduced"] = n * 4
+    return info

@@ -110,6 +110,15 @@ int cdbg_exchange_add(cdbg_ctx* ctx, uint64_t n_pieces, uint64_t n_bases, uint64
                       const void* piece_kc, const void* piece_boff, const void* bases, const void* glog_keys,
                       const void* glog_tag);
 int cdbg_exchange_end(cdbg_ctx* ctx);
+/* Sharded junction join (optional, after cdbg_exchange_end): instead of every rank hash-joining ALL glue
+ * records inside cdbg_glue, cdbg_glue_join joins only the junctions whose key hash selects this rank and
+ * leaves link[end] = -1 for the others.  The caller exports the int32 link array (n_ends entries), combines
+ * the arrays of all ranks with an element-wise MAX all-reduce (every end is set by exactly one rank), imports
+ * the result and calls cdbg_glue, which then only ranks the chains and emits.  Without these calls cdbg_glue
+ * performs the whole join itself on every rank. */
+int cdbg_glue_join(cdbg_ctx* ctx, uint64_t* n_ends);
+int cdbg_glue_links_export(cdbg_ctx* ctx, void* dst_dev, uint64_t nbytes);
+int cdbg_glue_links_import(cdbg_ctx* ctx, const void* src_dev, uint64_t nbytes);
 
 /* Results.  Solid k-mers: kmers has (k+1)-byte stride, NUL-terminated ASCII, canonical strand. */
 int cdbg_num_solid(cdbg_ctx* ctx, uint64_t* n);

@@ -48,7 +48,28 @@ def _worker(rank, world, port, q):
     info = cdist.exchange_glue(g, dist, torch.device("cpu"), 1)
     g.glue()
     canon2 = oracle_lib.canonical_set(orc, g.unitigs(), 31); g.close()
-    ok_graph = canon2 == exp2["unitigs"] and info["glue_records"] > 0
+    ok_graph = canon2 == exp2["unitigs"] and info["glue_records"] > 0 and info["link_bytes_reduced"] > 0
+    # (d) the same with the junction join NOT sharded (every rank joins all glue records inside cdbg_glue), and
+    #     a larger graph through the sharded join with repeated steps (reset keeps every buffer)
+    g = api.Graph(31, 2, lib=lib, log2_partitions=6, world_size=world, rank=rank)
+    g.push_text(shared); g.count(); g.compact()
+    cdist.exchange_glue(g, dist, torch.device("cpu"), 1, sharded_join=False)
+    g.glue()
+    ok_graph = ok_graph and oracle_lib.canonical_set(orc, g.unitigs(), 31) == exp2["unitigs"]
+    for _ in range(2):
+        g.reset(); g.count(); g.compact()
+        cdist.exchange_glue(g, dist, torch.device("cpu"), 1)
+        g.glue()
+        ok_graph = ok_graph and oracle_lib.canonical_set(orc, g.unitigs(), 31) == exp2["unitigs"]
+    g.close()
+    big = orc.synth_reads(600, 150, 4)
+    exp3 = orc.run(big, 21, 1)
+    g = api.Graph(21, 1, lib=lib, log2_partitions=8, world_size=world, rank=rank)
+    g.push_text(big); g.count(); g.compact()
+    cdist.exchange_glue(g, dist, torch.device("cpu"), 1)
+    g.glue()
+    ok_graph = ok_graph and oracle_lib.canonical_set(orc, g.unitigs(), 21) == exp3["unitigs"]
+    g.close()
     q.put((rank, ok, float(t.item()), int(n.item()), st["n_distinct"], full == exp2["solid"], len(mine), ok_graph))
     dist.destroy_process_group()
 
@@ -70,3 +91,41 @@ def test_two_rank_gloo():
     assert all(r[5] for r in res), "sharded k-mer sets do not partition the oracle's set"
     assert res[0][6] > 0 and res[1][6] > 0
     assert all(r[7] for r in res), "sharded single-graph mode (all-gather + merge + glue) differs from the oracle"
+
+
+def _worker_graph(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hostsim_lib
+    from bcalm_amd import api, dist as cdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = hostsim_lib.load()
+    orc = oracle_lib.load()
+    ok = True
+    for k, amin, n_reads, cfg in ((31, 2, 200, 3), (55, 1, 120, 4)):
+        text = orc.synth_reads(n_reads, 150, cfg)
+        exp = orc.run(text, k, amin)
+        g = api.Graph(k, amin, lib=lib, log2_partitions=7, world_size=world, rank=rank)
+        g.push_text(text); g.count(); g.compact()
+        cdist.exchange_glue(g, dist, torch.device("cpu"), 1 if k <= 31 else 2)
+        g.glue()
+        ok = ok and oracle_lib.canonical_set(orc, g.unitigs(), k) == exp["unitigs"]
+        g.close()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_four_rank_sharded_join_gloo():
+    """4 ranks: partitions split four ways, glue records all-gathered, junction join sharded by key hash and
+    combined with the MAX all-reduce; one- and two-word k-mers"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_graph, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=400) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res

@@ -137,6 +137,14 @@ def test_exchange_path_single_rank_nccl(oracle, hip):
         g = bcalm_amd.Graph(31, 2, lib=hip, world_size=1, rank=0)
         g.push_text(text); g.count(); g.compact()
         info = cdist.exchange_glue(g, dist, torch.device("cuda", 0), 1)
+        # the sharded-join leg (dist.py runs it for world > 1): join, int32 link array through an RCCL MAX all-reduce
+        n = g.glue_join()
+        links = torch.empty(n, dtype=torch.int32, device="cuda:0")
+        g.glue_links_export(links.data_ptr(), n * 4)
+        dist.all_reduce(links, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        assert int((links >= 0).sum().item()) > 0 and int(links.max().item()) < n
+        g.glue_links_import(links.data_ptr(), n * 4)
         g.glue()
         canon = oracle_lib.canonical_set(oracle, g.unitigs(), 31)
         g.close()
