@@ -31,9 +31,10 @@ constexpr int COMPACT_THREADS = 256;
 constexpr uint32_t PIECE_CHUNK = 1024, BASES_CHUNK = 1u << 16;   // per-workgroup reservations (one device atomic each)
 constexpr uint32_t LNK_DEAD = 0, LNK_INTERNAL = 1, LNK_OPEN = 2;
 constexpr uint32_t LNK_CONF = 1u << 30;                 // this end's junction is 1-1 with a traveller: post CONFIRM
-constexpr uint32_t LNK_POSTED = 1u << 31;               // open piece end; low 31 bits = piece-end id
+constexpr uint32_t LNK_POSTED = 1u << 31;               // open piece end; low bits = 2 * (piece index inside the bucket) + side, LNK_CONF kept
 constexpr uint32_t GLOG_CHUNK = 2048;                   // glue-log records a workgroup reserves per device atomic
 constexpr uint32_t GTAG_EMPTY = 0xFFFFFFFFu, GTAG_CONFIRM = 0xFFFFFFFEu;
+constexpr uint32_t GTAG_CONFBIT = 0x80000000u;          // end record that also confirms its junction (end ids stay below 0x7FFFFFF0)
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr uint32_t END_LEFT = 0, END_RIGHT = 1;
 
@@ -44,10 +45,13 @@ struct GlueTable {
     uint32_t* a; uint32_t* b;      // piece-end id + 1 (0 = empty)
     uint32_t* conf;                // 1 = junction confirmed 1-1 by its owning bucket
 };
+// conf_bit = GTAG_CONFBIT when the end's own bucket confirmed the junction 1-1: the flag rides in the top bit of
+// the a/b word, so an end + confirmation costs the same two device atomics as a plain end
 template <int W>
-CDBG_DEV void glue_post_end(const GlueTable<W>& G, const Kmer<W>& jc, uint32_t end_id) {
+CDBG_DEV void glue_post_end(const GlueTable<W>& G, const Kmer<W>& jc, uint32_t end_id, uint32_t conf_bit) {
     bool nw; const uint32_t s = ktable_insert<W, true>(G.t, jc, nw);
-    if (atomic_cas_u32(&G.a[s], 0u, end_id + 1u) != 0u) atomic_cas_u32(&G.b[s], 0u, end_id + 1u);
+    const uint32_t v = (end_id + 1u) | conf_bit;
+    if (atomic_cas_u32(&G.a[s], 0u, v) != 0u) atomic_cas_u32(&G.b[s], 0u, v);
 }
 template <int W>
 CDBG_DEV void glue_post_confirm(const GlueTable<W>& G, const Kmer<W>& jc) {
@@ -183,7 +187,8 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
                     if (home && yhome) link = LNK_INTERNAL | (ye << 2) | (y << 3);
                     else {
                         // 1-1 junction with a traveller on at least one side: confirm it for glue (once)
-                        if (home || (!yhome && s < y)) { conf = true; atomic_add_u32(&s_stat[1], 1u); }
+                        // (a home end is open and posted anyway: its confirmation rides on that record)
+                        if (home || (!yhome && s < y)) { conf = true; if (!home) atomic_add_u32(&s_stat[1], 1u); }
                         if (home) link = LNK_OPEN;
                     }
                 }
@@ -260,12 +265,13 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
     block_sync<GLOBAL>();
 
     CDBG_PH(4);
-    // ---- glue log, part 1: CONFIRM records (dense over all ends; no device atomics) ----
+    // ---- glue log, part 1: CONFIRM records of junctions whose two k-mers are both travellers here ----
     const uint32_t np = s_np;
     if (np || s_stat[1]) {
         for (uint32_t it = tid; it < 2 * E; it += COMPACT_THREADS) {
             const uint32_t s = slots[it >> 1], end = it & 1u;
-            if (!(lnk[s * 2 + end] & LNK_CONF)) continue;
+            const uint32_t l = lnk[s * 2 + end];
+            if (!(l & LNK_CONF) || (l & 3u) == LNK_OPEN) continue;   // open home ends carry their confirmation themselves
             const uint64_t o = s_lbase + atomic_add_u32(&s_lw, 1u);
             const Kmer<W> jc = canon_junction<W>(orient_out<W>(ktable_key<W>(T, s), end, k), k);
             for (int i = 0; i < W; ++i) P.glog_keys[o * W + i] = jc.w[i];
@@ -298,8 +304,8 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
             // left end of the piece = start terminal (s0, e0); right end = (cur, ex)
             const uint32_t il = s0 * 2 + e0, ir = cur * 2 + ex;
             const bool ol = (lnk[il] & 3u) == LNK_OPEN, orr = (lnk[ir] & 3u) == LNK_OPEN;
-            if (ol) lnk[il] = LNK_POSTED | (uint32_t)(pid * 2 + 0);
-            if (orr) lnk[ir] = LNK_POSTED | (uint32_t)(pid * 2 + 1);
+            if (ol) lnk[il] = LNK_POSTED | (lnk[il] & LNK_CONF) | (li * 2u + 0u);
+            if (orr) lnk[ir] = LNK_POSTED | (lnk[ir] & LNK_CONF) | (li * 2u + 1u);
         }
     }
     block_sync<GLOBAL>();
@@ -336,7 +342,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
             const uint64_t o = s_lbase + atomic_add_u32(&s_lw, 1u);
             const Kmer<W> jc = canon_junction<W>(orient_out<W>(ktable_key<W>(T, s), end, k), k);
             for (int i = 0; i < W; ++i) P.glog_keys[o * W + i] = jc.w[i];
-            P.glog_tag[o] = l & 0x7FFFFFFFu;
+            P.glog_tag[o] = (uint32_t)(s_pbase * 2 + (l & 0x3FFFFFFFu)) | ((l & LNK_CONF) ? GTAG_CONFBIT : 0u);
             ++my_open;
         }
         if (my_open) atomic_add_u32(&s_stat[0], my_open);
@@ -382,7 +388,7 @@ __global__ void k_glue_build(GlueBuildParams P) {
         for (int j = 0; j < W; ++j) jc.w[j] = P.glog_keys[i * W + j];
         if (P.shard_mask && (mix32(jc.hash()) & P.shard_mask) != P.shard_rank) continue;
         if (tag == GTAG_CONFIRM) glue_post_confirm<W>(G, jc);
-        else glue_post_end<W>(G, jc, tag);
+        else glue_post_end<W>(G, jc, tag & ~GTAG_CONFBIT, tag & GTAG_CONFBIT);
     }
 }
 

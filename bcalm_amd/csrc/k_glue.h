@@ -36,13 +36,16 @@ __global__ void k_glue_resolve(GlueResolveParams P) {
     uint32_t joined = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < P.cap; s += stride) {
-        if (!P.conf[s]) continue;
-        const uint32_t a = P.a[s], b = P.b[s];
-        if (a != 0 && b != 0) {
-            P.link[a - 1] = b - 1;
-            P.link[b - 1] = a - 1;
-            ++joined;
-        }
+        // confirmed 1-1 by the owning bucket: a CONFIRM record, or the flag riding on one of the two ends
+        const uint32_t a = P.a[s];
+        if (a == 0) continue;                                // no end posted
+        const uint32_t b = P.b[s];
+        if (b == 0) continue;
+        if (!(((a | b) & 0x80000000u) || P.conf[s])) continue;
+        const uint32_t ea = (a & 0x7FFFFFFFu) - 1u, eb = (b & 0x7FFFFFFFu) - 1u;
+        P.link[ea] = eb;
+        P.link[eb] = ea;
+        ++joined;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) joined += __shfl_xor(joined, d);
@@ -235,7 +238,7 @@ __global__ void k_merge_append(MergeParams P) {
     for (uint64_t i = i0; i < P.n_glog; i += stride) {
         const uint32_t t = P.src_gtag[i];
         // piece-end ids move with their piece: end = 2 * piece + side
-        P.dst_gtag[P.glog_base + i] = (t == GTAG_EMPTY || t == GTAG_CONFIRM) ? t : t + (uint32_t)(2 * P.piece_base);
+        P.dst_gtag[P.glog_base + i] = (t == GTAG_EMPTY || t == GTAG_CONFIRM) ? t : (((t & ~GTAG_CONFBIT) + (uint32_t)(2 * P.piece_base)) | (t & GTAG_CONFBIT));
         for (int j = 0; j < P.W; ++j) P.dst_gkeys[(P.glog_base + i) * P.W + j] = P.src_gkeys[i * P.W + j];
     }
 }
