@@ -79,11 +79,15 @@ constexpr int TS_COUNT_1 = CDBG_TSC1, TS_COUNT_2 = 2048, TS_COUNT_4 = 1024;     
 #ifndef CDBG_TSK1
 #define CDBG_TSK1 1024
 #endif
-constexpr int TS_COMPACT_1 = CDBG_TSK1, TS_COMPACT_2 = 1024, TS_COMPACT_4 = 512;
+// compaction runs in up to two LDS tiers: the bucket table of TSK slots for buckets with <= TSK/2 entries, then a
+// table twice the size for the deferred ones; only buckets beyond that use the HBM-resident tables.  Measured at
+// config 3 / config 4 shapes: W = 2 gains from the small first tier (7 instead of 3 workgroups per CU: 133 -> 84 ms),
+// W = 1 does not (its kernel is VALU bound and the denser table costs probes: 84 -> 96 ms), so W = 1 starts at 1024
+constexpr int TS_COMPACT_1 = CDBG_TSK1, TS_COMPACT_2 = 512, TS_COMPACT_4 = 512;
 template <int W> struct Cfg;
-template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1, NTC = CDBG_NTC1; };
-template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, NTC = 512; };
-template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, NTC = 256; };
+template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1, TSK2 = 2 * TS_COMPACT_1, NTC = CDBG_NTC1; };
+template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, TSK2 = 2 * TS_COMPACT_2, NTC = 512; };
+template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, TSK2 = 2 * TS_COMPACT_4, NTC = 256; };
 
 #ifndef CDBG_PGRID
 #define CDBG_PGRID (256 * 12)
@@ -122,7 +126,7 @@ struct cdbg_ctx {
     DBuf<uint32_t> part_count, spill_part; DBuf<uint64_t> part_off, part_cursor, records, exscan_tmp, spill_recs;
     DBuf<uint64_t> dstats; DBuf<uint32_t> derr;
     DBuf<uint64_t> solid_keys; DBuf<uint32_t> solid_cnt; DBuf<uint64_t> solid_cursor, seg_off; DBuf<uint32_t> seg_n;
-    DBuf<uint32_t> big_list, big_count;
+    DBuf<uint32_t> big_list, big_count, big_list2, big_count2;
     uint64_t n_solid_entries = 0;                // home + traveller solid entries
 
     DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
@@ -462,9 +466,17 @@ int compact_impl(cdbg_ctx* c) {
         c->st.n_launch_compact = NPL;
         HIPCK(hipStreamSynchronize(s));
         uint32_t nbig = 0; CK(read_u32(c->big_count.p, &nbig));
+        if (nbig) {                                          // second LDS tier: the deferred buckets with a table twice the size
+            CK(c->big_list2.alloc(nbig, false)); CK(c->big_count2.alloc(4, true));
+            CompactParams k2 = kp;
+            k2.part_list = c->big_list.p; k2.n_items = nbig; k2.big_list = c->big_list2.p; k2.big_count = c->big_count2.p;
+            CDBG_LAUNCH((k_compact<W, Cfg<W>::TSK2, false>), std::min<uint64_t>(nbig, PERSISTENT_GRID), COMPACT_THREADS, s, k2);
+            HIPCK(hipStreamSynchronize(s));
+            CK(read_u32(c->big_count2.p, &nbig));
+        }
         DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_state, g_cnt, g_lnk, g_aux;
         if (nbig) {                                          // buckets with more entries than fit LDS
-            std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list.p, bl.data(), nbig));
+            std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list2.p, bl.data(), nbig));
             std::sort(bl.begin(), bl.end());
             std::vector<uint64_t> offs(nbig + 1, 0);
             for (uint32_t i = 0; i < nbig; ++i) {
