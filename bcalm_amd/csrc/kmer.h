@@ -25,12 +25,21 @@ CDBG_HD bool base_valid(uint32_t c) {
 
 // reverse the order of the 32 2-bit groups of x (no complement)
 CDBG_HD uint64_t rev2(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // gfx950: two v_bfrev_b32 reverse all 64 bits, one swap of neighbouring bits restores each 2-bit code
+    x = __builtin_bitreverse64(x);
+    return ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+#endif
     x = __builtin_bswap64(x);
     x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
     x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
     return x;
 }
 CDBG_HD uint32_t rev2_32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    x = __builtin_bitreverse32(x);
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+#endif
     x = __builtin_bswap32(x);
     x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
     x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
