@@ -156,6 +156,14 @@ struct RecView {
     uint64_t r[RecFmt<W>::RW];
     // member k-mer t (bases [t, t+k)) as a number: one funnel shift of the RW-word record
     CDBG_DEV Kmer<W> kmer(int t, int k) const {
+        if (W == 1) {                                    // 128-bit record r[1]:r[0], k-mer = bits [sh, sh + 2k), sh >= 16
+            const int sh1 = 128 - 2 * (t + k);
+            const uint64_t lo = sh1 >= 64 ? r[1] : r[0], hi = sh1 >= 64 ? 0ULL : r[1];
+            const int b1 = sh1 & 63;
+            Kmer<W> x1;
+            x1.w[0] = ((lo >> b1) | (b1 ? (hi << (64 - b1)) : 0ULL)) & (~0ULL >> (64 - 2 * k));
+            return x1;
+        }
         const int sh = 64 * RecFmt<W>::RW - 2 * (t + k);
         const int ws = sh >> 6, bs = sh & 63;
         Kmer<W> x;

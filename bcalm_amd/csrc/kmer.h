@@ -149,6 +149,7 @@ struct Kmer {
     // reverse complement of a k-mer
     CDBG_HD Kmer rc(int k) const {
         Kmer r;
+        if (W == 1) { r.w[0] = (~rev2(w[0])) >> (64 - 2 * k); return r; }   // one word: no cross-word funnel (k <= 31)
         for (int i = 0; i < W; ++i) r.w[i] = ~rev2(w[W - 1 - i]);
         r = r.shr(64 * W - 2 * k);
         return r;                               // high bits are already zero after the shift
