@@ -200,18 +200,16 @@ CDBG_HD uint32_t junction_min(const Kmer<W>& j, int k, int m) {
 // rolling pass over its k-m+1 m-mers (canonical m-mers: the strand of x does not matter)
 template <int W>
 CDBG_HD void kmer_junction_mins(const Kmer<W>& x, int k, int m, uint32_t& g_left, uint32_t& g_right) {
-    const uint32_t mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
-    uint32_t fw = 0, rc = 0, gl = 0xFFFFFFFFu, gr = 0xFFFFFFFFu;
-    for (int i = 0; i < k; ++i) {
-        const uint32_t b = x.base(k, i);
-        fw = ((fw << 2) | b) & mmask;
-        rc = (rc >> 2) | ((3u - b) << (2 * (m - 1)));
-        const int j = i - (m - 1);                       // m-mer start completed by base i
-        if (j >= 0) {
-            const uint32_t key = mix32(rc < fw ? rc : fw);
-            if (j <= k - 1 - m) gl = key < gl ? key : gl;
-            if (j >= 1) gr = key < gr ? key : gr;
-        }
+    // every m-mer and its reverse complement are bit fields of x and of rc(x): the reverse complement of the
+    // m-mer at base j is the m-mer of rc(x) at base k-m-j (no per-base rolling, one rc() for the whole k-mer)
+    const Kmer<W> r = x.rc(k);
+    uint32_t gl = 0xFFFFFFFFu, gr = 0xFFFFFFFFu;
+    const int last = k - m;                                // m-mer starts 0 .. k-m; left junction owns 0 .. k-m-1, right 1 .. k-m
+    for (int j = 0; j <= last; ++j) {
+        const uint32_t fw = mmer_at<W>(x, k, j, m), rc = mmer_at<W>(r, k, last - j, m);
+        const uint32_t key = mix32(rc < fw ? rc : fw);
+        if (j < last) gl = key < gl ? key : gl;
+        if (j >= 1) gr = key < gr ? key : gr;
     }
     g_left = gl; g_right = gr;
 }
