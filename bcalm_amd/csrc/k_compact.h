@@ -170,32 +170,44 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
     CDBG_PH(1);
 
     // ---- classify both ends of every entry ----
+    // Step 1: every end whose junction this bucket owns probes its successors ONCE and notes its unique partner
+    // end (or none).  Step 2: a junction is 1-in/1-out exactly when two ends name each other, so the second
+    // round of probes (from the partner back) is replaced by one LDS read.  Final link words are staged in
+    // the piece-length/offset arrays (unused until walk 1) because step 2 still reads the notes in lnk[].
+    constexpr uint32_t NOTE_NONE = 0xFFFFFFFFu, NOTE_FOREIGN = 0xFFFFFFFEu;
+    uint32_t* const fin = pn;                                // 2E <= cap words (pn and pb are contiguous)
+    for (uint32_t it = tid; it < 2 * E; it += COMPACT_THREADS) {
+        const uint32_t s = slots[it >> 1], end = it & 1u, idx = s * 2 + end;
+        uint32_t note = NOTE_FOREIGN;                        // junction owned elsewhere: glue decides
+        if ((vis[s] >> (2 + end)) & 1u) {
+            const Kmer<W> u = orient_out<W>(ktable_key<W>(T, s), end, k);
+            uint32_t y = 0, ye = 0;
+            note = (probe_succ<W>(T, u, k, y, ye) == 1 && y != s) ? (y * 2 + ye) : NOTE_NONE;
+        }
+        lnk[idx] = note;
+    }
+    block_sync<GLOBAL>();
     for (uint32_t it = tid; it < 2 * E; it += COMPACT_THREADS) {
         const uint32_t s = slots[it >> 1], end = it & 1u, idx = s * 2 + end;
         const bool home = !(cnt[s] & TRAV_FLAG);
-        const Kmer<W> x = ktable_key<W>(T, s);
-        const Kmer<W> u = orient_out<W>(x, end, k);
+        const uint32_t note = lnk[idx];
         uint32_t link = LNK_DEAD; bool conf = false;
-        if (!((vis[s] >> (2 + end)) & 1u)) {
-            link = LNK_OPEN;                             // junction owned elsewhere: glue decides
-        } else {
-            uint32_t y = 0, ye = 0, z = 0, ze = 0;
-            if (probe_succ<W>(T, u, k, y, ye) == 1 && y != s) {
-                const Kmer<W> uy = orient_out<W>(ktable_key<W>(T, y), ye, k);   // leave y back through the entering end
-                if (probe_succ<W>(T, uy, k, z, ze) == 1) {
-                    const bool yhome = !(cnt[y] & TRAV_FLAG);
-                    if (home && yhome) link = LNK_INTERNAL | (ye << 2) | (y << 3);
-                    else {
-                        // 1-1 junction with a traveller on at least one side: confirm it for glue (once)
-                        // (a home end is open and posted anyway: its confirmation rides on that record)
-                        if (home || (!yhome && s < y)) { conf = true; if (!home) atomic_add_u32(&s_stat[1], 1u); }
-                        if (home) link = LNK_OPEN;
-                    }
-                }
+        if (note == NOTE_FOREIGN) link = LNK_OPEN;
+        else if (note != NOTE_NONE && lnk[note] == idx) {    // the partner end has exactly one successor too: this one
+            const uint32_t y = note >> 1, ye = note & 1u;
+            const bool yhome = !(cnt[y] & TRAV_FLAG);
+            if (home && yhome) link = LNK_INTERNAL | (ye << 2) | (y << 3);
+            else {
+                // 1-1 junction with a traveller on at least one side: confirm it for glue (once)
+                // (a home end is open and posted anyway: its confirmation rides on that record)
+                if (home || (!yhome && s < y)) { conf = true; if (!home) atomic_add_u32(&s_stat[1], 1u); }
+                if (home) link = LNK_OPEN;
             }
         }
-        lnk[idx] = (home ? link : LNK_DEAD) | (conf ? LNK_CONF : 0u);
+        fin[it] = (home ? link : LNK_DEAD) | (conf ? LNK_CONF : 0u);
     }
+    block_sync<GLOBAL>();
+    for (uint32_t it = tid; it < 2 * E; it += COMPACT_THREADS) lnk[slots[it >> 1] * 2 + (it & 1u)] = fin[it];
     block_sync<GLOBAL>();
     CDBG_PH(2);
 
@@ -353,7 +365,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
 }
 
 template <int W, int TS, bool GLOBAL>
-__global__ void __launch_bounds__(COMPACT_THREADS) k_compact(CompactParams P) {
+__global__ void __launch_bounds__(COMPACT_THREADS, (W == 2 && TS <= 512 && !GLOBAL) ? 6 : 1) k_compact(CompactParams P) {   // two-word small tier: <= 80 VGPRs so that 6 workgroups per CU fit (the others are LDS-limited below that)
     uint64_t acc[4] = {0, 0, 0, 0};
     uint64_t pc_base = 0, bc_base = 0, lc_base = 0; uint32_t pc_left = 0, bc_left = 0, lc_left = 0;
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_prev = 0;
