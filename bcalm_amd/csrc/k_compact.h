@@ -115,7 +115,6 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
                              uint64_t& pc_base, uint32_t& pc_left, uint64_t& bc_base, uint32_t& bc_left,
                              uint64_t& lc_base, uint32_t& lc_left, uint64_t (&ph)[8], uint64_t& t_prev) {
     CDBG_SHARED uint64_t l_keys[GLOBAL ? 1 : TS * W];
-    CDBG_SHARED uint32_t l_state[(GLOBAL || W == 1) ? 1 : TS];
     CDBG_SHARED uint32_t l_cnt[GLOBAL ? 1 : TS];
     CDBG_SHARED uint32_t l_lnk[GLOBAL ? 1 : 2 * TS];
     // aux words: [0, cap/4) visited bytes | piece starts | entry slots | piece lengths | piece base offsets (cap/2 each)
@@ -141,7 +140,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
             if (tid == 0) { const uint32_t i = atomic_add_u32(P.big_count, 1u); P.big_list[i] = p; }
             return;
         }
-        cap = TS; T.keys = l_keys; T.state = l_state; cnt = l_cnt; lnk = l_lnk; vis = reinterpret_cast<uint8_t*>(l_aux); pdesc = l_aux + TS / 4;
+        cap = TS; T.keys = l_keys; T.state = nullptr; cnt = l_cnt; lnk = l_lnk; vis = reinterpret_cast<uint8_t*>(l_aux); pdesc = l_aux + TS / 4;
     }
     T.mask = cap - 1;
     slots = pdesc + cap / 2; pn = slots + cap / 2; pb = pn + cap / 2;   // E <= cap/2 entries, <= cap/2 pieces

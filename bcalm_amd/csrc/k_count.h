@@ -27,7 +27,10 @@ namespace cdbg {
 // measured 13 % faster than 64-record batches at 2 workgroups per CU.
 constexpr uint32_t COUNT_CHUNK = 32768;                // solid entries a workgroup reserves per device atomic
 constexpr uint32_t TRAV_FLAG = 0x80000000u;          // in a count word: this entry is a traveller copy
-constexpr uint32_t ST_EMPTY = 0u, ST_BUSY = 1u;      // slot states for multi-word keys (W > 1)
+// Multi-word keys (W > 1) are claimed through their TOP word: a k-mer or (k-1)-mer of an odd k <= 127 leaves
+// the two top bits of that word clear, so all-ones can mean "empty" and bit 63 "claimed, lower words not written
+// yet".  One 64-bit compare-and-swap per probe, no separate state array.
+constexpr uint64_t KEY_EMPTY = ~0ULL, KEY_PENDING = 1ULL << 63;
 
 // ---------------------------------------------------------------------------
 // Open-address table of W-word keys.  W == 1: the key word itself is claimed with
@@ -38,20 +41,18 @@ constexpr uint32_t ST_EMPTY = 0u, ST_BUSY = 1u;      // slot states for multi-wo
 template <int W>
 struct KTable {
     uint64_t* keys;      // [cap * W]
-    uint32_t* state;     // [cap]   (W > 1 only)
+    uint32_t* state;     // unused (kept so that aggregate initialisers of the callers stay as they are)
     uint32_t mask;       // cap - 1
 };
 
 template <int W>
 CDBG_DEV void ktable_clear(const KTable<W>& t, int tid, int nthreads) {
     const uint32_t cap = t.mask + 1;
-    if (W == 1) { for (uint32_t i = tid; i < cap; i += nthreads) t.keys[i] = ~0ULL; }
-    else { for (uint32_t i = tid; i < cap; i += nthreads) t.state[i] = ST_EMPTY; }
+    for (uint32_t i = tid; i < cap; i += nthreads) t.keys[(uint64_t)i * W + (W - 1)] = KEY_EMPTY;   // the claim word only
 }
 template <int W>
 CDBG_DEV bool ktable_used(const KTable<W>& t, uint32_t s) {
-    if (W == 1) return t.keys[s] != ~0ULL;
-    return t.state[s] > ST_BUSY;
+    return t.keys[(uint64_t)s * W + (W - 1)] != KEY_EMPTY;
 }
 template <int W>
 CDBG_DEV Kmer<W> ktable_key(const KTable<W>& t, uint32_t s) {
@@ -90,19 +91,20 @@ CDBG_DEV uint32_t ktable_insert(const KTable<W>& t, const Kmer<W>& key, bool& is
         is_new = old == ~0ULL;
         return hit ? s : 0xFFFFFFFFu;
     } else {
-        const uint32_t tag = (h >> 1) | 0x80000000u;
+        const uint64_t top = key.w[W - 1];
         for (uint32_t probes = 0; probes < max_probe;) {
-            const uint32_t st = atomic_cas_u32(&t.state[s], ST_EMPTY, ST_BUSY);
-            if (st == ST_EMPTY) {
-                for (int i = 0; i < W; ++i) t.keys[(uint64_t)s * W + i] = key.w[i];
+            uint64_t* const claim = &t.keys[(uint64_t)s * W + (W - 1)];
+            const uint64_t old = atomic_cas_u64(claim, KEY_EMPTY, top | KEY_PENDING);
+            if (old == KEY_EMPTY) {                          // claimed: write the lower words, then publish the top word
+                for (int i = 0; i < W - 1; ++i) t.keys[(uint64_t)s * W + i] = key.w[i];
                 if (GLOBAL) __threadfence(); else __threadfence_block();
-                atomicExch(&t.state[s], tag);
+                atomic_exch_u64(claim, top);
                 is_new = true; return s;
             }
-            if (st == ST_BUSY) { CDBG_SPIN_YIELD(); continue; }
-            if (st == tag) {
+            if ((old & ~KEY_PENDING) == top) {
+                if (old & KEY_PENDING) { CDBG_SPIN_YIELD(); continue; }   // another lane is writing this slot: look again
                 bool eq = true;
-                for (int i = 0; i < W; ++i) eq &= ((GLOBAL ? ld_agent_u64(&t.keys[(uint64_t)s * W + i]) : t.keys[(uint64_t)s * W + i]) == key.w[i]);
+                for (int i = 0; i < W - 1; ++i) eq &= ((GLOBAL ? ld_agent_u64(&t.keys[(uint64_t)s * W + i]) : t.keys[(uint64_t)s * W + i]) == key.w[i]);
                 if (eq) return s;
             }
             s = (s + 1) & t.mask; ++probes;
@@ -126,17 +128,17 @@ CDBG_DEV uint32_t ktable_find(const KTable<W>& t, const Kmer<W>& key) {
         } while (!stop);
         return v == key.w[0] ? s : 0xFFFFFFFFu;
     } else {
-        const uint32_t tag = (h >> 1) | 0x80000000u;
+        const uint64_t top = key.w[W - 1];
         bool found = false, stop;
 #pragma clang loop unroll(disable)
         do {
-            const uint32_t st = t.state[s];
-            if (st == tag) {
+            const uint64_t v = t.keys[(uint64_t)s * W + (W - 1)];
+            if (v == top) {
                 bool eq = true;
-                for (int i = 0; i < W; ++i) eq &= (t.keys[(uint64_t)s * W + i] == key.w[i]);
+                for (int i = 0; i < W - 1; ++i) eq &= (t.keys[(uint64_t)s * W + i] == key.w[i]);
                 found = eq;
             }
-            stop = found | (st == ST_EMPTY);
+            stop = found | (v == KEY_EMPTY);
             s = stop ? s : ((s + 1) & t.mask);
         } while (!stop);
         return found ? s : 0xFFFFFFFFu;
@@ -236,7 +238,6 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
     constexpr int RW = RecFmt<W>::RW;
     constexpr int NW = NT / 64;
     CDBG_SHARED uint64_t l_keys[GLOBAL ? 1 : TS * W];
-    CDBG_SHARED uint32_t l_state[(GLOBAL || W == 1) ? 1 : TS];
     CDBG_SHARED uint32_t l_cnt[GLOBAL ? 1 : TS];
     // slots that received a new key, in insertion order: the single-pass sweep visits (and resets) only these
     // instead of all TS slots, most of which are empty at the usual ~20-45 % load
@@ -263,7 +264,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
         const uint64_t o0 = P.big_off[item]; cap = (uint32_t)(P.big_off[item + 1] - o0);
         T.keys = P.g_keys + o0 * W; T.state = P.g_state + o0; cnt = P.g_cnt + o0;
     } else {
-        cap = TS; T.keys = l_keys; T.state = l_state; cnt = l_cnt;
+        cap = TS; T.keys = l_keys; T.state = nullptr; cnt = l_cnt;
     }
     T.mask = cap - 1;
     const uint32_t maxfill = cap - cap / 4;                       // load limit; inserts also give up after 64 probes
@@ -380,7 +381,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                             }
                         }
                         if (by_list) {                             // hand the slot back empty
-                            if (W == 1) T.keys[s] = ~0ULL; else T.state[s] = ST_EMPTY;
+                            T.keys[(uint64_t)s * W + (W - 1)] = KEY_EMPTY;
                             cnt[s] = 0;
                         }
                     }
