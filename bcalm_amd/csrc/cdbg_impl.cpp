@@ -389,7 +389,7 @@ int count_impl(cdbg_ctx* c) {
             const uint64_t occ = nrec_p * nmax;
             offs[i + 1] = offs[i] + pow2_at_least(2 * occ + 4 * 256);
         }
-        CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_state.alloc(offs[nbig], false)); CK(g_cnt.alloc(offs[nbig], false));
+        CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_state.alloc(1, false)); CK(g_cnt.alloc(offs[nbig], false));
         CK(big_off.alloc(nbig + 1, false));
         HIPCK(hipMemcpy(big_off.p, offs.data(), (nbig + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -425,7 +425,7 @@ int compact_impl(cdbg_ctx* c) {
     // glue table: at most one junction per solid traveller entry
     c->glue_cap = (uint32_t)pow2_at_least(2 * c->st.n_solid_travellers + 64);
     CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false));
-    CK(c->glue_state.alloc(c->glue_cap, false));
+    CK(c->glue_state.alloc(1, false));
     CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
     CK(c->cursors.alloc(8, false));
     // glue log: <= 2 open ends + 1 confirm per junction, one junction per solid traveller at most
@@ -443,7 +443,6 @@ int compact_impl(cdbg_ctx* c) {
         HIPCK(hipMemsetAsync(c->cursors.p, 0, 8 * sizeof(uint64_t), s));
         HIPCK(hipMemsetAsync(c->glog_tag.p, 0xFF, c->glog_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), s));
-        HIPCK(hipMemsetAsync(c->glue_state.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->glue_b.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->glue_conf.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
@@ -483,7 +482,7 @@ int compact_impl(cdbg_ctx* c) {
                 uint32_t e = 0; CK(read_u32(c->seg_n.p + bl[i], &e));
                 offs[i + 1] = offs[i] + pow2_at_least(2 * (uint64_t)e + 16);
             }
-            CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_state.alloc(offs[nbig], false)); CK(g_cnt.alloc(offs[nbig], false));
+            CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_state.alloc(1, false)); CK(g_cnt.alloc(offs[nbig], false));
             CK(g_lnk.alloc(2 * offs[nbig], false)); CK(g_aux.alloc(3 * offs[nbig], false));
             CK(big_off.alloc(nbig + 1, false));
             HIPCK(hipMemcpy(big_off.p, offs.data(), (nbig + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -533,10 +532,9 @@ int glue_join_impl(cdbg_ctx* c, bool sharded) {
     const uint32_t world = sharded ? (uint32_t)c->prm.world_size : 1u;
     if (world > 1) {                                         // a table for this rank's share of the junctions
         c->glue_cap = (uint32_t)pow2_at_least((c->n_glog + c->n_glog / 4) / world + (c->n_glog >> 6) + 1024);
-        CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false)); CK(c->glue_state.alloc(c->glue_cap, false));
+        CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false)); CK(c->glue_state.alloc(1, false));
         CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
         HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), s));
-        HIPCK(hipMemsetAsync(c->glue_state.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->glue_b.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->glue_conf.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
@@ -643,7 +641,7 @@ int link_impl(cdbg_ctx* c) {
     if (NE >= 0x3FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many unitigs for 30-bit end slots");
     const uint32_t cap = (uint32_t)pow2_at_least(4 * U + 64);
     DBuf<uint64_t> lk_keys; DBuf<uint32_t> lk_state, lk_cnt, lk_ends, end_slot, deg;
-    CK(lk_keys.alloc((uint64_t)cap * W, false)); CK(lk_state.alloc(cap, true)); CK(lk_cnt.alloc((uint64_t)cap * 2, true));
+    CK(lk_keys.alloc((uint64_t)cap * W, false)); CK(lk_state.alloc(1, true)); CK(lk_cnt.alloc((uint64_t)cap * 2, true));
     CK(lk_ends.alloc((uint64_t)cap * 8, false)); CK(end_slot.alloc(NE, false)); CK(deg.alloc(NE, false));
     HIPCK(hipMemsetAsync(lk_keys.p, 0xFF, (uint64_t)cap * W * sizeof(uint64_t), s));
     CK(c->link_off.alloc(NE + 1, true));
@@ -931,10 +929,9 @@ int cdbg_exchange_end(cdbg_ctx* c) {
     // junction, so 1.25 x records keeps the load factor below one half in practice and below 0.8 always)
     const int W = c->W;
     c->glue_cap = (uint32_t)pow2_at_least(c->n_glog + c->n_glog / 4 + 64);
-    CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false)); CK(c->glue_state.alloc(c->glue_cap, false));
+    CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false)); CK(c->glue_state.alloc(1, false));
     CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
     HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), c->stream));
-    HIPCK(hipMemsetAsync(c->glue_state.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), c->stream));
     HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), c->stream));
     HIPCK(hipMemsetAsync(c->glue_b.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), c->stream));
     HIPCK(hipMemsetAsync(c->glue_conf.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), c->stream));
