@@ -26,6 +26,11 @@
 // wave-level rendezvous between an LDS write and reads of it by other lanes of the SAME wave:
 // the hardware executes a wave's LDS instructions in order, so only the compiler needs a barrier
 #define CDBG_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+// Pins a 64-bit value in registers as an opaque SSA value.  A select chain over the elements of a small register
+// array ("element idx without a runtime index") is otherwise folded back by the optimiser into a load with a
+// selected ADDRESS, which forces the whole array into scratch memory (seen in the ISA of the two- and four-word
+// kernels as scratch_store/scratch_load in the inner loops).
+#define CDBG_PIN64(x) asm volatile("" : "+v"(x))
 #endif
 
 namespace cdbg {

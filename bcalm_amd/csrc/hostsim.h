@@ -29,6 +29,7 @@
 #define CDBG_SHARED static
 #define CDBG_SPIN_YIELD() ::hostsim::spin_yield()
 #define CDBG_WAVE_SYNC() ::hostsim::wave_rendezvous(0)
+#define CDBG_PIN64(x) do { } while (0)
 #define CDBG_LAUNCH(kern, grid, block, stream, ...) \
     ::hostsim::launch((unsigned)(grid), (unsigned)(block), [=]() { kern(__VA_ARGS__); })
 

@@ -149,8 +149,9 @@ CDBG_DEV uint32_t ktable_find(const KTable<W>& t, const Kmer<W>& key) {
 template <int N>
 CDBG_DEV uint64_t sel_word(const uint64_t (&r)[N], int idx) {      // r[idx] without dynamic register indexing
     uint64_t w = r[0];
+    CDBG_PIN64(w);
 #pragma unroll
-    for (int j = 1; j < N; ++j) w = (idx == j) ? r[j] : w;
+    for (int j = 1; j < N; ++j) { uint64_t e = r[j]; CDBG_PIN64(e); w = (idx == j) ? e : w; }
     return idx < N ? w : 0ULL;
 }
 template <int W>
@@ -184,8 +185,9 @@ struct RecView {
         const int pos = 64 * RecFmt<W>::RW - 2 * (i + 1);
         const int wi = pos >> 6;
         uint64_t w = r[0];                               // select chain: keeps r[] in registers (no scratch)
+        CDBG_PIN64(w);
 #pragma unroll
-        for (int j = 1; j < RecFmt<W>::RW; ++j) w = (wi == j) ? r[j] : w;
+        for (int j = 1; j < RecFmt<W>::RW; ++j) { uint64_t e = r[j]; CDBG_PIN64(e); w = (wi == j) ? e : w; }
         return (uint32_t)(w >> (pos & 63)) & 3u;
     }
 };

@@ -14,6 +14,12 @@
 
 #include "devrt.h"
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CDBG_PIN(x) CDBG_PIN64(x)
+#else
+#define CDBG_PIN(x) do { } while (0)
+#endif
+
 namespace cdbg {
 
 // ASCII -> 2-bit code for ACGTacgt; validity must be checked separately.
@@ -93,7 +99,7 @@ struct Kmer {
     CDBG_HD uint64_t word_z(int idx) const {
         uint64_t r = 0;
 #pragma unroll
-        for (int j = 0; j < W; ++j) r = (idx == j) ? w[j] : r;
+        for (int j = 0; j < W; ++j) { uint64_t e = w[j]; if (W > 1) CDBG_PIN(e); r = (idx == j) ? e : r; }
         return r;
     }
     // logical shifts of the whole W-word integer by s bits, 0 <= s < 64*W
@@ -126,8 +132,9 @@ struct Kmer {
     // word `idx` without dynamic indexing of the register array (a runtime index sends w[] to scratch)
     CDBG_HD uint64_t word(int idx) const {
         uint64_t r = w[0];
+        if (W > 1) CDBG_PIN(r);
 #pragma unroll
-        for (int j = 1; j < W; ++j) r = (idx == j) ? w[j] : r;
+        for (int j = 1; j < W; ++j) { uint64_t e = w[j]; CDBG_PIN(e); r = (idx == j) ? e : r; }
         return r;
     }
     CDBG_HD void or_word(int idx, uint64_t v) {
