@@ -120,7 +120,13 @@ struct cdbg_ctx {
     int stage = 0;                               // 0 input, 1 counted, 2 compacted, 3 glued
     cdbg_stats_t st{};
 
-    std::vector<char> host_text;                 // pushed reads awaiting upload
+    // Ingest: pushed bytes go through two pinned staging buffers and are copied to the device asynchronously on
+    // their own stream while the caller parses the next chunk; the device text grows by doubling.
+    static constexpr uint64_t STAGE_BYTES = 32ull << 20;
+    uint8_t* pin[2] = { nullptr, nullptr }; hipEvent_t pin_ev[2] = {}; bool pin_busy[2] = { false, false };
+    int pin_cur = 0; uint64_t pin_fill = 0; hipStream_t copy_stream{};
+    uint64_t n_dev = 0;                          // bytes of text already on (or on their way to) the device
+    bool reads_final = false;                    // text complete, padded, nbytes set
     DBuf<uint8_t> reads; uint64_t nbytes = 0, nbytes_padded = 0;
 
     DBuf<uint32_t> part_count, spill_part; DBuf<uint64_t> part_off, part_cursor, records, exscan_tmp, spill_recs;
@@ -148,16 +154,69 @@ struct cdbg_ctx {
 
 namespace {
 
+// ---- streaming ingest ----
+int ingest_init(cdbg_ctx* c) {
+    if (c->pin[0]) return CDBG_OK;
+    HIPCK(hipStreamCreate(&c->copy_stream));
+    for (int i = 0; i < 2; ++i) {
+        if (hipHostMalloc((void**)&c->pin[i], cdbg_ctx::STAGE_BYTES) != hipSuccess) return fail(CDBG_E_NOMEM, "pinned staging buffer (%llu bytes)", (unsigned long long)cdbg_ctx::STAGE_BYTES);
+        HIPCK(hipEventCreate(&c->pin_ev[i]));
+    }
+    return CDBG_OK;
+}
+void ingest_release(cdbg_ctx* c) {
+    for (int i = 0; i < 2; ++i) {
+        if (c->pin[i]) { (void)hipHostFree(c->pin[i]); (void)hipEventDestroy(c->pin_ev[i]); c->pin[i] = nullptr; }
+    }
+    if (c->copy_stream) { (void)hipStreamDestroy(c->copy_stream); c->copy_stream = hipStream_t{}; }
+}
+// device text with room for `need` bytes: grows by doubling (device-to-device copy of what is already there)
+int ingest_reserve(cdbg_ctx* c, uint64_t need) {
+    if (c->reads.p && c->reads.cap >= need) return CDBG_OK;
+    uint64_t cap = std::max<uint64_t>(c->reads.cap * 2, 256ull << 20);
+    while (cap < need) cap *= 2;
+    DBuf<uint8_t> bigger;
+    CK(bigger.alloc(cap, false));
+    HIPCK(hipStreamSynchronize(c->copy_stream));             // copies into the old buffer have landed
+    if (c->n_dev) HIPCK(hipMemcpy(bigger.p, c->reads.p, c->n_dev, hipMemcpyDeviceToDevice));
+    c->reads.swap(bigger);
+    return CDBG_OK;
+}
+// send the current staging buffer on its way and switch to the other one
+int ingest_flush(cdbg_ctx* c) {
+    if (!c->pin_fill) return CDBG_OK;
+    CK(ingest_reserve(c, c->n_dev + c->pin_fill));
+    const int b = c->pin_cur;
+    HIPCK(hipMemcpyAsync(c->reads.p + c->n_dev, c->pin[b], c->pin_fill, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCK(hipEventRecord(c->pin_ev[b], c->copy_stream));
+    c->pin_busy[b] = true;
+    c->n_dev += c->pin_fill; c->pin_fill = 0;
+    c->pin_cur = b ^ 1;
+    if (c->pin_busy[b ^ 1]) { HIPCK(hipEventSynchronize(c->pin_ev[b ^ 1])); c->pin_busy[b ^ 1] = false; }   // its copy must be done before reuse
+    return CDBG_OK;
+}
+int ingest_append(cdbg_ctx* c, const char* src, uint64_t n) {
+    CK(ingest_init(c));
+    while (n) {
+        const uint64_t room = cdbg_ctx::STAGE_BYTES - c->pin_fill, take = std::min(room, n);
+        memcpy(c->pin[c->pin_cur] + c->pin_fill, src, take);
+        c->pin_fill += take; src += take; n -= take;
+        if (c->pin_fill == cdbg_ctx::STAGE_BYTES) CK(ingest_flush(c));
+    }
+    return CDBG_OK;
+}
+// text complete: last partial buffer out, all copies done, tail padded with separators
 int upload_pending(cdbg_ctx* c) {
-    if (c->host_text.empty()) return CDBG_OK;
-    if (c->reads.p) return fail(CDBG_E_STATE, "reads already resident: push all reads before the first stage");
-    const uint64_t n = c->host_text.size();
+    if (c->reads_final) return CDBG_OK;
+    if (!c->pin[0] || (c->n_dev == 0 && c->pin_fill == 0)) return CDBG_OK;     // nothing was pushed
+    CK(ingest_flush(c));
+    const uint64_t n = c->n_dev;
     const uint64_t np = ((n + 15) / 16) * 16 + 256;
-    CK(c->reads.alloc(np, false));
-    HIPCK(hipMemset(c->reads.p, '\n', np));
-    HIPCK(hipMemcpy(c->reads.p, c->host_text.data(), n, hipMemcpyHostToDevice));
-    c->nbytes = n; c->nbytes_padded = np;
-    std::vector<char>().swap(c->host_text);
+    CK(ingest_reserve(c, np));
+    HIPCK(hipStreamSynchronize(c->copy_stream));
+    HIPCK(hipMemset(c->reads.p + n, '\n', np - n));
+    c->nbytes = n; c->nbytes_padded = np; c->reads_final = true;
+    ingest_release(c);
     return CDBG_OK;
 }
 
@@ -706,30 +765,31 @@ int cdbg_create(const cdbg_params* p, cdbg_ctx** out) {
 
 void cdbg_destroy(cdbg_ctx* c) {
     if (!c) return;
+    ingest_release(c);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 int cdbg_push_reads(cdbg_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads) {
     if (!c || !bases || !offsets) return fail(CDBG_E_PARAM, "null argument");
-    if (c->stage != 0 || c->reads.p) return fail(CDBG_E_STATE, "reads must be pushed before the first stage");
+    if (c->stage != 0 || c->reads_final) return fail(CDBG_E_STATE, "reads must be pushed before the first stage");
     for (uint64_t i = 0; i < n_reads; ++i) {
         if (offsets[i + 1] < offsets[i]) return fail(CDBG_E_PARAM, "offsets not monotone at read %llu", (unsigned long long)i);
-        c->host_text.insert(c->host_text.end(), bases + offsets[i], bases + offsets[i + 1]);
-        c->host_text.push_back('\n');
+        CK(ingest_append(c, bases + offsets[i], offsets[i + 1] - offsets[i]));
+        CK(ingest_append(c, "\n", 1));
     }
     return CDBG_OK;
 }
 int cdbg_push_text(cdbg_ctx* c, const char* text, uint64_t nbytes) {
     if (!c || (!text && nbytes)) return fail(CDBG_E_PARAM, "null argument");
-    if (c->stage != 0 || c->reads.p) return fail(CDBG_E_STATE, "reads must be pushed before the first stage");
-    c->host_text.insert(c->host_text.end(), text, text + nbytes);
-    c->host_text.push_back('\n');
+    if (c->stage != 0 || c->reads_final) return fail(CDBG_E_STATE, "reads must be pushed before the first stage");
+    CK(ingest_append(c, text, nbytes));
+    CK(ingest_append(c, "\n", 1));
     return CDBG_OK;
 }
 int cdbg_generate_reads(cdbg_ctx* c, uint64_t first_read, uint64_t n_reads, uint64_t total_reads, uint64_t read_len, int cfg) {
     if (!c) return fail(CDBG_E_PARAM, "null argument");
-    if (c->stage != 0 || c->reads.p || !c->host_text.empty()) return fail(CDBG_E_STATE, "reads already present");
+    if (c->stage != 0 || c->reads_final || c->n_dev || c->pin_fill) return fail(CDBG_E_STATE, "reads already present");
     if (!n_reads || !read_len || total_reads < n_reads) return fail(CDBG_E_PARAM, "bad synthetic read set");
     const uint64_t n = n_reads * (read_len + 1);
     const uint64_t np = ((n + 15) / 16) * 16 + 256;
@@ -739,7 +799,7 @@ int cdbg_generate_reads(cdbg_ctx* c, uint64_t first_read, uint64_t n_reads, uint
     const uint64_t blocks = std::min<uint64_t>((n + 255) / 256, MAX_GRID);
     CDBG_LAUNCH(k_gen_reads, blocks, 256, c->stream, g);
     HIPCK(hipStreamSynchronize(c->stream));
-    c->nbytes = n; c->nbytes_padded = np;
+    c->nbytes = n; c->nbytes_padded = np; c->reads_final = true;
     return CDBG_OK;
 }
 int cdbg_read_text(cdbg_ctx* c, uint64_t first_byte, uint64_t nbytes, char* out) {

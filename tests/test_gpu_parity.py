@@ -194,3 +194,9 @@ def test_config2_genome_shape(oracle, hip):
     assert st["n_distinct"] == exp["stats"]["distinct"] == st["n_solid"]
     assert canon == exp["unitigs"]
     assert exp["stats"]["unitigs"] > 50                  # the repeats really branch the graph
+
+
+def test_streaming_ingest_roundtrip_gpu(hip):
+    """pinned double-buffered H2D ingest on the copy stream (several staging buffers, growing device text)"""
+    from test_hostsim_pipeline import _ingest_roundtrip
+    _ingest_roundtrip(hip)

@@ -128,3 +128,27 @@ def test_scan_window_variants(oracle, sim, k, m):
         reads.append(r)
     text = "\n".join(reads) + "\n"
     assert_parity(oracle, sim, text, k, rng.choice([1, 2]), log2_partitions=rng.choice([0, 4, 7]), minimizer_size=m)
+
+
+def _ingest_roundtrip(lib):
+    """push ~75 MB in uneven pieces (several 32 MB staging buffers, device text growing by doubling) and read it back"""
+    from bcalm_amd import api
+    rng = random.Random(99)
+    block = "".join(rng.choice("ACGT") for _ in range(1 << 16))
+    g = api.Graph(31, 1, lib=lib)
+    expect = []
+    total = 0
+    while total < 75 * (1 << 20):
+        n = rng.choice([1, 7, 150, 4096, 65536, 3 * 65536 + 11, 40 * 65536])
+        piece = (block * (n // len(block) + 1))[:n]
+        g.push_text(piece)
+        expect.append(piece); total += n + 1
+    text = "\n".join(expect) + "\n"
+    assert len(text) == total
+    for off, n in ((0, 1000), (total - 1000, 1000), ((32 << 20) - 500, 1000), ((64 << 20) - 500, 1000), (12345678, 200000)):
+        assert g.read_text(off, n).decode() == text[off:off + n], off
+    g.close()
+
+
+def test_streaming_ingest_roundtrip(sim):
+    _ingest_roundtrip(sim)
