@@ -107,6 +107,9 @@ uint64_t resident_grid(K kern, int threads, uint64_t fallback) {
 #endif
     return fallback;
 }
+// every persistent workgroup of every launch of a stage may leave one partly used output chunk behind: a stage has up to
+// three launches (count: main, spill repair, HBM fallback; compact: two LDS tiers, HBM fallback)
+constexpr uint64_t CHUNK_SLACK_WGS = 3 * (PERSISTENT_GRID + 1);
 constexpr uint64_t MAX_GRID = 1u << 22;          // workgroups per launch (grid * block must stay < 2^32)
 uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 
@@ -405,7 +408,7 @@ int count_impl(cdbg_ctx* c) {
     c->st.n_records = n_records; c->st.n_member_kmers = hs[0];
 
     // count
-    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + 2 * (PERSISTENT_GRID + 1) * (uint64_t)COUNT_CHUNK;
+    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + CHUNK_SLACK_WGS * (uint64_t)COUNT_CHUNK;
     CK(c->solid_keys.alloc(solid_cap * W, false));
     CK(c->solid_cnt.alloc(solid_cap, false));
     CK(c->solid_cursor.alloc(4, true));
@@ -487,12 +490,13 @@ int compact_impl(cdbg_ctx* c) {
     CK(c->glue_state.alloc(1, false));
     CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
     CK(c->cursors.alloc(8, false));
-    // glue log: <= 2 open ends + 1 confirm per junction, one junction per solid traveller at most
-    c->glog_cap = 3 * c->st.n_solid_travellers + 2 * (PERSISTENT_GRID + 1) * (uint64_t)GLOG_CHUNK + 64;
-    CK(c->glog_keys.alloc(c->glog_cap * W, false)); CK(c->glog_tag.alloc(c->glog_cap, false));
 
     for (int attempt = 0; attempt < 2; ++attempt) {
-        const uint64_t pslack = 2 * (PERSISTENT_GRID + 1) * (uint64_t)PIECE_CHUNK, bslack = 2 * (PERSISTENT_GRID + 1) * (uint64_t)BASES_CHUNK;
+        // glue log: <= 2 open ends + 1 confirm per junction, one junction per solid traveller at most; the tail of a
+        // chunk that the next bucket does not fit into is abandoned, hence the generous second attempt
+        c->glog_cap = (attempt == 0 ? 3 : 8) * c->st.n_solid_travellers + (attempt + 1) * CHUNK_SLACK_WGS * (uint64_t)GLOG_CHUNK + 64;
+        CK(c->glog_keys.alloc(c->glog_cap * W, false)); CK(c->glog_tag.alloc(c->glog_cap, false));
+        const uint64_t pslack = CHUNK_SLACK_WGS * (uint64_t)PIECE_CHUNK, bslack = CHUNK_SLACK_WGS * (uint64_t)BASES_CHUNK;
         const uint64_t pcap = (attempt == 0 ? std::min<uint64_t>(S, S / 3 + 4096) + 16 : S + 16) + pslack;
         const uint64_t bcap = (attempt == 0 ? S + (pcap - pslack) * (uint64_t)(c->k - 1) + 64 : S * (uint64_t)c->k + 64) + bslack;
         CK(c->piece_n.alloc(pcap, false)); HIPCK(hipMemsetAsync(c->piece_n.p, 0, pcap * sizeof(uint32_t), s));
@@ -554,7 +558,7 @@ int compact_impl(cdbg_ctx* c) {
             HIPCK(hipStreamSynchronize(s));
         }
         uint32_t e = 0; CK(read_u32(c->derr.p, &e));
-        if (e == 3 && attempt == 0) continue;                // piece arrays too small: retry with the exact bound
+        if ((e == 3 || e == 5) && attempt == 0) continue;    // piece arrays / glue log too small: retry with the safe bounds
         if (nbig) c->st.n_big_partitions += nbig;
         break;
     }

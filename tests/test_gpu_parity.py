@@ -200,3 +200,40 @@ def test_streaming_ingest_roundtrip_gpu(hip):
     """pinned double-buffered H2D ingest on the copy stream (several staging buffers, growing device text)"""
     from test_hostsim_pipeline import _ingest_roundtrip
     _ingest_roundtrip(hip)
+
+
+def test_config5_shape_long_reads_k127(hip):
+    """BASELINE config 5 shape (1 kbp reads, k = 127, four-word k-mers) at a size where every compaction tier
+    runs with thousands of persistent workgroups each (regression: the chunk slack of the piece / base / glue-log
+    arrays was sized for two launches per stage, the third overflowed the glue log).  Properties instead of the
+    oracle: each solid k-mer exactly once over the unitigs, KC conserved."""
+    import bcalm_amd
+    k = 127
+    g = bcalm_amd.Graph(k, 2, lib=hip, log2_partitions=12)   # ~500 entries per bucket: all three compaction tiers get thousands of buckets
+    g.generate_reads(60000, 1000, 5)
+    g.count()
+    solid = g.solid_kmers()
+    g.compact(); g.glue()
+    ut = g.unitigs()
+    st = g.stats()
+    g.close()
+    comp = str.maketrans("ACGT", "TGCA")
+    seen = set()
+    for s, kc in ut:
+        for i in range(len(s) - k + 1):
+            x = s[i:i + k]; r = x.translate(comp)[::-1]
+            c = x if x <= r else r
+            assert c not in seen
+            seen.add(c)
+    assert len(seen) == len(solid) == st["n_solid"]
+    assert sum(kc for _, kc in ut) == sum(c for _, c in solid)
+    # the size that overflowed: ~450 entries per bucket over 16384 buckets, so each of the three compaction
+    # launches runs its full complement of persistent workgroups while the traveller-based bounds are tiny
+    g = bcalm_amd.Graph(k, 2, lib=hip, log2_partitions=14)
+    g.generate_reads(200000, 1000, 5)
+    g.run()
+    st = g.stats()
+    ut = g.unitigs()
+    g.close()
+    assert st["n_big_partitions"] > 3000
+    assert sum(len(s) - k + 1 for s, _ in ut) == st["n_solid"] and len(ut) == st["n_unitigs"]
