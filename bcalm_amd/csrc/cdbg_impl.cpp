@@ -638,7 +638,24 @@ int glue_impl(cdbg_ctx* c) {
     const uint32_t gridS = (NS + GLUE_THREADS - 1) / GLUE_THREADS;
     RankParams rp{};
     uint4* fa_st = nullptr;                                  // final state array
+    bool ranked = false;
     if (NS) {
+        // usual case (no closed chains): doubling on 8-byte states, expanded once at the end.  The two 8-byte
+        // ping-pong arrays live in st_b, which heads/emit later reuse for their per-head records.
+        int max_rounds8 = 2; while ((1ull << (max_rounds8 - 1)) < NS) ++max_rounds8;
+        Rank8Params r8{ NS, link_p, c->piece_n.p, reinterpret_cast<uint2*>(st_b.p), reinterpret_cast<uint2*>(st_b.p) + NS, flag.p, st_a.p };
+        CDBG_LAUNCH(k_rank8_init, gridS, GLUE_THREADS, s, r8);
+        for (int r = 0; r < max_rounds8 && !ranked; ++r) {
+            HIPCK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), s));
+            CDBG_LAUNCH(k_rank8_jump, gridS, GLUE_THREADS, s, r8);
+            std::swap(r8.a, r8.b);
+            HIPCK(hipStreamSynchronize(s));
+            uint32_t ch = 0; CK(read_u32(flag.p, &ch));
+            if (!ch) ranked = true;
+        }
+        if (ranked) { CDBG_LAUNCH(k_rank8_expand, gridS, GLUE_THREADS, s, r8); fa_st = st_a.p; }
+    }
+    if (NS && !ranked) {                                     // closed chains: the 16-byte version elects cut points
         int max_rounds = 2; while ((1ull << (max_rounds - 1)) < NS) ++max_rounds;
         for (int pass = 0; pass < 2; ++pass) {
             rp.n_states = NS; rp.link = link_p; rp.piece_n = c->piece_n.p;

@@ -80,6 +80,40 @@ __global__ void k_rank_jump(RankParams P) {
     }
     P.st_b[e] = v;
 }
+// ---- (2b) the same doubling on 8-byte states, for the usual case without closed chains ----
+// {x, y}: x = successor state, or RANK_TAIL | tail state once the end of the chain is known; y as above.  Half the
+// bytes per round of the 16-byte version (the rounds stream every state, so they are bandwidth bound); the
+// smallest-piece field that elects a cut point on closed chains is not carried: if this version does not
+// converge, the caller falls back to the 16-byte version, which can cut cycles.
+constexpr uint32_t RANK_TAIL = 0x80000000u;
+struct Rank8Params { uint32_t n_states; const uint32_t* link; const uint32_t* piece_n; uint2* a; uint2* b; uint32_t* changed; uint4* out; };
+__global__ void k_rank8_init(Rank8Params P) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.n_states) return;
+    const uint32_t nxt = P.link[e ^ 1u];
+    uint2 v; v.x = nxt == NONE32 ? (RANK_TAIL | e) : nxt; v.y = P.piece_n[e >> 1];
+    P.a[e] = v;
+}
+__global__ void k_rank8_jump(Rank8Params P) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.n_states) return;
+    uint2 v = P.a[e];
+    if (!(v.x & RANK_TAIL)) {
+        const uint2 t = P.a[v.x];
+        v.y += t.y; v.x = t.x;
+        *P.changed = 1u;
+    }
+    P.b[e] = v;
+}
+// converged 8-byte states -> the 16-byte layout k_unitig_heads / k_emit read (y = k-mers to the tail, z = tail)
+__global__ void k_rank8_expand(Rank8Params P) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.n_states) return;
+    const uint2 v = P.a[e];
+    uint4 o; o.x = NONE32; o.y = v.y; o.z = v.x & ~RANK_TAIL; o.w = 0;
+    P.out[e] = o;
+}
+
 // states still unresolved after ceil(log2(n_states))+1 rounds lie on closed chains:
 // cut the chain at the left end of its smallest piece
 struct CutParams { uint32_t n_states; const uint4* st; uint32_t* link; uint32_t* n_cycles; };
