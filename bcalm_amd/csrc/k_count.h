@@ -245,7 +245,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
     // instead of all TS slots, most of which are empty at the usual ~20-45 % load
     constexpr uint32_t LIST_CAP = GLOBAL ? 1 : TS / 2;
     CDBG_SHARED uint16_t l_used[LIST_CAP];
-    CDBG_SHARED uint32_t s_fill, s_over, s_nsolid, s_wr;
+    CDBG_SHARED uint32_t s_fill, s_over, s_nsolid, s_wr, s_members;
     CDBG_SHARED uint64_t s_base;
     CDBG_SHARED uint32_t s_stat[4];
 
@@ -273,11 +273,37 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
     const int k = P.k;
 
     uint32_t npass = GLOBAL ? 1u : start_np;
+    // Multi-pass partitions of moderate size run ONE phase: the segment is reserved up front for members / amin
+    // entries (an upper bound of the solid entries) from the workgroup's chunk, every pass writes its solid entries
+    // straight behind those of the passes before it, and the unused tail goes back to the chunk.  Only partitions
+    // whose bound exceeds a chunk count first and write in a second round of passes.
+    bool have_ub = false, onephase = false, reserved = false; uint32_t ub = 0;
     for (;;) {                                                    // attempts with npass, 2 npass, ...
         if (tid == 0) { s_nsolid = 0; s_wr = 0; s_over = 0; }
         if (tid < 4) s_stat[tid] = 0;
+        if (!GLOBAL && npass > 1 && !have_ub) {                   // member k-mers of the partition (first byte of every record)
+            if (tid == 0) s_members = 0;
+            block_sync<GLOBAL>();
+            uint32_t mine = 0;
+            for (uint64_t i = rec0 + tid; i < rec1; i += NT) mine += (uint32_t)(P.records[i * RW] & 0xFFu);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+            if (lane == 0 && mine) atomic_add_u32(&s_members, mine);
+            block_sync<GLOBAL>();
+            ub = s_members / (P.amin ? P.amin : 1u);
+            onephase = ub <= COUNT_CHUNK; have_ub = true;
+        }
+        if (onephase && npass > 1 && !reserved) {
+            if (tid == 0) {
+                if (ub > chunk_left) { chunk_base = atomic_add_u64(P.solid_cursor, (uint64_t)COUNT_CHUNK); chunk_left = COUNT_CHUNK; }
+                uint64_t b = chunk_base; chunk_base += ub; chunk_left -= ub;
+                if (b + ub > P.solid_cap) { *P.error = 1; b = 0; s_over = 2; }
+                s_base = b;
+            }
+            reserved = true;
+        }
         bool overflow = false;
-        const int nphase = npass == 1 ? 1 : 2;
+        const int nphase = (npass == 1 || onephase) ? 1 : 2;
         for (int phase = 0; phase < nphase && !overflow; ++phase) {
             for (uint32_t pass = 0; pass < npass; ++pass) {
                 // ---- build the table of this pass ----
@@ -408,6 +434,36 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     CDBG_PH(4);
                     continue;
                 }
+                // ---- multi-pass, one phase: statistics and solid entries of this pass in one sweep ----
+                if (onephase) {
+                    const uint64_t obase = s_base; const bool wr_ok = s_over == 0;
+                    uint32_t st_dist = 0, st_occ = 0, st_sh = 0, st_st = 0;
+                    for (uint32_t s = tid; s < cap; s += NT) {
+                        if (!ktable_used<W>(T, s)) continue;
+                        const uint32_t c = cnt[s], n = c & ~TRAV_FLAG; const bool trav = c & TRAV_FLAG;
+                        if (!trav) { ++st_dist; st_occ += n; }
+                        if (n >= P.amin) {
+                            if (trav) ++st_st; else ++st_sh;
+                            if (wr_ok) {
+                                const uint64_t o = obase + atomic_add_u32(&s_wr, 1u);
+                                for (int i = 0; i < W; ++i) P.solid_keys[o * W + i] = T.keys[(uint64_t)s * W + i];
+                                P.solid_cnt[o] = c;
+                            }
+                        }
+                    }
+                    uint32_t pk0 = st_dist, pk1 = st_sh | (st_st << 16);
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) { pk0 += __shfl_xor(pk0, d); pk1 += __shfl_xor(pk1, d); st_occ += __shfl_xor(st_occ, d); }
+                    if (lane == 0) {
+                        if (pk0) atomic_add_u32(&s_stat[0], pk0);
+                        if (st_occ) atomic_add_u32(&s_stat[1], st_occ);
+                        if (pk1 & 0xFFFFu) atomic_add_u32(&s_stat[2], pk1 & 0xFFFFu);
+                        if (pk1 >> 16) atomic_add_u32(&s_stat[3], pk1 >> 16);
+                    }
+                    block_sync<GLOBAL>();
+                    CDBG_PH(3);
+                    continue;
+                }
                 // ---- sweep: statistics + number of solid entries (phase 0) ----
                 if (phase == 0) {
                     uint32_t my_solid = 0, st_dist = 0, st_occ = 0, st_sh = 0, st_st = 0;
@@ -463,12 +519,22 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                 CDBG_PH(4);
             }
         }
-        if (!overflow) break;
+        if (!overflow) {
+            if (onephase && npass > 1 && tid == 0) {              // (the last pass ended with a barrier: s_wr is final)
+                const uint32_t used = s_wr;
+                P.seg_off[p] = s_base; P.seg_n[p] = s_over ? 0u : used;
+                chunk_base -= (ub - used); chunk_left += (ub - used);   // the reservation is the newest of this chunk: return its tail
+            }
+            break;
+        }
         block_sync<GLOBAL>();
         if (GLOBAL) { if (tid == 0) *P.error = 2; return; }     // scratch sizing bug: cannot happen by construction
         npass *= 2;
         if (npass > P.max_passes) {                               // hopeless in LDS: defer to the HBM pass
-            if (tid == 0) { const uint32_t i = atomic_add_u32(P.big_count, 1u); P.big_list[i] = p; P.seg_off[p] = 0; P.seg_n[p] = 0; }
+            if (tid == 0) {
+                if (reserved) { chunk_base -= ub; chunk_left += ub; }   // hand the whole reservation back
+                const uint32_t i = atomic_add_u32(P.big_count, 1u); P.big_list[i] = p; P.seg_off[p] = 0; P.seg_n[p] = 0;
+            }
             return;
         }
     }
@@ -482,7 +548,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
 // persistent workgroups, grid-stride over partitions (HIP limits grid*block to < 2^32 work-items);
 // statistics are accumulated in registers and published with one atomic per workgroup
 template <int W, int TS, int NT, bool GLOBAL>
-__global__ void __launch_bounds__(NT) k_count(CountParams P) {
+__global__ void __launch_bounds__(NT, (W == 1 && !GLOBAL) ? 6 : 4) k_count(CountParams P) {   // waves per SIMD that the LDS tables allow: 3 workgroups x 2 waves (W = 1), 4 otherwise
     uint64_t acc[4] = {0, 0, 0, 0};
     uint32_t start_np = 1, strikes = 0; bool clean = false;
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_prev = 0;
