@@ -237,3 +237,17 @@ def test_config5_shape_long_reads_k127(hip):
     g.close()
     assert st["n_big_partitions"] > 3000
     assert sum(len(s) - k + 1 for s, _ in ut) == st["n_solid"] and len(ut) == st["n_unitigs"]
+
+
+def test_parity_one_million_reads(oracle, hip):
+    """bit-exact against the oracle at the largest size the oracle finishes in seconds (1 M x 150 bp, 36 M distinct
+    k-mers): single-pass capped scan, persistent kernels with thousands of workgroups, chunked output reservations"""
+    import bcalm_amd
+    text = oracle.synth_reads(1000000, 150, 3)
+    exp = oracle.run(text.decode(), 31, 2)
+    g = bcalm_amd.Graph(31, 2, lib=hip)
+    g.push_text(text); g.run()
+    got = oracle_lib.canonical_set(oracle, g.unitigs(), 31)
+    st = g.stats(); g.close()
+    assert st["n_distinct"] == exp["stats"]["distinct"] and st["n_solid"] == exp["stats"]["solid"]
+    assert got == exp["unitigs"]
