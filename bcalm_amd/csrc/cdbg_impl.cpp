@@ -139,7 +139,7 @@ struct cdbg_ctx {
     uint64_t n_solid_entries = 0;                // home + traveller solid entries
 
     DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
-    DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_state, glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;
+    DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;
     DBuf<uint64_t> glog_keys; DBuf<uint32_t> glog_tag; uint64_t glog_cap = 0, n_glog = 0;
     uint64_t n_pieces = 0, n_piece_bases = 0;
 
@@ -438,7 +438,7 @@ int count_impl(cdbg_ctx* c) {
     uint32_t nbig = 0;
     HIPCK(hipStreamSynchronize(s));
     CK(read_u32(c->big_count.p, &nbig));
-    DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_state, g_cnt;
+    DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_cnt;
     if (nbig) {                                              // partitions whose distinct k-mers overflow LDS
         std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list.p, bl.data(), nbig));
         std::sort(bl.begin(), bl.end());
@@ -451,12 +451,12 @@ int count_impl(cdbg_ctx* c) {
             const uint64_t occ = nrec_p * nmax;
             offs[i + 1] = offs[i] + pow2_at_least(2 * occ + 4 * 256);
         }
-        CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_state.alloc(1, false)); CK(g_cnt.alloc(offs[nbig], false));
+        CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_cnt.alloc(offs[nbig], false));
         CK(big_off.alloc(nbig + 1, false));
         HIPCK(hipMemcpy(big_off.p, offs.data(), (nbig + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
         CountParams bp = cp;
-        bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_state = g_state.p; bp.g_cnt = g_cnt.p; bp.big_off = big_off.p;
+        bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_cnt = g_cnt.p; bp.big_off = big_off.p;
         bp.n_items = nbig; bp.max_passes = 1;
         // (grid bounded: every workgroup reserves whole output chunks, the slack is sized for PERSISTENT_GRID)
         CDBG_LAUNCH((k_count<W, TS, 256, true>), std::min<uint64_t>(nbig, PERSISTENT_GRID), 256, s, bp);
@@ -487,7 +487,6 @@ int compact_impl(cdbg_ctx* c) {
     // glue table: at most one junction per solid traveller entry
     c->glue_cap = (uint32_t)pow2_at_least(2 * c->st.n_solid_travellers + 64);
     CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false));
-    CK(c->glue_state.alloc(1, false));
     CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
     CK(c->cursors.alloc(8, false));
 
@@ -519,7 +518,7 @@ int compact_impl(cdbg_ctx* c) {
         kp.piece_n = c->piece_n.p; kp.piece_kc = c->piece_kc.p; kp.piece_boff = c->piece_boff.p; kp.piece_bases = c->piece_bases.p;
         kp.piece_ab = c->prm.all_abundance_counts ? c->piece_ab.p : nullptr;
         kp.piece_cap = pcap; kp.bases_cap = bcap; kp.piece_cursor = c->cursors.p; kp.bases_cursor = c->cursors.p + 1;
-        kp.glue_keys = c->glue_keys.p; kp.glue_state = c->glue_state.p; kp.glue_a = c->glue_a.p; kp.glue_b = c->glue_b.p;
+        kp.glue_keys = c->glue_keys.p; kp.glue_a = c->glue_a.p; kp.glue_b = c->glue_b.p;
         kp.glue_conf = c->glue_conf.p; kp.glue_mask = c->glue_cap - 1;
         kp.glog_keys = c->glog_keys.p; kp.glog_tag = c->glog_tag.p; kp.glog_cap = c->glog_cap; kp.glog_cursor = c->cursors.p + 4;
         kp.big_list = c->big_list.p; kp.big_count = c->big_count.p; kp.error = c->derr.p; kp.stats = c->dstats.p;
@@ -536,7 +535,7 @@ int compact_impl(cdbg_ctx* c) {
             HIPCK(hipStreamSynchronize(s));
             CK(read_u32(c->big_count2.p, &nbig));
         }
-        DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_state, g_cnt, g_lnk, g_aux;
+        DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_cnt, g_lnk, g_aux;
         if (nbig) {                                          // buckets with more entries than fit LDS
             std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list2.p, bl.data(), nbig));
             std::sort(bl.begin(), bl.end());
@@ -545,13 +544,13 @@ int compact_impl(cdbg_ctx* c) {
                 uint32_t e = 0; CK(read_u32(c->seg_n.p + bl[i], &e));
                 offs[i + 1] = offs[i] + pow2_at_least(2 * (uint64_t)e + 16);
             }
-            CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_state.alloc(1, false)); CK(g_cnt.alloc(offs[nbig], false));
+            CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_cnt.alloc(offs[nbig], false));
             CK(g_lnk.alloc(2 * offs[nbig], false)); CK(g_aux.alloc(3 * offs[nbig], false));
             CK(big_off.alloc(nbig + 1, false));
             HIPCK(hipMemcpy(big_off.p, offs.data(), (nbig + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
             HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
             CompactParams bp = kp;
-            bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_state = g_state.p; bp.g_cnt = g_cnt.p;
+            bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_cnt = g_cnt.p;
             bp.g_lnk = g_lnk.p; bp.g_aux = g_aux.p; bp.big_off = big_off.p;
             bp.n_items = nbig;
             CDBG_LAUNCH((k_compact<W, TS, true>), std::min<uint64_t>(nbig, PERSISTENT_GRID), COMPACT_THREADS, s, bp);
@@ -595,7 +594,7 @@ int glue_join_impl(cdbg_ctx* c, bool sharded) {
     const uint32_t world = sharded ? (uint32_t)c->prm.world_size : 1u;
     if (world > 1) {                                         // a table for this rank's share of the junctions
         c->glue_cap = (uint32_t)pow2_at_least((c->n_glog + c->n_glog / 4) / world + (c->n_glog >> 6) + 1024);
-        CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false)); CK(c->glue_state.alloc(1, false));
+        CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false));
         CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
         HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), s));
         HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
@@ -603,12 +602,12 @@ int glue_join_impl(cdbg_ctx* c, bool sharded) {
         HIPCK(hipMemsetAsync(c->glue_conf.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
     }
     {   // build the junction table from the glue log (dense lanes => device atomics at throughput)
-        GlueBuildParams bp{ c->glog_keys.p, c->glog_tag.p, c->n_glog, c->glue_keys.p, c->glue_state.p, c->glue_a.p, c->glue_b.p, c->glue_conf.p, c->glue_cap - 1,
+        GlueBuildParams bp{ c->glog_keys.p, c->glog_tag.p, c->n_glog, c->glue_keys.p, c->glue_a.p, c->glue_b.p, c->glue_conf.p, c->glue_cap - 1,
                             world - 1, world > 1 ? (uint32_t)c->prm.rank : 0u };
         if (c->n_glog) CDBG_LAUNCH((k_glue_build<W>), std::min<uint64_t>((c->n_glog + GLUE_THREADS - 1) / GLUE_THREADS, MAX_GRID), GLUE_THREADS, s, bp);
     }
     GlueResolveParams gp{};
-    gp.keys = c->glue_keys.p; gp.state = c->glue_state.p; gp.a = c->glue_a.p; gp.b = c->glue_b.p; gp.conf = c->glue_conf.p;
+    gp.keys = c->glue_keys.p; gp.a = c->glue_a.p; gp.b = c->glue_b.p; gp.conf = c->glue_conf.p;
     gp.cap = c->glue_cap; gp.W = W; gp.link = c->link.p; gp.stats = c->dstats.p;
     CDBG_LAUNCH(k_glue_resolve, std::min<uint64_t>((c->glue_cap + GLUE_THREADS - 1) / GLUE_THREADS, GLUE_RESOLVE_GRID), GLUE_THREADS, s, gp);
     float ms = 0; CK(t.stop(&ms));
@@ -720,14 +719,14 @@ int link_impl(cdbg_ctx* c) {
     const uint64_t U = c->n_unitigs, NE = 2 * U;
     if (NE >= 0x3FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many unitigs for 30-bit end slots");
     const uint32_t cap = (uint32_t)pow2_at_least(4 * U + 64);
-    DBuf<uint64_t> lk_keys; DBuf<uint32_t> lk_state, lk_cnt, lk_ends, end_slot, deg;
-    CK(lk_keys.alloc((uint64_t)cap * W, false)); CK(lk_state.alloc(1, true)); CK(lk_cnt.alloc((uint64_t)cap * 2, true));
+    DBuf<uint64_t> lk_keys; DBuf<uint32_t> lk_cnt, lk_ends, end_slot, deg;
+    CK(lk_keys.alloc((uint64_t)cap * W, false)); CK(lk_cnt.alloc((uint64_t)cap * 2, true));
     CK(lk_ends.alloc((uint64_t)cap * 8, false)); CK(end_slot.alloc(NE, false)); CK(deg.alloc(NE, false));
     HIPCK(hipMemsetAsync(lk_keys.p, 0xFF, (uint64_t)cap * W * sizeof(uint64_t), s));
     CK(c->link_off.alloc(NE + 1, true));
     LinkParams lp{};
     lp.n_unitigs = U; lp.k = c->k; lp.unitig_off = c->unitig_off.p; lp.unitig_len = c->unitig_len.p; lp.bases = c->unitig_bases.p;
-    lp.lk_keys = lk_keys.p; lp.lk_state = lk_state.p; lp.lk_cnt = lk_cnt.p; lp.lk_ends = lk_ends.p; lp.lk_mask = cap - 1;
+    lp.lk_keys = lk_keys.p; lp.lk_cnt = lk_cnt.p; lp.lk_ends = lk_ends.p; lp.lk_mask = cap - 1;
     lp.end_slot = end_slot.p; lp.deg = deg.p;
     c->n_links = 0;
     if (NE) {
@@ -1010,7 +1009,7 @@ int cdbg_exchange_end(cdbg_ctx* c) {
     // junction, so 1.25 x records keeps the load factor below one half in practice and below 0.8 always)
     const int W = c->W;
     c->glue_cap = (uint32_t)pow2_at_least(c->n_glog + c->n_glog / 4 + 64);
-    CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false)); CK(c->glue_state.alloc(1, false));
+    CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false));
     CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
     HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), c->stream));
     HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), c->stream));

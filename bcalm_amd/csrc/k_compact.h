@@ -70,13 +70,13 @@ struct CompactParams {
     uint64_t piece_cap, bases_cap;
     uint64_t* piece_cursor; uint64_t* bases_cursor;
     // glue table (HBM)
-    uint64_t* glue_keys; uint32_t* glue_state; uint32_t* glue_a; uint32_t* glue_b; uint32_t* glue_conf; uint32_t glue_mask;
+    uint64_t* glue_keys; uint32_t* glue_a; uint32_t* glue_b; uint32_t* glue_conf; uint32_t glue_mask;
     // glue log: (junction key, tag) records; tag = piece-end id, GTAG_CONFIRM, or GTAG_EMPTY (pre-filled)
     uint64_t* glog_keys; uint32_t* glog_tag; uint64_t glog_cap; uint64_t* glog_cursor;
     uint32_t* big_list; uint32_t* big_count; uint32_t* error;
     uint64_t* stats;               // [0] open ends posted [1] confirms posted [2] in-bucket cycles [3] pieces written
     // HBM scratch (GLOBAL variant)
-    uint64_t* g_keys; uint32_t* g_state; uint32_t* g_cnt; uint32_t* g_lnk; uint32_t* g_aux; const uint64_t* big_off;
+    uint64_t* g_keys; uint32_t* g_cnt; uint32_t* g_lnk; uint32_t* g_aux; const uint64_t* big_off;
     uint32_t n_items;              // buckets (or part_list entries) to process
 };
 
@@ -133,14 +133,14 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
     KTable<W> T; uint32_t *cnt, *lnk, *pdesc, *slots, *pn, *pb; uint8_t* vis; uint32_t cap;
     if (GLOBAL) {
         const uint64_t o0 = P.big_off[item]; cap = (uint32_t)(P.big_off[item + 1] - o0);
-        T.keys = P.g_keys + o0 * W; T.state = P.g_state + o0; cnt = P.g_cnt + o0;
+        T.keys = P.g_keys + o0 * W; cnt = P.g_cnt + o0;
         lnk = P.g_lnk + 2 * o0; vis = reinterpret_cast<uint8_t*>(P.g_aux + 3 * o0); pdesc = P.g_aux + 3 * o0 + cap / 4;
     } else {
         if (E > (uint32_t)TS / 2) {                      // does not fit LDS: defer to the big pass
             if (tid == 0) { const uint32_t i = atomic_add_u32(P.big_count, 1u); P.big_list[i] = p; }
             return;
         }
-        cap = TS; T.keys = l_keys; T.state = nullptr; cnt = l_cnt; lnk = l_lnk; vis = reinterpret_cast<uint8_t*>(l_aux); pdesc = l_aux + TS / 4;
+        cap = TS; T.keys = l_keys; cnt = l_cnt; lnk = l_lnk; vis = reinterpret_cast<uint8_t*>(l_aux); pdesc = l_aux + TS / 4;
     }
     T.mask = cap - 1;
     slots = pdesc + cap / 2; pn = slots + cap / 2; pb = pn + cap / 2;   // E <= cap/2 entries, <= cap/2 pieces
@@ -385,13 +385,13 @@ __global__ void __launch_bounds__(COMPACT_THREADS, (W == 2 && TS <= 512 && !GLOB
 // atomics run at throughput instead of paying their latency inside the per-bucket kernel ----
 struct GlueBuildParams {
     const uint64_t* glog_keys; const uint32_t* glog_tag; uint64_t n_records;
-    uint64_t* glue_keys; uint32_t* glue_state; uint32_t* glue_a; uint32_t* glue_b; uint32_t* glue_conf; uint32_t glue_mask;
+    uint64_t* glue_keys; uint32_t* glue_a; uint32_t* glue_b; uint32_t* glue_conf; uint32_t glue_mask;
     uint32_t shard_mask, shard_rank;   // multi-GPU sharded join: this rank takes the junctions with (mix32(hash) & mask) == rank; mask 0 = all
 };
 template <int W>
 __global__ void k_glue_build(GlueBuildParams P) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const GlueTable<W> G{ { P.glue_keys, P.glue_state, P.glue_mask }, P.glue_a, P.glue_b, P.glue_conf };
+    const GlueTable<W> G{ { P.glue_keys, P.glue_mask }, P.glue_a, P.glue_b, P.glue_conf };
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n_records; i += stride) {
         const uint32_t tag = P.glog_tag[i];
         if (tag == GTAG_EMPTY) continue;

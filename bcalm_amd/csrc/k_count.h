@@ -41,7 +41,6 @@ constexpr uint64_t KEY_EMPTY = ~0ULL, KEY_PENDING = 1ULL << 63;
 template <int W>
 struct KTable {
     uint64_t* keys;      // [cap * W]
-    uint32_t* state;     // unused (kept so that aggregate initialisers of the callers stay as they are)
     uint32_t mask;       // cap - 1
 };
 
@@ -210,7 +209,7 @@ struct CountParams {
     uint32_t* big_list; uint32_t* big_count;   // partitions that overflowed LDS
     uint32_t* error;               // set to 1 on output overflow
     // HBM scratch table (GLOBAL variant): slot i of the big pass uses [big_off[i], big_off[i+1]) slots
-    uint64_t* g_keys; uint32_t* g_state; uint32_t* g_cnt; const uint64_t* big_off;
+    uint64_t* g_keys; uint32_t* g_cnt; const uint64_t* big_off;
     uint32_t n_items;              // partitions (or part_list entries) to process
     uint32_t max_passes;           // LDS multi-pass limit before a partition is deferred to the HBM pass
 };
@@ -264,9 +263,9 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
     KTable<W> T; uint32_t* cnt; uint32_t cap;
     if (GLOBAL) {
         const uint64_t o0 = P.big_off[item]; cap = (uint32_t)(P.big_off[item + 1] - o0);
-        T.keys = P.g_keys + o0 * W; T.state = P.g_state + o0; cnt = P.g_cnt + o0;
+        T.keys = P.g_keys + o0 * W; cnt = P.g_cnt + o0;
     } else {
-        cap = TS; T.keys = l_keys; T.state = nullptr; cnt = l_cnt;
+        cap = TS; T.keys = l_keys; cnt = l_cnt;
     }
     T.mask = cap - 1;
     const uint32_t maxfill = cap - cap / 4;                       // load limit; inserts also give up after 64 probes

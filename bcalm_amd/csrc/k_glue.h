@@ -24,7 +24,7 @@ constexpr int GLUE_THREADS = 256;
 
 // ---- (1) sweep the glue table: confirmed junction with two ends -> mutual links ----
 struct GlueResolveParams {
-    const uint64_t* keys; const uint32_t* state; const uint32_t* a; const uint32_t* b; const uint32_t* conf;
+    const uint64_t* keys; const uint32_t* a; const uint32_t* b; const uint32_t* conf;
     uint32_t cap; int W;
     uint32_t* link;                // [2 * n_pieces], NONE32 = no partner
     uint64_t* stats;               // [0] junctions joined

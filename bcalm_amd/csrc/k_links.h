@@ -30,7 +30,7 @@ struct LinkTable {
 struct LinkParams {
     uint64_t n_unitigs; int k;
     const uint64_t* unitig_off; const uint32_t* unitig_len; const uint8_t* bases;
-    uint64_t* lk_keys; uint32_t* lk_state; uint32_t* lk_cnt; uint32_t* lk_ends; uint32_t lk_mask;
+    uint64_t* lk_keys; uint32_t* lk_cnt; uint32_t* lk_ends; uint32_t lk_mask;
     uint32_t* end_slot;   // [2U] table slot of each end (bit 31 = flag, bit 30 = palindromic key)
     uint32_t* deg;        // [2U] out-degree of each end
     const uint64_t* link_off; uint32_t* link_to;   // fill pass
@@ -56,7 +56,7 @@ __global__ void k_link_insert(LinkParams P) {
     const bool pal = (r == j);
     const uint32_t flag = (!pal && r < j) ? 1u : 0u;
     const Kmer<W> jc = flag ? r : j;
-    const KTable<W> T{ P.lk_keys, P.lk_state, P.lk_mask };
+    const KTable<W> T{ P.lk_keys, P.lk_mask };
     bool nw; const uint32_t s = ktable_insert<W, true>(T, jc, nw);
     const uint32_t idx = atomic_add_u32(&P.lk_cnt[s * 2 + flag], 1u);
     if (idx < 4) P.lk_ends[s * 8 + flag * 4 + idx] = (uint32_t)e;
