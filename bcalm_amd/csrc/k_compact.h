@@ -111,7 +111,7 @@ CDBG_DEV int probe_succ(const KTable<W>& T, const Kmer<W>& u, int k, uint32_t& s
 }
 
 template <int W, int TS, bool GLOBAL>
-CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64_t (&acc)[4],
+CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64_t (&acc)[4], bool& clean,
                              uint64_t& pc_base, uint32_t& pc_left, uint64_t& bc_base, uint32_t& bc_left,
                              uint64_t& lc_base, uint32_t& lc_left, uint64_t (&ph)[8], uint64_t& t_prev) {
     CDBG_SHARED uint64_t l_keys[GLOBAL ? 1 : TS * W];
@@ -147,8 +147,10 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
     const uint32_t pg = (p << P.rank_bits) | (uint32_t)P.rank;     // global partition id of this bucket
 
     if (tid == 0) { s_np = 0; s_nb = 0; s_nopen = 0; s_lw = 0; s_stat[0] = s_stat[1] = s_stat[2] = s_stat[3] = 0; }
-    ktable_clear<W>(T, tid, COMPACT_THREADS);
-    for (uint32_t i = tid; i < cap; i += COMPACT_THREADS) vis[i] = 0;
+    if (GLOBAL || !clean) {                                  // (the previous bucket emptied the slots it had used)
+        ktable_clear<W>(T, tid, COMPACT_THREADS);
+        for (uint32_t i = tid; i < cap; i += COMPACT_THREADS) vis[i] = 0;
+    }
     block_sync<GLOBAL>();
 
     // ---- load the bucket: home + traveller solid k-mers ----
@@ -359,6 +361,13 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
         if (my_open) atomic_add_u32(&s_stat[0], my_open);
     }
     block_sync<GLOBAL>();
+    if (!GLOBAL) {                                           // hand the LDS table back empty: E slots instead of all TS
+        for (uint32_t e = tid; e < E; e += COMPACT_THREADS) {
+            const uint32_t s = slots[e];
+            T.keys[(uint64_t)s * W + (W - 1)] = KEY_EMPTY; vis[s] = 0;
+        }
+        clean = true;                                        // (the kernel's per-bucket barrier orders this before the next load)
+    }
     CDBG_PH(5);
     if (tid == 0) for (int i = 0; i < 4; ++i) acc[i] += (uint64_t)s_stat[i];
 }
@@ -371,8 +380,9 @@ __global__ void __launch_bounds__(COMPACT_THREADS, (W == 2 && TS <= 512 && !GLOB
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
     t_prev = wall_clock64();
 #endif
+    bool clean = false;
     for (uint32_t item = blockIdx.x; item < P.n_items; item += gridDim.x) {
-        compact_bucket<W, TS, GLOBAL>(P, item, acc, pc_base, pc_left, bc_base, bc_left, lc_base, lc_left, ph, t_prev);
+        compact_bucket<W, TS, GLOBAL>(P, item, acc, clean, pc_base, pc_left, bc_base, bc_left, lc_base, lc_left, ph, t_prev);
         __syncthreads();                                 // LDS is reused by the next bucket
     }
     if (threadIdx.x == 0) for (int i = 0; i < 4; ++i) if (acc[i]) atomic_add_u64(&P.stats[i], acc[i]);
