@@ -45,11 +45,30 @@ EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", 
            "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end", "cdbg_glue_join", "cdbg_glue_links_export", "cdbg_glue_links_import"]
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 and looks it up by file name, libcdbg.so
+    asks for the soname libamdhip64.so.7: whichever of the two is loaded first decides whether the process ends up
+    with one runtime (torch first) or two (libcdbg first; the second one to touch the device then finds no GPU).
+    Loading torch's copy before libcdbg.so -- without importing torch -- makes every order work."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        for root in (spec.submodule_search_locations or []) if spec else []:
+            cand = os.path.join(root, "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+                return
+    except Exception:
+        pass                                             # no torch, or not a ROCm build: libcdbg uses the system runtime
+
+
 def load(path: str | None = None) -> C.CDLL:
     path = path or DEFAULT_LIB
     if not os.path.exists(path):
         raise CdbgError(-2, f"{path} not found: build the HIP extension first "
                             f"(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    if os.path.abspath(path) == os.path.abspath(DEFAULT_LIB):
+        _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     lib.cdbg_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]

@@ -251,3 +251,57 @@ def test_parity_one_million_reads(oracle, hip):
     st = g.stats(); g.close()
     assert st["n_distinct"] == exp["stats"]["distinct"] and st["n_solid"] == exp["stats"]["solid"]
     assert got == exp["unitigs"]
+
+
+def test_two_rank_flow_on_one_device(oracle, hip):
+    """the complete N = 2 data path on the real device, ranks emulated one after the other on GPU 0 (RCCL refuses two
+    ranks on one GPU): partitions split two ways, glue records exchanged through cdbg_exchange_* with device buffers,
+    junction join sharded by key hash, link arrays combined with an element-wise MAX, rank + emit on both; the two
+    ranks must end with the same unitig set as the single-rank run and the oracle"""
+    import torch
+    import bcalm_amd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0); torch.zeros(1, device=dev)     # torch's HIP runtime initialises before libcdbg's first call here
+    text = oracle.synth_reads(300000, 150, 3)
+    exp = oracle.run(text, 31, 2)
+    world = 2
+    gs = []
+    for r in range(world):
+        g = bcalm_amd.Graph(31, 2, lib=hip, world_size=world, rank=r)
+        g.push_text(text); g.count(); g.compact()
+        gs.append(g)
+    sizes = [g.exchange_sizes() for g in gs]
+    kinds = [(0, 4, 0), (1, 8, 0), (2, 8, 0), (3, 1, 1), (4, 8, 2), (5, 4, 2)]        # (export kind, bytes per item, which size)
+    bufs = []                                                                          # bufs[r][kind] = device tensor
+    for r, g in enumerate(gs):
+        row = []
+        for kind, item, which in kinds:
+            nb = max(int(sizes[r][which]) * item, 16)
+            t = torch.empty(nb, dtype=torch.uint8, device=dev)
+            g.exchange_export(kind, t.data_ptr(), nb)
+            row.append(t)
+        bufs.append(row)
+    totals = [sum(int(sizes[r][j]) for r in range(world)) for j in range(3)]
+    links = []
+    for g in gs:
+        g.exchange_begin(*totals)
+        for r in range(world):
+            g.exchange_add(int(sizes[r][0]), int(sizes[r][1]), int(sizes[r][2]), [t.data_ptr() for t in bufs[r]])
+        g.exchange_end()
+        n = g.glue_join()
+        t = torch.empty(n, dtype=torch.int32, device=dev)
+        g.glue_links_export(t.data_ptr(), n * 4)
+        links.append(t)
+    assert links[0].numel() == links[1].numel() == 2 * totals[0]
+    both = (links[0] >= 0) & (links[1] >= 0)
+    assert int(both.sum().item()) == 0, "an end was joined by both ranks"
+    assert int((links[0] >= 0).sum().item()) > 0 and int((links[1] >= 0).sum().item()) > 0
+    merged = torch.maximum(links[0], links[1])
+    torch.cuda.synchronize()
+    sets = []
+    for g in gs:
+        g.glue_links_import(merged.data_ptr(), merged.numel() * 4)
+        g.glue()
+        sets.append(oracle_lib.canonical_set(oracle, g.unitigs(), 31))
+        g.close()
+    assert sets[0] == sets[1] == exp["unitigs"]
