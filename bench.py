@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r01_g_pmc_hbm_traffic_per_kernel.csv")
+PMC_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r01_h_pmc_hbm_traffic_per_kernel.csv")
 
 
 def pmc_traffic(kernel_key):
@@ -217,7 +217,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic({"k_count": "k_count<", "k_compact": "k_compact<", "k_scan<emit>": "k_scan_fast<1, 2",
                                                  "k_scan<hist>": "k_scan_fast<1, 0"}.get(dom, "k_glue_build")),
-                         "traffic_source": "profiles/r01_g_pmc_hbm_traffic_per_kernel.csv (separate rocprofv3 --pmc passes)",
+                         "traffic_source": "profiles/r01_h_pmc_hbm_traffic_per_kernel.csv (separate rocprofv3 --pmc passes)",
                          "alg_bytes_per_launch": per_kernel[dom], "avg_launch_ms": dom_ms,
                          "pipeline": {"alg_bytes": alg_total, "gpu_ms": gpu_ms,
                                       "achieved": alg_total / (gpu_ms * 1e-3) / 1e9,
