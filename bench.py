@@ -68,18 +68,85 @@ def alg_bytes(k, st, n_reads, read_len):
     return per_kernel, A1 + A2 + A3 + A4 + A5
 
 
-def cpu_baseline(k, amin, read_len, cfg, sample_reads):
+def _cpu_worker(args):
+    """one scalar run of the CPU port on its own read sample (separate process: the port is single-threaded)"""
+    k, amin, read_len, cfg, sample_reads = args
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     orc = oracle_lib.load()
     text = orc.synth_reads(sample_reads, read_len, cfg)
     t0 = time.time()
     r = orc.run(text, k, amin)
-    dt = time.time() - t0
-    return {"value": r["stats"]["distinct"] / dt, "unit": "kmers/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_reads} x {read_len} bp synthetic reads (same generator, 30x coverage), "
-                      f"{r['stats']['distinct']} distinct k-mers in {dt:.1f} s; CPU restatement of the spec, "
-                      f"NOT BCALM2 (its gatb-core sources are absent)"}
+    return r["stats"]["distinct"], time.time() - t0
+
+
+def _reference_binary():
+    """a real BCALM 2 binary, if the box happens to have one"""
+    import shutil
+    cand = os.environ.get("BCALM_BIN") or shutil.which("bcalm")
+    if cand and os.path.isfile(cand) and os.path.realpath(cand) != os.path.realpath(os.path.join(ROOT, "bcalm_amd", "_build", "bcalm")):
+        return cand
+    return None
+
+
+def cpu_baseline(k, amin, read_len, cfg, sample_reads):
+    """CPU baseline on the host cores of this box (reported, not the target).
+    Preferred: the reference's own binary ($BCALM_BIN / `which bcalm`) on a FASTA dump of the sample, all cores.
+    Otherwise (expected: gatb-core is absent, nothing to build): the scalar CPU port of the spec (oracle/), one
+    process per core on up to 32 cores, each on its own sample of the same generator -- the aggregate rate of an
+    embarrassingly parallel use of the port, which flatters the CPU (no shared table, no merge)."""
+    import subprocess
+    import tempfile
+    ref = _reference_binary()
+    if ref:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            orc = oracle_lib.load()
+            text = orc.synth_reads(sample_reads, read_len, cfg).decode()
+            with tempfile.TemporaryDirectory() as t:
+                fa = os.path.join(t, "sample.fa")
+                with open(fa, "w") as f:
+                    for i, line in enumerate(text.split("\n")):
+                        if line:
+                            f.write(">r%d\n%s\n" % (i, line))
+                cores = os.cpu_count() or 1
+                t0 = time.time()
+                subprocess.run([ref, "-in", fa, "-kmer-size", str(k), "-abundance-min", str(amin), "-nb-cores", str(cores)],
+                               cwd=t, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+                dt = time.time() - t0
+            distinct = orc.run(text, k, amin)["stats"]["distinct"]
+            return {"value": distinct / dt, "unit": "kmers/s", "cores": cores, "kind": "reference",
+                    "sample": f"{sample_reads} x {read_len} bp synthetic reads through {ref} in {dt:.1f} s"}
+        except Exception:
+            pass                                             # fall through to the port
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    t0 = time.time()
+    res = []
+    if cores > 1:                                            # one child process per core (never a Pool: a bench must not hang)
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--k", str(k), "--abundance-min", str(amin),
+                                   "--read-len", str(read_len), "--cfg", str(cfg + 16 * i), "--cpu-sample-reads", str(sample_reads)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(cores)]
+        for p in procs:
+            try:
+                out, _ = p.communicate(timeout=300)
+                d, dt = out.strip().split()[-2:]
+                res.append((int(d), float(dt)))
+            except Exception:
+                p.kill()
+    if not res:
+        cores = 1
+        res = [_cpu_worker((k, amin, read_len, cfg, sample_reads))]
+    cores = len(res)
+    wall = time.time() - t0
+    total = sum(d for d, _ in res)
+    one = res[0][0] / res[0][1]
+    slowest = max(dt for _, dt in res)
+    return {"value": total / slowest, "unit": "kmers/s", "cores": cores, "kind": "port",
+            "single_core_value": one,
+            "sample": f"{cores} processes x {sample_reads} x {read_len} bp synthetic reads (same generator, 30x coverage, one sample "
+                      f"per core), {total} distinct k-mers, slowest process {slowest:.1f} s ({wall:.1f} s with start-up); "
+                      f"scalar CPU restatement of the spec run once per core, NOT BCALM2 (its gatb-core sources are absent)"}
 
 
 def main():
@@ -95,11 +162,16 @@ def main():
     ap.add_argument("--cfg", type=int, default=3)
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)   # child of cpu_baseline: one scalar run, prints 'distinct seconds'
     ap.add_argument("--mode", choices=["sharded", "independent"], default="sharded",
                     help="N>1: sharded = ONE graph, minimizer partitions split over the ranks, glue records exchanged with an RCCL "
                          "all-gather (strong scaling); independent = one read set per rank, no collective (weak scaling)")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded (collective) code path even with one rank (testing)")
     a = ap.parse_args()
+    if a.cpu_worker:
+        d, dt = _cpu_worker((a.k, a.abundance_min, a.read_len, a.cfg, a.cpu_sample_reads))
+        print(d, dt)
+        return
 
     # the one JSON line must be the only thing on stdout: RCCL / HIP runtime banners written to fd 1 by native
     # code go to stderr instead
