@@ -115,6 +115,21 @@ def _worker_graph(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_eight_rank_sharded_join_gloo():
+    """the world size of the full node: 8 ranks, partitions split eight ways (3 rank bits), eight-way sharded join"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_graph, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert len(res) == 8 and all(r[1] for r in res), res
+
+
 def test_four_rank_sharded_join_gloo():
     """4 ranks: partitions split four ways, glue records all-gathered, junction join sharded by key hash and
     combined with the MAX all-reduce; one- and two-word k-mers"""
