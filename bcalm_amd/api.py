@@ -42,7 +42,8 @@ class Stats(C.Structure):
 EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
            "cdbg_generate_reads", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
            "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats",
-           "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end", "cdbg_glue_join", "cdbg_glue_links_export", "cdbg_glue_links_import"]
+           "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end", "cdbg_glue_join", "cdbg_glue_links_export", "cdbg_glue_links_import",
+           "cdbg_exchange_sizes_packed", "cdbg_exchange_export_packed", "cdbg_exchange_add_packed"]
 
 
 def _share_hip_runtime_with_torch() -> None:
@@ -96,6 +97,9 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_exchange_add.argtypes = [vp, u64, u64, u64, vp, vp, vp, vp, vp, vp]
     lib.cdbg_exchange_end.argtypes = [vp]
     lib.cdbg_glue_join.argtypes = [vp, C.POINTER(u64)]
+    lib.cdbg_exchange_sizes_packed.argtypes = [vp, C.POINTER(u64)]
+    lib.cdbg_exchange_export_packed.argtypes = [vp, vp, u64]
+    lib.cdbg_exchange_add_packed.argtypes = [vp, u64, u64, u64, u64, vp, vp, vp, vp, vp]
     lib.cdbg_glue_links_export.argtypes = [vp, vp, u64]
     lib.cdbg_glue_links_import.argtypes = [vp, vp, u64]
     return lib
@@ -227,6 +231,18 @@ class Graph:
 
     def exchange_end(self):
         self._ck(self.lib.cdbg_exchange_end(self._h))
+
+    def exchange_sizes_packed(self):
+        """packs this rank's piece bases; -> (piece ids, bases once unpacked, glue-log records, packed bytes)"""
+        out = (C.c_uint64 * 4)()
+        self._ck(self.lib.cdbg_exchange_sizes_packed(self._h, out))
+        return tuple(int(x) for x in out)
+
+    def exchange_export_packed(self, dst_ptr, nbytes):
+        self._ck(self.lib.cdbg_exchange_export_packed(self._h, C.c_void_p(dst_ptr), nbytes))
+
+    def exchange_add_packed(self, n_pieces, n_bases, n_packed, n_glog, ptrs):
+        self._ck(self.lib.cdbg_exchange_add_packed(self._h, n_pieces, n_bases, n_packed, n_glog, *[C.c_void_p(p) for p in ptrs]))
 
     def glue_join(self):
         """sharded junction join; -> number of piece ends (length of the int32 link array)"""

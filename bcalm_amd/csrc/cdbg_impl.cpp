@@ -148,6 +148,9 @@ struct cdbg_ctx {
     uint64_t mg_np = 0, mg_nb = 0, mg_nl = 0, mg_cap_p = 0, mg_cap_b = 0, mg_cap_l = 0; bool mg_open = false;
     // junction join result (cdbg_glue_join / first half of cdbg_glue): partner end of every piece end
     DBuf<uint32_t> link; bool joined = false; uint64_t n_join_local = 0;
+    // packed exchange (cdbg_exchange_sizes_packed / _add_packed): this rank's piece bases, 4 per byte, no gaps
+    DBuf<uint8_t> xp_bases, xp_dense; DBuf<uint32_t> xp_lens; DBuf<uint64_t> xp_uoff; uint64_t xp_bytes = 0, xp_unpacked = 0;
+    DBuf<uint32_t> xr_lens; DBuf<uint64_t> xr_uoff;      // receiver-side scratch of cdbg_exchange_add_packed
 
     DBuf<uint64_t> unitig_off; DBuf<uint32_t> unitig_len; DBuf<uint64_t> unitig_kc; DBuf<uint8_t> unitig_bases;
     uint64_t n_unitigs = 0, unitig_total = 0;
@@ -269,6 +272,18 @@ void configure(cdbg_ctx* c) {
     c->log_np = log_np; c->m = m;
     c->n_local_parts = ((uint64_t)1 << log_np) >> c->rank_bits;
     c->st.minimizer_size = m; c->st.log2_partitions = log_np; c->st.kmer_words = W;
+}
+
+// exclusive prefix sum of n uint32 counts into n + 1 uint64 offsets (off[n] = total), on the context's stream
+int exscan_u32(cdbg_ctx* c, const uint32_t* counts, uint64_t* off, uint64_t n) {
+    hipStream_t s = c->stream;
+    const uint64_t nb = (n + EXSCAN_BLOCK - 1) / EXSCAN_BLOCK;
+    CK(c->exscan_tmp.alloc(nb + 1, false));
+    if (n == 0) { HIPCK(hipMemsetAsync(off, 0, sizeof(uint64_t), s)); return CDBG_OK; }
+    CDBG_LAUNCH(k_exscan_sums, nb, EXSCAN_THREADS, s, counts, c->exscan_tmp.p, n);
+    CDBG_LAUNCH(k_exscan_top, 1, EXSCAN_THREADS, s, c->exscan_tmp.p, nb, off + n);
+    CDBG_LAUNCH(k_exscan_apply, nb, EXSCAN_THREADS, s, counts, (const uint64_t*)c->exscan_tmp.p, off, n);
+    return CDBG_OK;
 }
 
 template <int W>
@@ -976,9 +991,10 @@ int cdbg_exchange_begin(cdbg_ctx* c, uint64_t total_pieces, uint64_t total_bases
     // capacity, so that a re-run after cdbg_reset finds arrays that are large enough and never reallocates
     CK(c->mg_n.alloc(std::max<size_t>(total_pieces, c->piece_n.cap), false)); CK(c->mg_kc.alloc(std::max<size_t>(total_pieces, c->piece_kc.cap), false));
     CK(c->mg_boff.alloc(std::max<size_t>(total_pieces, c->piece_boff.cap), false));
-    CK(c->mg_bases.alloc(std::max<size_t>(total_bases, c->piece_bases.cap), false));
+    const uint64_t bases_slack = 64ull * 4096;               // the packed exchange starts every rank's bases on a 64-byte boundary
+    CK(c->mg_bases.alloc(std::max<size_t>(total_bases + bases_slack, c->piece_bases.cap), false));
     CK(c->mg_gkeys.alloc(std::max<size_t>(total_glog * c->W, c->glog_keys.cap), false)); CK(c->mg_gtag.alloc(std::max<size_t>(total_glog, c->glog_tag.cap), false));
-    c->mg_np = c->mg_nb = c->mg_nl = 0; c->mg_cap_p = total_pieces; c->mg_cap_b = total_bases; c->mg_cap_l = total_glog; c->mg_open = true;
+    c->mg_np = c->mg_nb = c->mg_nl = 0; c->mg_cap_p = total_pieces; c->mg_cap_b = total_bases + bases_slack; c->mg_cap_l = total_glog; c->mg_open = true;
     return CDBG_OK;
 }
 int cdbg_exchange_add(cdbg_ctx* c, uint64_t n_pieces, uint64_t n_bases, uint64_t n_glog, const void* piece_n, const void* piece_kc,
@@ -995,6 +1011,82 @@ int cdbg_exchange_add(cdbg_ctx* c, uint64_t n_pieces, uint64_t n_bases, uint64_t
     const uint64_t work = std::max(n_pieces, n_glog);
     if (work) CDBG_LAUNCH(k_merge_append, std::min<uint64_t>((work + 255) / 256, MAX_GRID), 256, c->stream, mp);
     HIPCK(hipStreamSynchronize(c->stream));
+    c->mg_np += n_pieces; c->mg_nb += n_bases; c->mg_nl += n_glog;
+    return CDBG_OK;
+}
+// ---- packed variant of the exchange: bases travel as 2 bits (pieces padded to whole bytes, reservation gaps squeezed
+// out) and the per-piece base offsets do not travel at all -- the receiver recomputes them from the piece lengths ----
+int cdbg_exchange_sizes_packed(cdbg_ctx* c, uint64_t out[4]) {
+    if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    if (c->prm.all_abundance_counts) return fail(CDBG_E_PARAM, "-all-abundance-counts is single-GPU only in this version");
+    if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
+    hipStream_t s = c->stream;
+    const uint64_t NP = c->n_pieces;
+    CK(c->xp_lens.alloc(NP, false)); CK(c->xp_uoff.alloc(NP + 1, false));
+    if (NP) {
+        PackLenParams lp{ NP, c->k, c->piece_n.p, c->xp_lens.p };
+        CDBG_LAUNCH(k_pack_lens, (NP + 255) / 256, 256, s, lp);
+    }
+    CK(exscan_u32(c, c->xp_lens.p, c->xp_uoff.p, NP));
+    HIPCK(hipStreamSynchronize(s));
+    CK(read_u64(c->xp_uoff.p + NP, &c->xp_unpacked));
+    const uint64_t chunks = (c->xp_unpacked + 63) / 64;      // 64 bases -> 16 bytes per lane
+    c->xp_bytes = chunks * 16;
+    CK(c->xp_dense.alloc(chunks * 64 + 64, false)); CK(c->xp_bases.alloc(c->xp_bytes + 16, false));
+    if (chunks) HIPCK(hipMemsetAsync(c->xp_dense.p + (chunks - 1) * 64, 'A', 64, s));     // tail padding of the last chunk
+    if (NP) {
+        SqueezeParams sq{ NP, c->xp_lens.p, c->xp_uoff.p, c->piece_boff.p, c->piece_bases.p, c->xp_dense.p };
+        CDBG_LAUNCH(k_squeeze_bases, (NP + 255) / 256, 256, s, sq);
+    }
+    if (chunks) {
+        StreamPackParams pp{ chunks, c->xp_dense.p, c->xp_bases.p, c->xp_unpacked };
+        CDBG_LAUNCH(k_pack_stream, (chunks + 255) / 256, 256, s, pp);
+    }
+    HIPCK(hipStreamSynchronize(s));
+    out[0] = NP; out[1] = c->xp_unpacked; out[2] = c->n_glog; out[3] = c->xp_bytes;
+    return CDBG_OK;
+}
+int cdbg_exchange_export_packed(cdbg_ctx* c, void* dst_dev, uint64_t nbytes) {
+    if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage != 2 || !c->xp_bases.p) return fail(CDBG_E_STATE, "cdbg_exchange_export_packed before cdbg_exchange_sizes_packed");
+    if (nbytes < c->xp_bytes) return fail(CDBG_E_PARAM, "export buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)c->xp_bytes);
+    if (c->xp_bytes) HIPCK(hipMemcpyAsync(dst_dev, c->xp_bases.p, c->xp_bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return CDBG_OK;
+}
+int cdbg_exchange_add_packed(cdbg_ctx* c, uint64_t n_pieces, uint64_t n_bases, uint64_t n_packed, uint64_t n_glog, const void* piece_n, const void* piece_kc,
+                             const void* packed_bases, const void* glog_keys, const void* glog_tag) {
+    if (!c) return fail(CDBG_E_PARAM, "null context");
+    if (!c->mg_open) return fail(CDBG_E_STATE, "cdbg_exchange_add_packed without cdbg_exchange_begin");
+    c->mg_nb = (c->mg_nb + 63) / 64 * 64;                    // 16-byte stores of the streaming unpack
+    if (c->mg_np + n_pieces > c->mg_cap_p || c->mg_nb + n_bases > c->mg_cap_b || c->mg_nl + n_glog > c->mg_cap_l)
+        return fail(CDBG_E_PARAM, "cdbg_exchange_add_packed exceeds the totals given to cdbg_exchange_begin");
+    if (2 * (c->mg_np + n_pieces) >= 0x7FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 31-bit end ids");
+    if (n_packed != (n_bases + 63) / 64 * 16) return fail(CDBG_E_PARAM, "packed size %llu does not match %llu bases", (unsigned long long)n_packed, (unsigned long long)n_bases);
+    hipStream_t s = c->stream;
+    // offsets of the source rank's pieces inside its gap-free stream, recomputed here from its piece_n
+    // (context members: a step must not allocate or free device memory once the buffers of the first step exist)
+    DBuf<uint32_t>& lens = c->xr_lens; DBuf<uint64_t>& uoff = c->xr_uoff;
+    CK(lens.alloc(n_pieces, false)); CK(uoff.alloc(n_pieces + 1, false));
+    if (n_pieces) {
+        PackLenParams lp{ n_pieces, c->k, (const uint32_t*)piece_n, lens.p };
+        CDBG_LAUNCH(k_pack_lens, (n_pieces + 255) / 256, 256, s, lp);
+    }
+    CK(exscan_u32(c, lens.p, uoff.p, n_pieces));
+    HIPCK(hipStreamSynchronize(s));
+    uint64_t tu = 0; CK(read_u64(uoff.p + n_pieces, &tu));
+    if (tu != n_bases) return fail(CDBG_E_PARAM, "piece lengths (%llu bases) do not match the packed stream (%llu bases)", (unsigned long long)tu, (unsigned long long)n_bases);
+    const uint64_t chunks = (n_bases + 63) / 64;
+    if (chunks) {
+        StreamUnpackParams up{ chunks, (const uint8_t*)packed_bases, c->mg_bases.p + c->mg_nb, n_bases };
+        CDBG_LAUNCH(k_unpack_stream, (chunks + 255) / 256, 256, s, up);
+    }
+    MergeParams mp{ n_pieces, n_glog, c->mg_np, c->mg_nb, c->mg_nl, c->W,
+                    (const uint32_t*)piece_n, (const uint64_t*)piece_kc, uoff.p, (const uint64_t*)glog_keys, (const uint32_t*)glog_tag,
+                    c->mg_n.p, c->mg_kc.p, c->mg_boff.p, c->mg_gkeys.p, c->mg_gtag.p };
+    const uint64_t work = std::max(n_pieces, n_glog);
+    if (work) CDBG_LAUNCH(k_merge_append, std::min<uint64_t>((work + 255) / 256, MAX_GRID), 256, s, mp);
+    HIPCK(hipStreamSynchronize(s));
     c->mg_np += n_pieces; c->mg_nb += n_bases; c->mg_nl += n_glog;
     return CDBG_OK;
 }

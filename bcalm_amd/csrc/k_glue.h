@@ -258,9 +258,72 @@ __global__ void k_decode_solid(DecodeParams P) {
 // ---- multi-GPU merge: append one rank's pieces / glue log to the merged arrays, renumbering ----
 struct MergeParams {
     uint64_t n_pieces, n_glog, piece_base, bases_base, glog_base; int W;
-    const uint32_t* src_n; const uint64_t* src_kc; const uint64_t* src_boff; const uint64_t* src_gkeys; const uint32_t* src_gtag;
+    const uint32_t* src_n; const uint64_t* src_kc; const uint64_t* src_boff; const uint64_t* src_gkeys; const uint32_t* src_gtag;   // src_boff: offsets inside the source's base array (packed exchange: inside its gap-free stream)
     uint32_t* dst_n; uint64_t* dst_kc; uint64_t* dst_boff; uint64_t* dst_gkeys; uint32_t* dst_gtag;
 };
+// ---- packed piece bases for the wire: the pieces' bases as ONE gap-free stream, 4 bases per byte ----
+// lens[i] = bases of piece i (0 for ids inside reservation gaps)
+struct PackLenParams { uint64_t n_pieces; int k; const uint32_t* piece_n; uint32_t* lens; };
+__global__ void k_pack_lens(PackLenParams P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_pieces) return;
+    const uint32_t n = P.piece_n[i];
+    P.lens[i] = n ? n + (uint32_t)P.k - 1u : 0u;
+}
+// sender, step 1: squeeze the reservation gaps out (one lane per piece; only this rank's own pieces)
+struct SqueezeParams { uint64_t n_pieces; const uint32_t* lens; const uint64_t* uoff; const uint64_t* boff; const uint8_t* bases; uint8_t* dense; };
+__global__ void k_squeeze_bases(SqueezeParams P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_pieces) return;
+    const uint32_t len = P.lens[i];
+    const uint8_t* src = P.bases + P.boff[i];
+    uint8_t* dst = P.dense + P.uoff[i];
+    for (uint32_t j = 0; j < len; ++j) dst[j] = src[j];
+}
+// sender, step 2 / receiver: streaming 64 ASCII bases <-> 16 packed bytes per lane (dense is padded to 64 bytes)
+struct StreamPackParams { uint64_t n_chunks; const uint8_t* ascii; uint8_t* packed; uint64_t n_bases; };
+__global__ void k_pack_stream(StreamPackParams P) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.n_chunks) return;
+    uint32_t out[4] = {0, 0, 0, 0};
+    const uint4* src = reinterpret_cast<const uint4*>(P.ascii + 64 * c);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 v = src[q];
+        const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t x = w[t], code = ((x >> 1) ^ (x >> 2)) & 0x03030303u;      // 2-bit code of each of 4 ASCII bases
+            out[q] |= ((code & 3u) | ((code >> 6) & 0xCu) | ((code >> 12) & 0x30u) | ((code >> 18) & 0xC0u)) << (8 * t);
+        }
+    }
+    uint4 o; o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3];
+    reinterpret_cast<uint4*>(P.packed)[c] = o;
+}
+struct StreamUnpackParams { uint64_t n_chunks; const uint8_t* packed; uint8_t* ascii; uint64_t n_bases; };
+__global__ void k_unpack_stream(StreamUnpackParams P) {        // the last chunk may be partial
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.n_chunks) return;
+    const uint4 v = reinterpret_cast<const uint4*>(P.packed)[c];
+    const uint32_t in[4] = { v.x, v.y, v.z, v.w };
+    uint8_t* dst = P.ascii + 64 * c;
+    const uint64_t left = P.n_bases - 64 * c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t b = (in[q] >> (8 * t)) & 0xFFu;
+            uint32_t x = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x |= (uint32_t)(uint8_t)("ACGT"[(b >> (2 * u)) & 3u]) << (8 * u);
+            w[t] = x;
+        }
+        if (left >= (uint64_t)(16 * q + 16)) { uint4 o; o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3]; *reinterpret_cast<uint4*>(dst + 16 * q) = o; }
+        else { for (int j = 0; j < 16; ++j) if ((uint64_t)(16 * q + j) < left) dst[16 * q + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3))); }
+    }
+}
+
 __global__ void k_merge_append(MergeParams P) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

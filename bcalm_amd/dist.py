@@ -3,8 +3,8 @@ xGMI on the GPU box; "gloo" in the CPU tests with the simulator library).
 
 Minimizer partitions are sharded over the ranks (cdbg_params.world_size / rank): every rank scans
 the same resident reads and counts / compacts only the partitions it owns.  What has to cross
-ranks are the glue records: pieces (length, abundance, bases) and the glue log (junction key,
-piece-end id / CONFIRM).  They are gathered with all_gather_into_tensor and merged in rank order
+ranks are the glue records: pieces (length, abundance, bases packed 4 per byte) and the glue log
+(junction key, piece-end id / CONFIRM).  They are gathered with all_gather_into_tensor and merged in rank order
 by libcdbg (cdbg_exchange_*).  The junction hash-join over the union is sharded by key hash
 (cdbg_glue_join) and its result, one partner id per piece end, is combined with a MAX all-reduce;
 every rank then ranks the chains and emits, and holds the complete unitig set.  torch only moves
@@ -14,36 +14,44 @@ from __future__ import annotations
 
 import torch
 
-# (export kind, bytes per item given W) in the order cdbg_exchange_add expects them
-_KINDS = [(0, lambda W: 4, 0), (1, lambda W: 8, 0), (2, lambda W: 8, 0), (3, lambda W: 1, 1), (4, lambda W: 8 * W, 2), (5, lambda W: 4, 2)]
+
+def _gather_bytes(dist, device, world, graph, nbytes_per_rank, export):
+    """all-gather one variable-length byte array (padded to the longest rank); -> (tensor, stride)"""
+    pad = max(max(nbytes_per_rank), 16)
+    pad = (pad + 15) // 16 * 16
+    send = torch.empty(pad, dtype=torch.uint8, device=device)
+    export(send.data_ptr(), pad)
+    recv = torch.empty(world * pad, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(recv, send)
+    return recv, pad
 
 
 def exchange_glue(graph, dist, device, W: int, sharded_join: bool = True):
-    """all-gather every rank's pieces + glue log and merge them into `graph` (stage: compacted)."""
+    """all-gather every rank's pieces + glue log and merge them into `graph` (stage: compacted).
+    On the wire per rank: piece lengths (u32), piece abundance sums (u64), piece bases packed 4 per byte with the
+    reservation gaps squeezed out (no base offsets: the receiver recomputes them), glue-log keys and tags."""
     world = dist.get_world_size()
     device = torch.device(device)
-    mine = torch.tensor(graph.exchange_sizes(), dtype=torch.int64, device=device)
-    sizes = torch.empty(world * 3, dtype=torch.int64, device=device)
+    mine = torch.tensor(graph.exchange_sizes_packed(), dtype=torch.int64, device=device)      # pieces, bases, glog, packed bytes
+    sizes = torch.empty(world * 4, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(sizes, mine)
-    sizes = sizes.view(world, 3).cpu().tolist()
-    gathered = []
-    for kind, bpi, which in _KINDS:
-        item = bpi(W)
-        nbytes = [int(sizes[r][which]) * item for r in range(world)]
-        pad = max(max(nbytes), 16)
-        pad = (pad + 15) // 16 * 16
-        send = torch.empty(pad, dtype=torch.uint8, device=device)
-        graph.exchange_export(kind, send.data_ptr(), pad)
-        recv = torch.empty(world * pad, dtype=torch.uint8, device=device)
-        dist.all_gather_into_tensor(recv, send)
-        gathered.append((recv, pad))
+    sizes = sizes.view(world, 4).cpu().tolist()
+    col = lambda j: [int(sizes[r][j]) for r in range(world)]
+    parts = [
+        _gather_bytes(dist, device, world, graph, [n * 4 for n in col(0)], lambda p, n: graph.exchange_export(0, p, n)),          # piece_n
+        _gather_bytes(dist, device, world, graph, [n * 8 for n in col(0)], lambda p, n: graph.exchange_export(1, p, n)),          # piece_kc
+        _gather_bytes(dist, device, world, graph, col(3), lambda p, n: graph.exchange_export_packed(p, n)),                        # packed bases
+        _gather_bytes(dist, device, world, graph, [n * 8 * W for n in col(2)], lambda p, n: graph.exchange_export(4, p, n)),      # glog keys
+        _gather_bytes(dist, device, world, graph, [n * 4 for n in col(2)], lambda p, n: graph.exchange_export(5, p, n)),          # glog tags
+    ]
     if device.type == "cuda":
         torch.cuda.synchronize(device)                   # collectives run on torch's stream, libcdbg on its own
-    totals = [sum(int(sizes[r][j]) for r in range(world)) for j in range(3)]
+    totals = [sum(col(j)) for j in range(3)]
     graph.exchange_begin(*totals)
     for r in range(world):
-        ptrs = [recv.data_ptr() + r * pad for recv, pad in gathered]
-        graph.exchange_add(int(sizes[r][0]), int(sizes[r][1]), int(sizes[r][2]), ptrs)
+        ptrs = [recv.data_ptr() + r * pad for recv, pad in parts]
+        graph.exchange_add_packed(int(sizes[r][0]), int(sizes[r][1]), int(sizes[r][3]), int(sizes[r][2]), ptrs)
+    gathered = parts
     graph.exchange_end()
     info = {"pieces": totals[0], "piece_bases": totals[1], "glue_records": totals[2],
             "bytes_gathered": sum(recv.numel() for recv, _ in gathered)}

@@ -110,6 +110,16 @@ int cdbg_exchange_add(cdbg_ctx* ctx, uint64_t n_pieces, uint64_t n_bases, uint64
                       const void* piece_kc, const void* piece_boff, const void* bases, const void* glog_keys,
                       const void* glog_tag);
 int cdbg_exchange_end(cdbg_ctx* ctx);
+/* Packed variant (what bcalm_amd/dist.py uses): the piece bases travel as ONE gap-free stream at 2 bits per base (padded
+ * to 64 bases) and the base offsets do not travel -- the receiver recomputes them from the piece lengths.  cdbg_exchange_sizes_packed packs and returns {piece ids, bases once unpacked, glue-log records, packed bytes};
+ * piece_n / piece_kc / glue-log arrays are exported with cdbg_exchange_export (what = 0, 1, 4, 5), the packed bases with
+ * cdbg_exchange_export_packed; cdbg_exchange_begin takes the totals of the first three; one cdbg_exchange_add_packed per
+ * rank in rank order; cdbg_exchange_end as before. */
+int cdbg_exchange_sizes_packed(cdbg_ctx* ctx, uint64_t out[4]);
+int cdbg_exchange_export_packed(cdbg_ctx* ctx, void* dst_dev, uint64_t nbytes);
+int cdbg_exchange_add_packed(cdbg_ctx* ctx, uint64_t n_pieces, uint64_t n_bases, uint64_t n_packed, uint64_t n_glog,
+                             const void* piece_n, const void* piece_kc, const void* packed_bases, const void* glog_keys,
+                             const void* glog_tag);
 /* Sharded junction join (optional, after cdbg_exchange_end): instead of every rank hash-joining ALL glue
  * records inside cdbg_glue, cdbg_glue_join joins only the junctions whose key hash selects this rank and
  * leaves link[end] = -1 for the others.  The caller exports the int32 link array (n_ends entries), combines

@@ -305,3 +305,32 @@ def test_two_rank_flow_on_one_device(oracle, hip):
         sets.append(oracle_lib.canonical_set(oracle, g.unitigs(), 31))
         g.close()
     assert sets[0] == sets[1] == exp["unitigs"]
+    # the packed exchange (2-bit bases, no offsets on the wire: what bcalm_amd/dist.py ships) through the same emulation
+    gs = []
+    for r in range(world):
+        g = bcalm_amd.Graph(31, 2, lib=hip, world_size=world, rank=r)
+        g.push_text(text); g.count(); g.compact()
+        gs.append(g)
+    psizes = [g.exchange_sizes_packed() for g in gs]
+    assert all(ps[3] * 3 < ps[1] for ps in psizes)            # packed bytes ~ bases / 4 (+ padding)
+    pbufs = []
+    for r, g in enumerate(gs):
+        row = []
+        for kind, nb in ((0, psizes[r][0] * 4), (1, psizes[r][0] * 8), (None, psizes[r][3]), (4, psizes[r][2] * 8), (5, psizes[r][2] * 4)):
+            t = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+            if kind is None:
+                g.exchange_export_packed(t.data_ptr(), t.numel())
+            else:
+                g.exchange_export(kind, t.data_ptr(), t.numel())
+            row.append(t)
+        pbufs.append(row)
+    ptot = [sum(psizes[r][j] for r in range(world)) for j in range(3)]
+    g = gs[0]
+    g.exchange_begin(*ptot)
+    for r in range(world):
+        g.exchange_add_packed(psizes[r][0], psizes[r][1], psizes[r][3], psizes[r][2], [t.data_ptr() for t in pbufs[r]])
+    g.exchange_end()
+    g.glue()                                                  # unsharded join on the union
+    assert oracle_lib.canonical_set(oracle, g.unitigs(), 31) == exp["unitigs"]
+    for g in gs:
+        g.close()
