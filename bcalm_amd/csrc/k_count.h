@@ -413,14 +413,14 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                         }
                     }
                     clean = by_list;
-                    uint32_t pk0 = st_dist, pk1 = st_sh | (st_st << 16);
+                    // (full 32-bit sums: a giant partition -- one bucket for the whole input -- overflows 16-bit fields)
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) { pk0 += __shfl_xor(pk0, d); pk1 += __shfl_xor(pk1, d); st_occ += __shfl_xor(st_occ, d); }
+                    for (int d = 32; d >= 1; d >>= 1) { st_dist += __shfl_xor(st_dist, d); st_occ += __shfl_xor(st_occ, d); st_sh += __shfl_xor(st_sh, d); st_st += __shfl_xor(st_st, d); }
                     if (lane == 0) {
-                        if (pk0) atomic_add_u32(&s_stat[0], pk0);
+                        if (st_dist) atomic_add_u32(&s_stat[0], st_dist);
                         if (st_occ) atomic_add_u32(&s_stat[1], st_occ);
-                        if (pk1 & 0xFFFFu) atomic_add_u32(&s_stat[2], pk1 & 0xFFFFu);
-                        if (pk1 >> 16) atomic_add_u32(&s_stat[3], pk1 >> 16);
+                        if (st_sh) atomic_add_u32(&s_stat[2], st_sh);
+                        if (st_st) atomic_add_u32(&s_stat[3], st_st);
                     }
                     block_sync<GLOBAL>();
                     if (tid == 0) {
@@ -450,14 +450,14 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                             }
                         }
                     }
-                    uint32_t pk0 = st_dist, pk1 = st_sh | (st_st << 16);
+                    // (full 32-bit sums: a giant partition -- one bucket for the whole input -- overflows 16-bit fields)
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) { pk0 += __shfl_xor(pk0, d); pk1 += __shfl_xor(pk1, d); st_occ += __shfl_xor(st_occ, d); }
+                    for (int d = 32; d >= 1; d >>= 1) { st_dist += __shfl_xor(st_dist, d); st_occ += __shfl_xor(st_occ, d); st_sh += __shfl_xor(st_sh, d); st_st += __shfl_xor(st_st, d); }
                     if (lane == 0) {
-                        if (pk0) atomic_add_u32(&s_stat[0], pk0);
+                        if (st_dist) atomic_add_u32(&s_stat[0], st_dist);
                         if (st_occ) atomic_add_u32(&s_stat[1], st_occ);
-                        if (pk1 & 0xFFFFu) atomic_add_u32(&s_stat[2], pk1 & 0xFFFFu);
-                        if (pk1 >> 16) atomic_add_u32(&s_stat[3], pk1 >> 16);
+                        if (st_sh) atomic_add_u32(&s_stat[2], st_sh);
+                        if (st_st) atomic_add_u32(&s_stat[3], st_st);
                     }
                     block_sync<GLOBAL>();
                     CDBG_PH(3);
@@ -474,15 +474,17 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     }
                     // wave-level tree reduction first (an LDS atomic with per-lane values is serialised
                     // lane by lane by the compiler), then one LDS atomic per wave and counter
-                    uint32_t pk0 = st_dist | (my_solid << 16), pk1 = st_sh | (st_st << 16);
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) { pk0 += __shfl_xor(pk0, d); pk1 += __shfl_xor(pk1, d); st_occ += __shfl_xor(st_occ, d); }
+                    for (int d = 32; d >= 1; d >>= 1) {
+                        my_solid += __shfl_xor(my_solid, d); st_dist += __shfl_xor(st_dist, d); st_occ += __shfl_xor(st_occ, d);
+                        st_sh += __shfl_xor(st_sh, d); st_st += __shfl_xor(st_st, d);
+                    }
                     if (lane == 0) {
-                        if (pk0 >> 16) atomic_add_u32(&s_nsolid, pk0 >> 16);
-                        if (pk0 & 0xFFFFu) atomic_add_u32(&s_stat[0], pk0 & 0xFFFFu);
+                        if (my_solid) atomic_add_u32(&s_nsolid, my_solid);
+                        if (st_dist) atomic_add_u32(&s_stat[0], st_dist);
                         if (st_occ) atomic_add_u32(&s_stat[1], st_occ);
-                        if (pk1 & 0xFFFFu) atomic_add_u32(&s_stat[2], pk1 & 0xFFFFu);
-                        if (pk1 >> 16) atomic_add_u32(&s_stat[3], pk1 >> 16);
+                        if (st_sh) atomic_add_u32(&s_stat[2], st_sh);
+                        if (st_st) atomic_add_u32(&s_stat[3], st_st);
                     }
                     block_sync<GLOBAL>();
                     if (pass == npass - 1 && tid == 0) {          // everything counted: reserve the segment

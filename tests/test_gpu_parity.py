@@ -334,3 +334,16 @@ def test_two_rank_flow_on_one_device(oracle, hip):
     assert oracle_lib.canonical_set(oracle, g.unitigs(), 31) == exp["unitigs"]
     for g in gs:
         g.close()
+
+
+def test_one_giant_partition_statistics(oracle, hip):
+    """the whole input in ONE partition (log2_partitions = 0, abundance-min 1): 300 K solid k-mers go through the
+    HBM-table fallbacks of count and compact; found by bench_micro/fuzz_gpu.py -- the per-partition statistics were
+    reduced in 16-bit fields and n_solid (which sizes the later stages) came out short"""
+    rng = random.Random(5)
+    g = "".join(rng.choice("ACGT") for _ in range(300000))
+    text = g + "\n" + g[1000:5000] + "\n"
+    for k in (21, 61):
+        exp = oracle.run(text, k, 1)
+        got = assert_parity(oracle, hip, text, k, 1, log2_partitions=0)
+        assert got["stats"]["n_solid"] == exp["stats"]["solid"] == got["stats"]["n_distinct"]
