@@ -112,6 +112,12 @@ uint64_t resident_grid(K kern, int threads, uint64_t fallback) {
 constexpr uint64_t CHUNK_SLACK_WGS = 3 * (PERSISTENT_GRID + 1);
 constexpr uint64_t MAX_GRID = 1u << 22;          // workgroups per launch (grid * block must stay < 2^32)
 uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
+// slots of a junction table: 32-bit slot indices
+int glue_table_slots(uint64_t want, uint32_t* out) {
+    const uint64_t p = pow2_at_least(want);
+    if (p > (1ull << 31)) return fail(CDBG_E_INTERNAL, "junction table of %llu slots exceeds 32-bit slot indices: shard the input over more GPUs", (unsigned long long)p);
+    *out = (uint32_t)p; return CDBG_OK;
+}
 
 }  // namespace
 
@@ -500,7 +506,7 @@ int compact_impl(cdbg_ctx* c) {
     const uint64_t S = c->st.n_solid;
     Timer t; CK(t.start(s));
     // glue table: at most one junction per solid traveller entry
-    c->glue_cap = (uint32_t)pow2_at_least(2 * c->st.n_solid_travellers + 64);
+    CK(glue_table_slots(2 * c->st.n_solid_travellers + 64, &c->glue_cap));
     CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false));
     CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
     CK(c->cursors.alloc(8, false));
@@ -608,7 +614,7 @@ int glue_join_impl(cdbg_ctx* c, bool sharded) {
     HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
     const uint32_t world = sharded ? (uint32_t)c->prm.world_size : 1u;
     if (world > 1) {                                         // a table for this rank's share of the junctions
-        c->glue_cap = (uint32_t)pow2_at_least((c->n_glog + c->n_glog / 4) / world + (c->n_glog >> 6) + 1024);
+        CK(glue_table_slots((c->n_glog + c->n_glog / 4) / world + (c->n_glog >> 6) + 1024, &c->glue_cap));
         CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false));
         CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
         HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), s));
@@ -1100,7 +1106,7 @@ int cdbg_exchange_end(cdbg_ctx* c) {
     // junction table for the union: at most one junction per glue record (typically 2-3 records per
     // junction, so 1.25 x records keeps the load factor below one half in practice and below 0.8 always)
     const int W = c->W;
-    c->glue_cap = (uint32_t)pow2_at_least(c->n_glog + c->n_glog / 4 + 64);
+    CK(glue_table_slots(c->n_glog + c->n_glog / 4 + 64, &c->glue_cap));
     CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false));
     CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
     HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), c->stream));
