@@ -3,7 +3,13 @@ import sys, os, time, random, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib, bcalm_amd
-orc = oracle_lib.load(); lib = bcalm_amd.load()
+orc = oracle_lib.load()
+SIM = os.environ.get('FUZZ_SIM') == '1'            # same fuzzer through the CPU simulator build (small cases)
+if SIM:
+    import hostsim_lib
+    lib = hostsim_lib.load()
+else:
+    lib = bcalm_amd.load()
 budget = float(sys.argv[1]); seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 only = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else None
 dump = os.environ.get('FUZZ_DUMP')
@@ -39,7 +45,7 @@ while time.time() < t_end:
         reads.append(r)
     if rng.random() < 0.2: reads.append(g + g[:k - 1])          # whole (circularised) genome as one read
     text = "\n".join(reads) + "\n"
-    if len(text) > 6_000_000: continue
+    if len(text) > (60_000 if SIM else 6_000_000): continue
     if only and it not in only: continue
     if dump: open(os.path.join(dump, 'fuzz_%d_%d.txt' % (seed0, it)), 'w').write(text)
     params = dict(k=k, amin=amin, log2_partitions=rng.choice([-1, -1, 0, 3, 8, 12]), minimizer_size=rng.choice([0, 0, 0, min(k - 1, rng.randrange(2, 17))]))
