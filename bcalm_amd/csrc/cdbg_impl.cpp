@@ -136,6 +136,7 @@ struct cdbg_ctx {
     int pin_cur = 0; uint64_t pin_fill = 0; hipStream_t copy_stream{};
     uint64_t n_dev = 0;                          // bytes of text already on (or on their way to) the device
     bool reads_final = false;                    // text complete, padded, nbytes set
+    int log_np_override = -1;                    // set when a first count showed buckets too full for the LDS compaction tiers
     DBuf<uint8_t> reads; uint64_t nbytes = 0, nbytes_padded = 0;
 
     DBuf<uint32_t> part_count, spill_part; DBuf<uint64_t> part_off, part_cursor, records, exscan_tmp, spill_recs;
@@ -265,7 +266,7 @@ void configure(cdbg_ctx* c) {
 #define CDBG_OCC_DEN 2
 #endif
     const uint64_t target_occ = (uint64_t)ts * CDBG_OCC_NUM / CDBG_OCC_DEN;
-    int log_np = c->prm.log2_partitions;
+    int log_np = c->log_np_override >= 0 ? c->log_np_override : c->prm.log2_partitions;
     if (log_np < 0) {
         log_np = 0;
         while (log_np < 24 && ((uint64_t)1 << log_np) * target_occ < c->nbytes) ++log_np;
@@ -857,7 +858,30 @@ int cdbg_read_text(cdbg_ctx* c, uint64_t first_byte, uint64_t nbytes, char* out)
         case 2: return fn<2>(c);                                     \
         default: return fn<4>(c);                                    \
     }
-int cdbg_count(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); if (c->stage != 0) return fail(CDBG_E_STATE, "cdbg_count called twice"); DISPATCH_W(count_impl) }
+static int count_dispatch(cdbg_ctx* c) { DISPATCH_W(count_impl) }
+int cdbg_count(cdbg_ctx* c) {
+    if (!c) return fail(CDBG_E_PARAM, "null context");
+    if (c->stage != 0) return fail(CDBG_E_STATE, "cdbg_count called twice");
+    CK(count_dispatch(c));
+    // Compaction handles a bucket in LDS up to 1024 entries (2 x TSK / 2); beyond that it falls back to tables in HBM,
+    // which is 20-50 x slower per bucket.  The partition count was chosen for the COUNT table (occurrences per
+    // partition); with few k-mers filtered out (abundance-min 1, deep coverage without errors) the solid entries per
+    // bucket can be several times what the compaction tiers hold.  One look at the exact number after counting:
+    // if the mean is above 300 entries, count again with enough partitions for ~150 per bucket (scan + count are
+    // cheap next to the fallback), unless the caller fixed the partition count.
+    const uint64_t per_bucket = (c->st.n_solid + c->st.n_solid_travellers) / std::max<uint64_t>(c->n_local_parts, 1);
+    // (single rank only: with several ranks the decision would have to be taken collectively -- every rank must use the
+    // same partitioning -- and each rank sees only its own shard's counts)
+    if (c->prm.world_size == 1 && c->prm.log2_partitions < 0 && c->log_np_override < 0 && per_bucket > 300 && c->log_np < 26) {
+        int extra = 1; while ((per_bucket >> extra) > 150 && c->log_np + extra < 26) ++extra;
+        const float first_ms = c->st.ms_total;
+        c->log_np_override = c->log_np + extra;
+        c->stage = 0;
+        CK(count_dispatch(c));
+        c->st.ms_total += first_ms;                          // the first attempt is part of the stage's time
+    }
+    return CDBG_OK;
+}
 int cdbg_compact(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(compact_impl) }
 int cdbg_glue(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(glue_impl) }
 // ---- multi-GPU: sharded junction join.  After cdbg_exchange_end every rank holds the union of the glue records;
