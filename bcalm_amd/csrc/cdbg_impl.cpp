@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "k_links.h"
+#include "k_count_fast.h"
 
 using namespace cdbg;
 
@@ -108,8 +109,8 @@ uint64_t resident_grid(K kern, int threads, uint64_t fallback) {
     return fallback;
 }
 // every persistent workgroup of every launch of a stage may leave one partly used output chunk behind: a stage has up to
-// three launches (count: main, spill repair, HBM fallback; compact: two LDS tiers, HBM fallback)
-constexpr uint64_t CHUNK_SLACK_WGS = 3 * (PERSISTENT_GRID + 1);
+// four launches (count: one-pass, multi-pass retry, spill repair, HBM fallback; compact: two LDS tiers, HBM fallback)
+constexpr uint64_t CHUNK_SLACK_WGS = 4 * (PERSISTENT_GRID + 1);
 constexpr uint64_t MAX_GRID = 1u << 22;          // workgroups per launch (grid * block must stay < 2^32)
 uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 // slots of a junction table: 32-bit slot indices
@@ -142,7 +143,7 @@ struct cdbg_ctx {
     DBuf<uint32_t> part_count, spill_part; DBuf<uint64_t> part_off, part_cursor, records, exscan_tmp, spill_recs;
     DBuf<uint64_t> dstats; DBuf<uint32_t> derr;
     DBuf<uint64_t> solid_keys; DBuf<uint32_t> solid_cnt; DBuf<uint64_t> solid_cursor, seg_off; DBuf<uint32_t> seg_n;
-    DBuf<uint32_t> big_list, big_count, big_list2, big_count2;
+    DBuf<uint32_t> big_list, big_count, big_list2, big_count2, retry_list;
     uint64_t n_solid_entries = 0;                // home + traveller solid entries
 
     DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
@@ -430,14 +431,16 @@ int count_impl(cdbg_ctx* c) {
     c->st.n_records = n_records; c->st.n_member_kmers = hs[0];
 
     // count
-    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + CHUNK_SLACK_WGS * (uint64_t)COUNT_CHUNK;
+    // (slack: every persistent workgroup of every launch of the stage may strand one partly used chunk)
+    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + 4 * (std::min<uint64_t>(NPL, PERSISTENT_GRID) + 1) * (uint64_t)COUNT_CHUNK;
     CK(c->solid_keys.alloc(solid_cap * W, false));
     CK(c->solid_cnt.alloc(solid_cap, false));
     CK(c->solid_cursor.alloc(4, true));
     CK(c->seg_off.alloc(NPL, true));
     CK(c->seg_n.alloc(NPL, true));
     CK(c->big_list.alloc(NPL, false));
-    CK(c->big_count.alloc(4, true));
+    CK(c->retry_list.alloc(NPL, false));
+    CK(c->big_count.alloc(4, true));                         // [0] partitions for the HBM pass, [1] partitions for the multi-pass kernel
     HIPCK(hipMemset(c->dstats.p, 0, 32 * sizeof(uint64_t)));
 
     CountParams cp{};
@@ -449,8 +452,23 @@ int count_impl(cdbg_ctx* c) {
     cp.big_list = c->big_list.p; cp.big_count = c->big_count.p; cp.error = c->derr.p;
     CK(t.start(s));
     cp.n_items = (uint32_t)NPL; cp.max_passes = 64;
-    CDBG_LAUNCH((k_count<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, cp);
+    // one-pass kernel over all partitions; the ones whose distinct k-mers do not fit the LDS table at once come back on
+    // the retry list and go through the multi-pass kernel
+    {
+        CountFastParams fp{ cp, c->retry_list.p, c->big_count.p + 1 };
+        if (capped) CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, true>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, fp);
+        else CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, fp);
+    }
     c->st.n_launch_count = NPL;
+    uint32_t nretry = 0;
+    HIPCK(hipStreamSynchronize(s));
+    CK(read_u32(c->big_count.p + 1, &nretry));
+    c->st.n_multipass_partitions = nretry;
+    if (nretry) {
+        CountParams rp1 = cp;
+        rp1.part_list = c->retry_list.p; rp1.n_items = nretry;
+        CDBG_LAUNCH((k_count<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(nretry, PERSISTENT_GRID), Cfg<W>::NTC, s, rp1);
+    }
     if (!spill_parts.empty()) {                              // spilled partitions: count their gathered copies
         CountParams rp2 = cp;
         rp2.records = repair_recs.p; rp2.item_off = repair_off.p; rp2.part_list = repair_part.p; rp2.part_stride = 0;
@@ -488,7 +506,9 @@ int count_impl(cdbg_ctx* c) {
     CK(check_device_error(c, "count"));
     uint64_t cs[4]; CK(read_u64(c->dstats.p, cs, 4));
 #ifdef CDBG_PROFILE_PHASES
-    { uint64_t ph[8]; CK(read_u64(c->dstats.p + 8, ph, 8)); fprintf(stderr, "k_count phase ticks (100MHz wall clock, summed over WGs): part_off %llu clear %llu insert %llu sweep1+reserve %llu write %llu tail %llu\n", (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3], (unsigned long long)ph[4], (unsigned long long)ph[5]); }
+    { uint64_t ph[16]; CK(read_u64(c->dstats.p + 8, ph, 16));
+      for (int w = 0; w < 2; ++w) fprintf(stderr, "k_count_fast phase cycles, %s wave, summed over WGs: loop-end->top %llu | wait own records + stage %llu | insert %llu | barrier A %llu | sweep %llu | barrier B %llu\n", w ? "last" : "first",
+          (unsigned long long)ph[8 * w + 0], (unsigned long long)ph[8 * w + 1], (unsigned long long)ph[8 * w + 2], (unsigned long long)ph[8 * w + 3], (unsigned long long)ph[8 * w + 4], (unsigned long long)ph[8 * w + 5]); }
 #endif
     c->st.n_distinct = cs[0]; c->st.n_occurrences = cs[1]; c->st.n_solid = cs[2]; c->st.n_solid_travellers = cs[3];
     CK(read_u64(c->solid_cursor.p, &c->n_solid_entries));

@@ -60,5 +60,55 @@ CDBG_DEV uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { return atomicOr(p, v)
 CDBG_DEV uint32_t atomic_cas_u32(uint32_t* p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
 CDBG_DEV uint32_t atomic_max_u32(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
 CDBG_DEV uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
+CDBG_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { (void)atomicOr((unsigned long long*)p, (unsigned long long)v); }
+
+// ---- wave64 primitives that do not go through the LDS crossbar ----
+// (measured on MI355X, bench_micro/micro_r02: one ds_bpermute costs ~19 SIMD cycles per wave, a DPP-modified
+// VALU op ~3; the wave scans / broadcasts of the per-partition kernels therefore use DPP and v_readlane)
+#ifdef CDBG_HOSTSIM
+CDBG_DEV uint32_t wave_incl_sum_u32(uint32_t v) {
+    const int lane = (int)(threadIdx.x & 63);
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(v, (unsigned)d); if (lane >= d) v += x; }
+    return v;
+}
+CDBG_DEV uint32_t wave_readlane_u32(uint32_t v, int src_lane) { return __shfl(v, src_lane); }   // src_lane wave-uniform
+CDBG_DEV uint32_t alignbit_u32(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
+#else
+CDBG_DEV uint32_t wave_incl_sum_u32(uint32_t v) {
+    // row_shr:1,2,4,8 inside rows of 16 lanes, then row_bcast:15 / row_bcast:31 across rows; lanes without a source add 0
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+CDBG_DEV uint32_t wave_readlane_u32(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane); }
+CDBG_DEV uint32_t alignbit_u32(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+#endif
+// value known to be identical in every lane -> scalar register (frees VGPRs, makes the address math scalar)
+#ifdef CDBG_HOSTSIM
+CDBG_DEV uint32_t uni_u32(uint32_t v) { return v; }
+#define CDBG_NOINLINE
+#define CDBG_DEV_NOINL inline
+#define CDBG_LDS_BARRIER() __syncthreads()
+#else
+CDBG_DEV uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+#define CDBG_NOINLINE __attribute__((noinline))
+#define CDBG_DEV_NOINL __device__
+// Workgroup barrier for threads that communicate through LDS ONLY.  __syncthreads() carries a workgroup-scope fence
+// over every address space, which on gfx950 becomes s_waitcnt vmcnt(0): each barrier then drains the wave's global
+// loads and stores -- prefetches stop being prefetches and a barrier behind a burst of stores waits for their
+// acknowledgements.  The "local" fences order LDS traffic only (s_waitcnt lgkmcnt(0)); global accesses stay in flight.
+#define CDBG_LDS_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
+                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
+#endif
+CDBG_DEV uint64_t uni_u64(uint64_t v) { return ((uint64_t)uni_u32((uint32_t)(v >> 32)) << 32) | uni_u32((uint32_t)v); }
+CDBG_DEV uint64_t wave_sum_u64(uint64_t v) {        // all lanes -> the wave total (kernel epilogues only)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
 
 }  // namespace cdbg

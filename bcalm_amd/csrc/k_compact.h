@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(COMPACT_THREADS, (W == 2 && TS <= 512 && !GLOB
     bool clean = false;
     for (uint32_t item = blockIdx.x; item < P.n_items; item += gridDim.x) {
         compact_bucket<W, TS, GLOBAL>(P, item, acc, clean, pc_base, pc_left, bc_base, bc_left, lc_base, lc_left, ph, t_prev);
-        __syncthreads();                                 // LDS is reused by the next bucket
+        block_sync<GLOBAL>();                            // LDS is reused by the next bucket
     }
     if (threadIdx.x == 0) for (int i = 0; i < 4; ++i) if (acc[i]) atomic_add_u64(&P.stats[i], acc[i]);
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)

@@ -65,9 +65,8 @@ CDBG_DEV Kmer<W> ktable_key(const KTable<W>& t, uint32_t s) {
 // stale-line case within a CU as well).  LDS tables need only the barrier.
 template <bool GLOBAL>
 CDBG_DEV void block_sync() {
-    if (GLOBAL) __threadfence();
-    __syncthreads();
-    if (GLOBAL) __threadfence();
+    if (GLOBAL) { __threadfence(); __syncthreads(); __threadfence(); }
+    else CDBG_LDS_BARRIER();                             // LDS tables: no need to drain the wave's global loads / stores
 }
 // find-or-insert; returns slot, sets is_new.  GLOBAL selects the fence flavour.
 // Gives up (returns 0xFFFFFFFF) after max_probe occupied slots, so a full table cannot hang a lane.
@@ -90,25 +89,32 @@ CDBG_DEV uint32_t ktable_insert(const KTable<W>& t, const Kmer<W>& key, bool& is
         is_new = old == ~0ULL;
         return hit ? s : 0xFFFFFFFFu;
     } else {
+        // Single-exit loop with the publish INSIDE the iteration that claimed the slot: lanes of one wave that insert
+        // the same key must see the claimer finish before the back edge (a wave has no independent thread scheduling,
+        // so a claimer parked behind the loop exit while a sibling lane spins on PENDING would never run again).
         const uint64_t top = key.w[W - 1];
-        for (uint32_t probes = 0; probes < max_probe;) {
+        uint32_t probes = 0, res = 0xFFFFFFFFu; bool done = false;
+#pragma clang loop unroll(disable)
+        do {
             uint64_t* const claim = &t.keys[(uint64_t)s * W + (W - 1)];
             const uint64_t old = atomic_cas_u64(claim, KEY_EMPTY, top | KEY_PENDING);
+            bool advance = true;
             if (old == KEY_EMPTY) {                          // claimed: write the lower words, then publish the top word
                 for (int i = 0; i < W - 1; ++i) t.keys[(uint64_t)s * W + i] = key.w[i];
                 if (GLOBAL) __threadfence(); else __threadfence_block();
                 atomic_exch_u64(claim, top);
-                is_new = true; return s;
+                is_new = true; res = s; done = true; advance = false;
+            } else if ((old & ~KEY_PENDING) == top) {
+                if (old & KEY_PENDING) { CDBG_SPIN_YIELD(); advance = false; }   // being written by another lane: look again
+                else {
+                    bool eq = true;
+                    for (int i = 0; i < W - 1; ++i) eq &= ((GLOBAL ? ld_agent_u64(&t.keys[(uint64_t)s * W + i]) : t.keys[(uint64_t)s * W + i]) == key.w[i]);
+                    if (eq) { res = s; done = true; advance = false; }
+                }
             }
-            if ((old & ~KEY_PENDING) == top) {
-                if (old & KEY_PENDING) { CDBG_SPIN_YIELD(); continue; }   // another lane is writing this slot: look again
-                bool eq = true;
-                for (int i = 0; i < W - 1; ++i) eq &= ((GLOBAL ? ld_agent_u64(&t.keys[(uint64_t)s * W + i]) : t.keys[(uint64_t)s * W + i]) == key.w[i]);
-                if (eq) return s;
-            }
-            s = (s + 1) & t.mask; ++probes;
-        }
-        return 0xFFFFFFFFu;
+            if (advance) { s = (s + 1) & t.mask; ++probes; }
+        } while (!done && probes < max_probe);
+        return res;
     }
 }
 // lookup only (table no longer being modified); returns slot or 0xFFFFFFFF
@@ -534,6 +540,8 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
         if (npass > P.max_passes) {                               // hopeless in LDS: defer to the HBM pass
             if (tid == 0) {
                 if (reserved) { chunk_base -= ub; chunk_left += ub; }   // hand the whole reservation back
+                // (a partition of the repair launch has no region the HBM pass could read: report instead of dropping it)
+                if (P.item_off) *P.error = 7;
                 const uint32_t i = atomic_add_u32(P.big_count, 1u); P.big_list[i] = p; P.seg_off[p] = 0; P.seg_n[p] = 0;
             }
             return;
@@ -559,7 +567,7 @@ __global__ void __launch_bounds__(NT, (W == 1 && !GLOBAL) ? 6 : 4) k_count(Count
 #endif
     for (uint32_t item = blockIdx.x; item < P.n_items; item += gridDim.x) {
         count_partition<W, TS, NT, GLOBAL>(P, item, acc, start_np, strikes, clean, chunk_base, chunk_left, ph, t_prev);
-        __syncthreads();                                 // LDS is reused by the next partition
+        block_sync<GLOBAL>();                            // LDS is reused by the next partition
         CDBG_PH(5);
     }
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)

@@ -1,0 +1,388 @@
+// k_count_fast.h -- stage 1b, the one-pass kernel: a minimizer partition counted in ONE LDS pass.
+//
+// Same job and same outputs as k_count (k_count.h; SURVEY.md section 8 row a6, abundance filter of
+// /root/reference/README.md:23-25) for the partitions whose distinct k-mers fit the LDS table at once -- at
+// sequencing depth that is all of them.  A partition that does not fit is appended to `retry_list` and counted
+// by the generic multi-pass kernel k_count in a second launch.
+//
+// What the round-1 profile said (k_count VALU bound: 1044 SIMD cycles per 64 member k-mers) and what
+// bench_micro/micro_r02 measured on MI355X: one ds_bpermute costs ~19 SIMD cycles per wave, a 64-bit multiply
+// 18, while LDS CAS64 + add32 sustain 2.2 lane-inserts per clock and CU (28 CU cycles per wave-insert, far from
+// being the limit).  Hence:
+//   * owner search without shuffles: every record of a batch sets the bit of its first member position in a
+//     per-wave LDS mask (ds_or_b64); lane j of step g0 reads the step's mask word (one broadcast read) and
+//     popcounts the bits at or below j -> owning record.  No binary search over ds_bpermute;
+//   * the record is read from the wave's LDS stage at a runtime index (the three dwords that hold the k-mer,
+//     two v_alignbit) instead of four ds_bpermute + a 128-bit funnel shift built from selects;
+//   * hash_lds(): two 32-bit multiplies instead of a 64-bit product;
+//   * statistics live in per-thread registers until the kernel ends (no per-partition wave reductions);
+//   * the output segment is carved from the workgroup's chunk by every thread redundantly (uniform
+//     registers), so a partition costs two workgroup barriers: inserts done / sweep done;
+//   * the wave's records for the NEXT partition and the fill count of the one after are requested right after
+//     the first batch of the current partition has been staged -- behind the only s_waitcnt vmcnt the
+//     iteration needs, so the requests have a whole partition's time to land.
+#pragma once
+#include "k_count.h"
+
+namespace cdbg {
+
+constexpr int COUNT_CB = 16;                            // records per wave batch
+template <int W> struct CountGeom {
+    // member positions of one batch: COUNT_CB records of at most CAPB - k + 1 members, k >= 3 (W = 1), 33, 65
+    static constexpr int KMIN = W == 1 ? 3 : W == 2 ? 33 : 65;
+    static constexpr int NMAX = RecFmt<W>::CAPB - KMIN + 1;
+    static constexpr int MASKW = (COUNT_CB * NMAX + 63) / 64;
+};
+// LDS of one workgroup:
+//   keys / cnt   the open-address table (claim word EMPTY <=> slot free)
+//   stage        per wave: the COUNT_CB records of the batch being expanded
+//   rbase        per wave: 128 - 2k + 2 * (first member position) of each staged record (bit offset of member g = rbase - 2g)
+//   smask        per wave: bit g set <=> a record of the batch starts at member position g
+//   tmask        per wave: bit g set <=> the member at position g is a traveller copy
+template <int W, int TS, int NT>
+struct CountFastLds {
+    uint64_t keys[TS * W];
+    uint32_t cnt[TS];
+    uint64_t stage[(NT / 64) * COUNT_CB * RecFmt<W>::RW + 2];   // + 2: the dword window of the last record may over-read
+    uint64_t smask[(NT / 64) * CountGeom<W>::MASKW];
+    uint64_t tmask[(NT / 64) * CountGeom<W>::MASKW];
+    uint16_t rbase[(NT / 64) * COUNT_CB];
+    uint32_t fill[2], wr[2];                             // per partition parity: new keys / solid entries written
+    uint32_t over;
+    uint64_t cbase;                                      // chunk hand-out broadcast
+};
+
+struct CountFastParams {
+    CountParams c;                                       // part_list / item_off / g_* unused here
+    uint32_t* retry_list; uint32_t* retry_count;         // partitions that need the multi-pass kernel
+};
+
+// raw words of a partition's record range as loaded: resolved one partition later, so that no load is waited for
+// in the partition that issues it (unconditional loads from a clamped index: a select on a loaded value would
+// put an s_waitcnt right behind the load).  CAPPED: fixed-capacity regions + fill counts; else exact offsets.
+template <bool CAPPED> struct CountRaw;
+template <> struct CountRaw<true> { uint32_t f; };
+template <> struct CountRaw<false> { uint64_t a, b; };
+template <bool CAPPED>
+CDBG_DEV CountRaw<CAPPED> count_raw_load(const CountParams& P, uint32_t item) {
+    const uint32_t i = item < P.n_items ? item : P.n_items - 1u;
+    CountRaw<CAPPED> r;
+    if constexpr (CAPPED) r.f = P.part_fill[i];
+    else { r.a = P.part_off[i]; r.b = P.part_off[i + 1]; }
+    return r;
+}
+struct CountRange { uint64_t rec0; uint32_t n; uint32_t p; };      // records [rec0, rec0 + n) of partition p (n == 0: nothing to do here); wave-uniform
+template <bool CAPPED>
+CDBG_DEV CountRange count_raw_resolve(const CountParams& P, uint32_t item, const CountRaw<CAPPED>& w) {
+    CountRange r; r.p = item; r.rec0 = 0; r.n = 0;
+    if (item >= P.n_items) return r;
+    if constexpr (CAPPED) { const uint32_t f = uni_u32(w.f); r.rec0 = (uint64_t)item * P.part_stride; r.n = f > P.part_stride ? 0u : f; }   // spilled: counted by the repair launch
+    else { const uint64_t a = uni_u64(w.a), b = uni_u64(w.b); r.rec0 = a; r.n = (uint32_t)(b - a); }
+    return r;
+}
+// this wave's share of a partition's records: [w0, w1)
+template <int NW>
+CDBG_DEV void count_wave_share(const CountRange& rg, int wave, uint64_t& w0, uint64_t& w1) {
+    const uint64_t per_wave = ((uint64_t)rg.n + NW - 1) / NW;
+    const uint64_t end = rg.rec0 + rg.n;
+    w0 = rg.rec0 + (uint64_t)wave * per_wave;
+    if (w0 > end) w0 = end;
+    w1 = (w0 + per_wave < end) ? w0 + per_wave : end;
+}
+template <int W>
+CDBG_DEV void count_load_chunk(const CountParams& P, uint64_t first, uint64_t end, int lane, RecView<W>& R) {
+    constexpr int RW = RecFmt<W>::RW;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) R.r[i] = 0;
+    if (first + (uint64_t)lane < end) {
+#pragma unroll
+        for (int i = 0; i < RW; ++i) R.r[i] = P.records[(first + lane) * RW + i];
+    }
+}
+struct CountAcc { uint32_t dist, sh, st; uint64_t occ;
+#ifdef CDBG_PROFILE_PHASES
+    uint64_t ph[8], t_prev;
+#endif
+};
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+#define CDBG_FPH(i) do { const uint64_t t_ = clock64(); acc.ph[i] += t_ - acc.t_prev; acc.t_prev = t_; } while (0)
+#else
+#define CDBG_FPH(i) do { } while (0)
+#endif
+// what the kernel's loop carries one partition ahead
+// The loop is unrolled twice over two register sets (ping-pong): a register COPY of a requested value would be its
+// first use and put the wait for it at the end of the partition that issued the request.
+template <int W, bool CAPPED>
+struct CountSet { RecView<W> R; CountRaw<CAPPED> raw; };    // R: this wave's records of a partition; raw: range words of the partition after it
+template <int W, bool CAPPED>
+struct CountAhead { CountSet<W, CAPPED>* cur; CountSet<W, CAPPED>* nxt; CountRange rg_nxt; uint32_t item_nxt, item_nn; bool issued; };
+// resolve the next partition's range from the words requested one partition ago, request this wave's share of its
+// records and the range words of the partition after it
+template <int W, int NW, bool CAPPED>
+CDBG_DEV void count_issue_ahead(const CountParams& P, CountAhead<W, CAPPED>& A, int wave, int lane) {
+    A.rg_nxt = count_raw_resolve<CAPPED>(P, A.item_nxt, A.cur->raw);
+    uint64_t w0, w1; count_wave_share<NW>(A.rg_nxt, wave, w0, w1);
+    count_load_chunk<W>(P, w0, w1, lane, A.nxt->R);
+    A.nxt->raw = count_raw_load<CAPPED>(P, A.item_nn);
+    A.issued = true;
+}
+
+// returns false when the partition did not fit one pass (table left dirty)
+template <int W, int TS, int NT, bool CAPPED>
+CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>& L, const CountRange& rg, CountAhead<W, CAPPED>& A,
+                                   const uint32_t par, uint64_t& chunk_base, uint32_t& chunk_left, CountAcc& acc) {
+    constexpr int RW = RecFmt<W>::RW;
+    constexpr int NW = NT / 64;
+    constexpr int MASKW = CountGeom<W>::MASKW;
+    constexpr int LOG_TS = TS == 8192 ? 13 : TS == 4096 ? 12 : TS == 2048 ? 11 : TS == 1024 ? 10 : TS == 512 ? 9 : -1;
+    static_assert(LOG_TS > 0, "table size");
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)uni_u32((uint32_t)tid >> 6);
+    const int k = P.k;
+    uint64_t* const stage = L.stage + (size_t)wave * COUNT_CB * RW;
+    uint64_t* const smask = L.smask + (size_t)wave * MASKW;
+    uint64_t* const tmask = L.tmask + (size_t)wave * MASKW;
+    uint16_t* const rbase = L.rbase + (size_t)wave * COUNT_CB;
+    const uint64_t lane_le = lane == 63 ? ~0ULL : ((2ULL << lane) - 1ULL);      // bits 0 .. lane
+    const uint64_t lane_bit = 1ULL << lane;
+    const uint32_t RBITS = 64u * RW;                                            // bits of a record
+    const uint64_t kmask1 = ~0ULL >> (64 - 2 * (k < 32 ? k : 31));             // (W == 1 only)
+
+    uint64_t w0, w1; count_wave_share<NW>(rg, wave, w0, w1);
+    CDBG_FPH(0);
+    uint32_t n_new = 0;                                                       // wave-uniform: keys this wave added
+    RecView<W> R = A.cur->R;
+    for (uint64_t c0 = w0; c0 < w1; c0 += 64) {                               // wave-uniform
+        if (c0 != w0) count_load_chunk<W>(P, c0, w1, lane, R);                 // (the first 64 records came prefetched)
+        const int nrec = (int)((w1 - c0) < 64 ? (w1 - c0) : 64);
+        const uint32_t n = lane < nrec ? (uint32_t)R.n() : 0u;
+        const uint32_t incl = wave_incl_sum_u32(n);
+        for (int lo = 0; lo < nrec; lo += COUNT_CB) {                         // batches of COUNT_CB records
+            const uint32_t before = lo ? wave_readlane_u32(incl, lo - 1) : 0u;
+            const uint32_t total = wave_readlane_u32(incl, lo + COUNT_CB - 1) - before;
+            const uint32_t excl = incl - n - before;
+            if (lane >= lo && lane < lo + COUNT_CB && n) {
+#pragma unroll
+                for (int i = 0; i < RW; ++i) stage[(lane - lo) * RW + i] = R.r[i];
+                rbase[lane - lo] = (uint16_t)(RBITS - 2u * (uint32_t)k + 2u * excl);
+                atomic_or_u64(&smask[excl >> 6], 1ULL << (excl & 63u));
+                const uint32_t meta = (uint32_t)R.r[0], last = excl + n - 1u;
+                if (meta & 0x100u) atomic_or_u64(&tmask[excl >> 6], 1ULL << (excl & 63u));
+                if (meta & 0x200u) atomic_or_u64(&tmask[last >> 6], 1ULL << (last & 63u));
+            }
+            CDBG_WAVE_SYNC();
+            if (!A.issued) { CDBG_FPH(1); count_issue_ahead<W, NW, CAPPED>(P, A, wave, lane); }        // behind the wait for this partition's own records
+            uint32_t started = 0;                                             // records of the batch that start before the step's window
+            for (uint32_t g0 = 0; g0 < total; g0 += 64) {                     // wave-uniform trip count
+                const uint64_t M = smask[g0 >> 6], T = tmask[g0 >> 6];
+                const uint32_t g = g0 + (uint32_t)lane;
+                const bool active = g < total;
+                const uint32_t slot = started + (uint32_t)__popcll(M & lane_le) - 1u;   // active lanes: >= 0 (member 0 starts record 0)
+                started += (uint32_t)__popcll(M);
+                bool is_new = false;
+                if (active) {
+                    const uint32_t sh = (uint32_t)rbase[slot] - 2u * g;       // the member's k-mer = record bits [sh, sh + 2k)
+                    Kmer<W> fw;
+                    if (W == 1) {
+                        // 128-bit record, sh >= 16: the three dwords from bit sh on, two funnel shifts
+                        const uint32_t* dw = reinterpret_cast<const uint32_t*>(stage + slot * RW) + (sh >> 5);
+                        const uint32_t d0 = dw[0], d1 = dw[1], d2 = dw[2];
+                        const uint32_t lo32 = alignbit_u32(d1, d0, sh), hi32 = alignbit_u32(d2, d1, sh);
+                        fw.w[0] = (((uint64_t)hi32 << 32) | lo32) & kmask1;
+                    } else {
+                        RecView<W> Q;
+#pragma unroll
+                        for (int i = 0; i < RW; ++i) Q.r[i] = stage[slot * RW + i];
+                        fw = Q.kmer((int)((RBITS - sh) / 2u) - k, k);
+                    }
+                    const Kmer<W> rc = fw.rc(k);
+                    const Kmer<W>& can = (rc < fw) ? rc : fw;
+                    uint32_t s = can.hash_lds() >> (32 - LOG_TS);
+                    bool hit;
+                    if (W == 1) {
+                        // only `old` and `s` live out of the probe loop: every flag carried across its back edge costs three
+                        // scalar mask operations per probe, and the longest probe sequence of the 64 lanes sets the trip count
+                        uint32_t probes = 0; uint64_t old;
+#pragma clang loop unroll(disable)
+                        for (;;) {
+                            old = atomic_cas_u64(&L.keys[s], ~0ULL, can.w[0]);
+                            if ((old == ~0ULL) | (old == can.w[0]) | (++probes == 64u)) break;
+                            s = (s + 1) & (TS - 1);
+                        }
+                        is_new = old == ~0ULL;
+                        hit = is_new | (old == can.w[0]);
+                    } else {
+                        const uint64_t top = can.w[W - 1];
+                        uint32_t probes = 0;
+                        hit = false;
+#pragma clang loop unroll(disable)
+                        do {                                                   // (single exit, publish inside the iteration: see ktable_insert)
+                            uint64_t* const claim = &L.keys[(uint64_t)s * W + (W - 1)];
+                            const uint64_t old = atomic_cas_u64(claim, KEY_EMPTY, top | KEY_PENDING);
+                            bool advance = true;
+                            if (old == KEY_EMPTY) {
+                                for (int i = 0; i < W - 1; ++i) L.keys[(uint64_t)s * W + i] = can.w[i];
+                                __threadfence_block();
+                                atomic_exch_u64(claim, top);
+                                is_new = true; hit = true; advance = false;
+                            } else if ((old & ~KEY_PENDING) == top) {
+                                if (old & KEY_PENDING) { CDBG_SPIN_YIELD(); advance = false; }
+                                else {
+                                    bool eq = true;
+                                    for (int i = 0; i < W - 1; ++i) eq &= (L.keys[(uint64_t)s * W + i] == can.w[i]);
+                                    if (eq) { hit = true; advance = false; }
+                                }
+                            }
+                            if (advance) { s = (s + 1) & (TS - 1); ++probes; }
+                        } while (!hit && probes < 64u);
+                    }
+                    if (!hit) L.over = 1;                                      // table (nearly) full: not a one-pass partition
+                    else {
+                        atomic_add_u32(&L.cnt[s], 1u);
+                        if (T & lane_bit) atomic_or_u32(&L.cnt[s], TRAV_FLAG);
+                    }
+                }
+                n_new += (uint32_t)__popcll(__ballot(is_new));
+            }
+            CDBG_WAVE_SYNC();                                                  // every lane has read the stage and the mask
+            if (lane < MASKW && lane <= (int)((total + 63) >> 6)) { smask[lane] = 0; tmask[lane] = 0; }   // hand the masks back clean
+            CDBG_WAVE_SYNC();
+        }
+    }
+    if (!A.issued) count_issue_ahead<W, NW, CAPPED>(P, A, wave, lane);                // (a wave without records of this partition)
+    if (lane == 0 && n_new) atomic_add_u32(&L.fill[par], n_new);
+    CDBG_FPH(2);
+    CDBG_LDS_BARRIER();                                                           // ---- barrier A: all inserts done ----
+    CDBG_FPH(3);
+    const uint32_t need = uni_u32(L.fill[par]);
+    if (uni_u32(L.over) || need > (uint32_t)(TS - TS / 4)) return false;       // uniform
+    if (need > chunk_left) {                                                   // uniform: new chunk (one device atomic per COUNT_CHUNK entries)
+        if (tid == 0) L.cbase = atomic_add_u64(P.solid_cursor, (uint64_t)COUNT_CHUNK);
+        CDBG_LDS_BARRIER();
+        chunk_base = uni_u64(L.cbase); chunk_left = COUNT_CHUNK;
+    }
+    const uint64_t obase = chunk_base;
+    const bool wr_ok = obase + need <= P.solid_cap;
+    if (!wr_ok && tid == 0) *P.error = 1;
+    // sweep: statistics, solid entries out, slots back to EMPTY.  Every thread owns TS / NT slots; all of their LDS reads
+    // are issued first (one wait), the wave's solid entries get their places from ONE returning LDS atomic.
+    {
+        constexpr int SPT = TS / NT;
+        static_assert(TS % NT == 0, "slots per thread");
+        uint64_t topw[SPT]; uint32_t cv[SPT];
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) { const uint32_t sl = (uint32_t)tid + (uint32_t)j * NT; topw[j] = L.keys[(uint64_t)sl * W + (W - 1)]; cv[j] = L.cnt[sl]; }
+        uint32_t my_solid = 0;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const bool used_j = topw[j] != KEY_EMPTY;
+            const uint32_t cn = cv[j] & ~TRAV_FLAG; const bool trav = cv[j] & TRAV_FLAG;
+            if (used_j && !trav) { ++acc.dist; acc.occ += cn; }
+            if (used_j && cn >= P.amin) { ++my_solid; if (trav) ++acc.st; else ++acc.sh; }
+        }
+        const uint32_t incl = wave_incl_sum_u32(my_solid);
+        const uint32_t wave_total = wave_readlane_u32(incl, 63);
+        uint32_t wbase = 0;
+        if (lane == 0 && wave_total) wbase = atomic_add_u32(&L.wr[par], wave_total);
+        wbase = wave_readlane_u32(wbase, 0);
+        uint64_t o = obase + wbase + (incl - my_solid);
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const uint32_t sl = (uint32_t)tid + (uint32_t)j * NT;
+            if (topw[j] == KEY_EMPTY) continue;
+            if ((cv[j] & ~TRAV_FLAG) >= P.amin && wr_ok) {
+#pragma unroll
+                for (int i = 0; i < W - 1; ++i) P.solid_keys[o * W + i] = L.keys[(uint64_t)sl * W + i];
+                P.solid_keys[o * W + (W - 1)] = topw[j];
+                P.solid_cnt[o] = cv[j];
+                ++o;
+            }
+            L.keys[(uint64_t)sl * W + (W - 1)] = KEY_EMPTY;
+            L.cnt[sl] = 0;
+        }
+    }
+    if (tid == 0) { L.fill[par ^ 1u] = 0; L.wr[par ^ 1u] = 0; }               // the next partition's counters (nobody touches them now)
+    CDBG_FPH(4);
+    CDBG_LDS_BARRIER();                                                           // ---- barrier B: sweep done, table clean ----
+    CDBG_FPH(5);
+    const uint32_t used = uni_u32(L.wr[par]);
+    chunk_base += used; chunk_left -= used;                                    // the unused tail of the reservation stays in the chunk
+    if (tid == 0) { P.seg_off[rg.p] = obase; P.seg_n[rg.p] = used; }
+    return true;
+}
+
+// the rare path's table reset, kept out of line so that its address arithmetic is not hoisted into (and spilled
+// around) the partition loop
+template <int W, int TS, int NT>
+CDBG_NOINLINE CDBG_DEV_NOINL void count_fast_clear(CountFastLds<W, TS, NT>& L) {
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < (uint32_t)TS; i += NT) { L.keys[(uint64_t)i * W + (W - 1)] = KEY_EMPTY; L.cnt[i] = 0; }
+    for (uint32_t i = tid; i < (uint32_t)((NT / 64) * CountGeom<W>::MASKW); i += NT) { L.smask[i] = 0; L.tmask[i] = 0; }
+    if (tid == 0) { L.fill[0] = L.fill[1] = 0; L.wr[0] = L.wr[1] = 0; L.over = 0; }
+}
+
+// persistent workgroups, grid-stride over partitions; statistics are accumulated in registers and published once
+// per wave when the kernel ends
+template <int W, int TS, int NT, bool CAPPED>
+__global__ void __launch_bounds__(NT, W == 1 ? 6 : W == 2 ? 4 : 3) k_count_fast(CountFastParams FP) {   // waves per SIMD that the LDS tables allow: 3 workgroups x 2 waves (W = 1)
+    CDBG_SHARED CountFastLds<W, TS, NT> L;
+    const CountParams& P = FP.c;
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)uni_u32((uint32_t)tid >> 6);
+    CountAcc ca; ca.dist = 0; ca.sh = 0; ca.st = 0; ca.occ = 0;
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+    for (int i = 0; i < 8; ++i) ca.ph[i] = 0;
+    ca.t_prev = clock64();
+#endif
+    uint64_t chunk_base = 0; uint32_t chunk_left = 0;
+    count_fast_clear<W, TS, NT>(L);
+    CDBG_LDS_BARRIER();
+    // software pipeline: range words two partitions ahead, this wave's records one partition ahead
+    const uint32_t stride = gridDim.x;
+    CountRange rg_cur = count_raw_resolve<CAPPED>(P, blockIdx.x, count_raw_load<CAPPED>(P, blockIdx.x));
+    CountSet<W, CAPPED> S0, S1;
+    S0.raw = count_raw_load<CAPPED>(P, blockIdx.x + stride);
+    { uint64_t w0, w1; count_wave_share<NW>(rg_cur, wave, w0, w1); count_load_chunk<W>(P, w0, w1, lane, S0.R); }
+    uint32_t par = 0, misses = 0;                        // misses: consecutive partitions that did not fit one pass
+    auto one_partition = [&](CountSet<W, CAPPED>& cur, CountSet<W, CAPPED>& nxt, const uint32_t item) {
+        CountAhead<W, CAPPED> A;
+        A.cur = &cur; A.nxt = &nxt; A.item_nxt = item + stride; A.item_nn = item + 2 * stride; A.issued = false;
+        if (rg_cur.n) {                                  // uniform
+            bool done = false;
+            if (misses < 4) {
+                done = count_partition_fast<W, TS, NT, CAPPED>(P, L, rg_cur, A, par, chunk_base, chunk_left, ca);
+                if (done) { par ^= 1u; misses = 0; }
+                else {                                   // leave a clean table and known counters behind
+                    CDBG_LDS_BARRIER();
+                    count_fast_clear<W, TS, NT>(L);
+                    par = 0; ++misses;
+                    CDBG_LDS_BARRIER();
+                }
+            }
+            if (!done && tid == 0) {                     // (after four misses in a row the workgroup stops trying: an input of mostly distinct k-mers)
+                const uint32_t i = atomic_add_u32(FP.retry_count, 1u);
+                FP.retry_list[i] = rg_cur.p;
+            }
+        }
+        if (!A.issued) count_issue_ahead<W, NW, CAPPED>(P, A, wave, lane);
+        rg_cur = A.rg_nxt;
+    };
+    for (uint32_t item = blockIdx.x; item < P.n_items;) {
+        one_partition(S0, S1, item); item += stride;
+        if (item >= P.n_items) break;
+        one_partition(S1, S0, item); item += stride;
+    }
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+    if (lane == 0 && (wave == 0 || wave == NW - 1)) for (int i = 0; i < 6; ++i) atomic_add_u64(&P.stats[8 + (wave ? 8 : 0) + i], ca.ph[i]);
+#endif
+    {   // statistics: one atomic per wave and counter
+        uint64_t d = wave_sum_u64(ca.dist), o = wave_sum_u64(ca.occ), h = wave_sum_u64(ca.sh), t = wave_sum_u64(ca.st);
+        if (lane == 0) {
+            if (d) atomic_add_u64(&P.stats[0], d);
+            if (o) atomic_add_u64(&P.stats[1], o);
+            if (h) atomic_add_u64(&P.stats[2], h);
+            if (t) atomic_add_u64(&P.stats[3], t);
+        }
+    }
+}
+
+}  // namespace cdbg

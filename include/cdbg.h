@@ -58,6 +58,7 @@ typedef struct cdbg_stats_t {
     int minimizer_size, log2_partitions, kmer_words;
     float ms_scan_hist, ms_scan_emit, ms_count, ms_compact, ms_glue, ms_total;
     uint64_t n_launch_scan, n_launch_count, n_launch_compact;   /* workgroups launched */
+    uint64_t n_multipass_partitions; /* partitions whose distinct k-mers did not fit one LDS pass (multi-pass kernel) */
 } cdbg_stats_t;
 
 /* error codes */

@@ -32,3 +32,23 @@ def assert_parity(oracle, lib, text, k, amin, **kw):
     assert st["n_unitigs"] == exp["stats"]["unitigs"]
     assert oracle_lib.digest_of(canon) == exp["digest"]
     return got
+
+
+def config2_genome(oracle):
+    """BASELINE config 2 shape: one 4.64 Mbp sequence (E. coli MG1655 length; the FASTA itself is not available
+    offline, so a seeded synthetic genome with planted direct and inverted repeats stands in) -> bytes with '\n'"""
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    g0 = bytearray(oracle.synth_reads(1, 4_641_652, 2)[:-1])
+    for i in range(7):                                   # 7 x 5 kbp repeats, alternating strands
+        seg = bytes(g0[100_000 + 50_000 * i:105_000 + 50_000 * i])
+        if i & 1:
+            seg = seg.translate(comp)[::-1]
+        pos = 2_000_000 + 300_000 * i
+        g0[pos:pos + 5000] = seg
+    for i in range(20):                                  # 20 x 1.3 kbp repeats
+        seg = bytes(g0[3_000_000 + 7_000 * i:3_001_300 + 7_000 * i])
+        if i % 3 == 0:
+            seg = seg.translate(comp)[::-1]
+        pos = 500_000 + 60_000 * i
+        g0[pos:pos + 1300] = seg
+    return bytes(g0) + b"\n"

@@ -1,0 +1,167 @@
+"""GPU tests (-m gpu) of exactly the code path bench.py times, of the reference's own checker on
+the HIP output, and of the real `bcalm` CLI binary (HIP build).
+
+  * BENCH_r01 ran `minimizer_size 16, log2_partitions 22` -> k_scan_fast<1, EMIT_CAPPED, 15>, the
+    capped single-pass record layout and sparse partitions: forced here at sizes the oracle
+    finishes in seconds, bit-exact (VERDICT r1 "What's weak" #2).
+  * /root/reference/scripts/unitigEvaluator.cpp:147-217 (prebuilt oracle/_ref/unitigEvaluator)
+    judges the HIP unitigs of the config-2-shaped genome: the only reference-produced verdict
+    available on this machine.
+  * bcalm_amd/_build/bcalm (the replacement of /root/reference/src/main.cpp:26-51 and
+    src/bcalm_1.cpp:49-97) on FASTA, FASTQ.gz and file-list inputs.
+"""
+import gzip
+import os
+import re
+import subprocess
+
+import pytest
+
+import oracle_lib
+from parity import assert_parity, config2_genome
+
+pytestmark = pytest.mark.gpu
+ROOT = oracle_lib.ROOT
+EVAL = os.path.join(ROOT, "oracle", "_ref", "unitigEvaluator")
+BCALM = os.path.join(ROOT, "bcalm_amd", "_build", "bcalm")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import bcalm_amd
+    return bcalm_amd.load()
+
+
+def _run_stats(hip, text, k, amin, **kw):
+    import bcalm_amd
+    g = bcalm_amd.Graph(k, amin, lib=hip, **kw)
+    try:
+        g.push_text(text); g.run()
+        return g.stats(), oracle_lib.canonical_set(oracle_lib.load(), g.unitigs(), k)
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("log_np", [20, 22])
+def test_config3_instantiation_parity(oracle, oracle_1m, hip, log_np, monkeypatch):
+    """k = 31, m = 16 (window of exactly 15 m-mers), 2^20 / 2^22 partitions, capped single-pass scan, 1 M reads:
+    the template instance and layout of the bench line, against the oracle"""
+    monkeypatch.setenv("CDBG_SCAN_MODE", "capped")
+    text, exp = oracle_1m
+    st, canon = _run_stats(hip, text, 31, 2, minimizer_size=16, log2_partitions=log_np)
+    assert st["minimizer_size"] == 16 and st["log2_partitions"] == log_np
+    assert st["n_occurrences"] == exp["stats"]["occurrences"]
+    assert st["n_distinct"] == exp["stats"]["distinct"] and st["n_solid"] == exp["stats"]["solid"]
+    assert canon == exp["unitigs"]
+
+
+def test_config3_instantiation_solid_set(oracle, hip, monkeypatch):
+    """same instantiation, stage-1 surface: the exact (k-mer, count) set"""
+    monkeypatch.setenv("CDBG_SCAN_MODE", "capped")
+    text = oracle.synth_reads(200000, 150, 3)
+    assert_parity(oracle, hip, text, 31, 2, minimizer_size=16, log2_partitions=20)
+    assert_parity(oracle, hip, text, 31, 1, minimizer_size=16, log2_partitions=20)
+
+
+def test_config4_instantiation_parity(oracle, hip, monkeypatch):
+    """k = 55 (two-word k-mers), m = 16, 2^20 partitions, capped scan: the config-4 shape of bench.py --cfg 4"""
+    monkeypatch.setenv("CDBG_SCAN_MODE", "capped")
+    text = oracle.synth_reads(400000, 150, 4)
+    exp = oracle.run(text, 55, 2)
+    st, canon = _run_stats(hip, text, 55, 2, minimizer_size=16, log2_partitions=20)
+    assert st["n_distinct"] == exp["stats"]["distinct"] and st["n_solid"] == exp["stats"]["solid"]
+    assert canon == exp["unitigs"]
+
+
+def test_config5_instantiation_parity(oracle, hip, monkeypatch):
+    """k = 127 (four-word k-mers, generic scan), m = 16, 2^18 partitions, capped scan, 1 kbp reads"""
+    monkeypatch.setenv("CDBG_SCAN_MODE", "capped")
+    text = oracle.synth_reads(30000, 1000, 5)
+    exp = oracle.run(text, 127, 2)
+    st, canon = _run_stats(hip, text, 127, 2, minimizer_size=16, log2_partitions=18)
+    assert st["n_distinct"] == exp["stats"]["distinct"] and st["n_solid"] == exp["stats"]["solid"]
+    assert canon == exp["unitigs"]
+
+
+@pytest.mark.skipif(not os.path.exists(EVAL), reason="oracle/_ref/unitigEvaluator not prebuilt (needs /root/reference at build time)")
+def test_reference_checker_accepts_hip_unitigs(oracle, hip, tmp_path):
+    """the reference's own checker on the GPU output of the config-2 shape (4.64 Mbp genome with planted direct and
+    inverted repeats, k = 31, abundance-min 1): TP == all, FP == FN == 0, no repeated k-mer"""
+    import bcalm_amd
+    k = 31
+    text = config2_genome(oracle)
+    g = bcalm_amd.Graph(k, 1, lib=hip)
+    g.push_text(text); g.run()
+    ut = g.unitigs(); st = g.stats(); g.close()
+    ref = tmp_path / "ref.fa"; utg = tmp_path / "utg.fa"
+    ref.write_text(">genome\n" + text.decode().strip() + "\n")
+    utg.write_text("".join(f">{i}\n{s}\n" for i, (s, _) in enumerate(ut)))
+    out = subprocess.run([EVAL, str(utg), str(ref), str(k), "1"], capture_output=True, text=True, timeout=600).stdout
+    final = out[out.index("FINAL RESULTS"):]
+    nums = re.search(r"FINAL RESULTS:\s*\n(\d+) (\d+)", final)
+    assert nums, out
+    assert int(nums.group(1)) == int(nums.group(2)) == st["n_solid"] == st["n_distinct"]
+    assert re.search(r"ERRONEOUS kmers:\s*0\b", final), final
+    assert re.search(r"MISSING kmers:\s*0\b", final), final
+    assert "REPEATED" not in final
+
+
+def _parse_fa(path, k):
+    recs = []
+    lines = open(path).read().split("\n")
+    for i in range(0, len(lines) - 1, 2):
+        m = re.match(r">(\d+) LN:i:(\d+) KC:i:(\d+) km:f:(\d+\.\d)((?: L:[+-]:\d+:[+-])*) $", lines[i])
+        assert m, lines[i]
+        s = lines[i + 1]
+        assert int(m.group(2)) == len(s)
+        assert abs(float(m.group(4)) - round(int(m.group(3)) / (len(s) - k + 1), 1)) < 1e-9
+        recs.append((s, int(m.group(3))))
+    return recs
+
+
+def test_real_cli_binary_on_gpu(oracle, tmp_path):
+    """the HIP build of the CLI, file to file: FASTA, FASTQ.gz, a file listing both; `<prefix>.unitigs.fa` naming
+    (bcalm_1.cpp:68-74), header grammar (README.md:62-72), error contract (main.cpp:39-48)"""
+    assert os.path.exists(BCALM), "bcalm_amd/_build/bcalm missing: run __graft_entry__.build()"
+    k = 31
+    text = oracle.synth_reads(60000, 150, 3).decode()
+    reads = [r for r in text.split("\n") if r]
+    half = len(reads) // 2
+    fa = tmp_path / "part1.fa"; fq = tmp_path / "part2.fastq.gz"; lst = tmp_path / "list_reads"
+    # FASTA with wrapped lines, lower case and an N; FASTQ gzipped
+    with open(fa, "w") as f:
+        for i, r in enumerate(reads[:half]):
+            r2 = r.lower() if i % 7 == 0 else r
+            f.write(f">r{i} some comment\n{r2[:70]}\n{r2[70:]}\n")
+        f.write(">with_n\nACGTACGTACGTACGTACGTACGTACGTACGTACGTNACGTTTGACCAGTAGGATACCAGATTTAGGACCATTAGGACCAT\n")
+    with gzip.open(fq, "wt") as f:
+        for i, r in enumerate(reads[half:]):
+            f.write(f"@q{i}\n{r}\n+\n{'I' * len(r)}\n")
+    lst.write_text(f"{fa}\n{fq}\n")
+    whole = "\n".join(reads) + "\nACGTACGTACGTACGTACGTACGTACGTACGTACGTNACGTTTGACCAGTAGGATACCAGATTTAGGACCATTAGGACCAT\n"
+    exp_all = oracle.run(whole, k, 2)
+    exp_1 = oracle.run("\n".join(reads[:half]) + "\nACGTACGTACGTACGTACGTACGTACGTACGTACGTNACGTTTGACCAGTAGGATACCAGATTTAGGACCATTAGGACCAT\n", k, 2)
+    exp_2 = oracle.run("\n".join(reads[half:]) + "\n", k, 1)
+
+    r = subprocess.run([BCALM, "-in", str(lst), "-kmer-size", str(k), "-abundance-min", "2", "-gfa"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    recs = _parse_fa(tmp_path / "list_reads.unitigs.fa", k)
+    assert oracle_lib.canonical_set(oracle, recs, k) == exp_all["unitigs"]
+    gfa = (tmp_path / "list_reads.unitigs.gfa").read_text()
+    assert gfa.startswith(f"H\tVN:Z:1.0\tks:i:{k}\n")
+    fa_links = re.findall(r" L:([+-]):(\d+):([+-])", (tmp_path / "list_reads.unitigs.fa").read_text())
+    gfa_links = re.findall(r"^L\t\d+\t([+-])\t(\d+)\t([+-])\t30M$", gfa, flags=re.M)
+    assert sorted(fa_links) == sorted(gfa_links) and len(fa_links) > 0
+
+    r = subprocess.run([BCALM, "-in", str(fa), "-kmer-size", str(k), "-abundance-min", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert oracle_lib.canonical_set(oracle, _parse_fa(tmp_path / "part1.unitigs.fa", k), k) == exp_1["unitigs"]
+
+    r = subprocess.run([BCALM, "-in", str(fq), "-kmer-size", str(k), "-abundance-min", "1", "-out", "fromfq"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert oracle_lib.canonical_set(oracle, _parse_fa(tmp_path / "fromfq.unitigs.fa", k), k) == exp_2["unitigs"]
+
+    r = subprocess.run([BCALM, "-kmer-size", "21"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "EXCEPTION: Specifiy -in" in r.stdout
+    r = subprocess.run([BCALM, "-in", "/nonexistent.fa"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "EXCEPTION:" in r.stdout

@@ -170,21 +170,8 @@ def test_config2_genome_shape(oracle, hip):
     k=31, abundance-min 1: every k-mer distinct -> exercises the multi-pass LDS counting path;
     bit-exact unitig set vs the oracle."""
     import bcalm_amd
-    comp = bytes.maketrans(b"ACGT", b"TGCA")
-    g0 = bytearray(oracle.synth_reads(1, 4_641_652, 2)[:-1])
-    for i in range(7):                                   # 7 x 5 kbp repeats, alternating strands
-        seg = bytes(g0[100_000 + 50_000 * i:105_000 + 50_000 * i])
-        if i & 1:
-            seg = seg.translate(comp)[::-1]
-        pos = 2_000_000 + 300_000 * i
-        g0[pos:pos + 5000] = seg
-    for i in range(20):                                  # 20 x 1.3 kbp repeats
-        seg = bytes(g0[3_000_000 + 7_000 * i:3_001_300 + 7_000 * i])
-        if i % 3 == 0:
-            seg = seg.translate(comp)[::-1]
-        pos = 500_000 + 60_000 * i
-        g0[pos:pos + 1300] = seg
-    text = bytes(g0) + b"\n"
+    from parity import config2_genome
+    text = config2_genome(oracle)
     exp = oracle.run(text, 31, 1)
     g = bcalm_amd.Graph(31, 1, lib=hip)
     g.push_text(text); g.run()
@@ -239,12 +226,11 @@ def test_config5_shape_long_reads_k127(hip):
     assert sum(len(s) - k + 1 for s, _ in ut) == st["n_solid"] and len(ut) == st["n_unitigs"]
 
 
-def test_parity_one_million_reads(oracle, hip):
+def test_parity_one_million_reads(oracle, oracle_1m, hip):
     """bit-exact against the oracle at the largest size the oracle finishes in seconds (1 M x 150 bp, 36 M distinct
     k-mers): single-pass capped scan, persistent kernels with thousands of workgroups, chunked output reservations"""
     import bcalm_amd
-    text = oracle.synth_reads(1000000, 150, 3)
-    exp = oracle.run(text.decode(), 31, 2)
+    text, exp = oracle_1m
     g = bcalm_amd.Graph(31, 2, lib=hip)
     g.push_text(text); g.run()
     got = oracle_lib.canonical_set(oracle, g.unitigs(), 31)
