@@ -24,6 +24,7 @@
 
 #include "k_links.h"
 #include "k_count_fast.h"
+#include "k_compact_wave.h"
 
 using namespace cdbg;
 
@@ -86,10 +87,14 @@ constexpr int TS_COUNT_1 = CDBG_TSC1, TS_COUNT_2 = 2048, TS_COUNT_4 = 1024;     
 // W = 1 does not (its kernel is VALU bound and the denser table costs probes: 84 -> 96 ms), so W = 1 starts at 1024
 constexpr int TS_COMPACT_1 = CDBG_TSK1, TS_COMPACT_2 = 512, TS_COMPACT_4 = 512;
 template <int W> struct Cfg;
-template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1, TSK2 = 2 * TS_COMPACT_1, NTC = CDBG_NTC1; };
-template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, TSK2 = 2 * TS_COMPACT_2, NTC = 512; };
-template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, TSK2 = 2 * TS_COMPACT_4, NTC = 256; };
+// TSW: slots of the wave-per-bucket compaction tier (buckets of at most TSW / 2 entries; k_compact_wave.h)
+template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1, TSK2 = 2 * TS_COMPACT_1, NTC = CDBG_NTC1, TSW = 512; };
+template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, TSK2 = 2 * TS_COMPACT_2, NTC = 512, TSW = 256; };
+template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, TSK2 = 2 * TS_COMPACT_4, NTC = 256, TSW = 128; };
 
+#ifndef CDBG_TSW1
+#define CDBG_TSW1 512
+#endif
 #ifndef CDBG_PGRID
 #define CDBG_PGRID (256 * 12)
 #endif
@@ -535,9 +540,11 @@ int compact_impl(cdbg_ctx* c) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         // glue log: <= 2 open ends + 1 confirm per junction, one junction per solid traveller at most; the tail of a
         // chunk that the next bucket does not fit into is abandoned, hence the generous second attempt
-        c->glog_cap = (attempt == 0 ? 3 : 8) * c->st.n_solid_travellers + (attempt + 1) * CHUNK_SLACK_WGS * (uint64_t)GLOG_CHUNK + 64;
+        // (every persistent wave of tier 0 may strand one partly used chunk of each output array as well)
+        const uint64_t wave_slack = std::min<uint64_t>(NPL, 256ull * 32);
+        c->glog_cap = (attempt == 0 ? 3 : 8) * c->st.n_solid_travellers + (attempt + 1) * (CHUNK_SLACK_WGS * (uint64_t)GLOG_CHUNK + wave_slack * CW_GLOG_CHUNK) + 64;
         CK(c->glog_keys.alloc(c->glog_cap * W, false)); CK(c->glog_tag.alloc(c->glog_cap, false));
-        const uint64_t pslack = CHUNK_SLACK_WGS * (uint64_t)PIECE_CHUNK, bslack = CHUNK_SLACK_WGS * (uint64_t)BASES_CHUNK;
+        const uint64_t pslack = CHUNK_SLACK_WGS * (uint64_t)PIECE_CHUNK + wave_slack * CW_PIECE_CHUNK, bslack = CHUNK_SLACK_WGS * (uint64_t)BASES_CHUNK + wave_slack * CW_BASES_CHUNK;
         const uint64_t pcap = (attempt == 0 ? std::min<uint64_t>(S, S / 3 + 4096) + 16 : S + 16) + pslack;
         const uint64_t bcap = (attempt == 0 ? S + (pcap - pslack) * (uint64_t)(c->k - 1) + 64 : S * (uint64_t)c->k + 64) + bslack;
         CK(c->piece_n.alloc(pcap, false)); HIPCK(hipMemsetAsync(c->piece_n.p, 0, pcap * sizeof(uint32_t), s));
@@ -565,21 +572,35 @@ int compact_impl(cdbg_ctx* c) {
         kp.glog_keys = c->glog_keys.p; kp.glog_tag = c->glog_tag.p; kp.glog_cap = c->glog_cap; kp.glog_cursor = c->cursors.p + 4;
         kp.big_list = c->big_list.p; kp.big_count = c->big_count.p; kp.error = c->derr.p; kp.stats = c->dstats.p;
         kp.n_items = (uint32_t)NPL;
-        CDBG_LAUNCH((k_compact<W, TS, false>), std::min<uint64_t>(NPL, PERSISTENT_GRID), COMPACT_THREADS, s, kp);
-        c->st.n_launch_compact = NPL;
-        HIPCK(hipStreamSynchronize(s));
-        uint32_t nbig = 0; CK(read_u32(c->big_count.p, &nbig));
-        if (nbig) {                                          // second LDS tier: the deferred buckets with a table twice the size
+        // tier 0: one wave per bucket (k_compact_wave.h); buckets beyond its table come back on big_list
+        uint32_t nbig = 0;
+        {
+            CompactWaveParams wp{ kp, (uint32_t)NPL, reinterpret_cast<uint32_t*>(c->cursors.p + 5) };
+            const uint64_t wgrid = resident_grid(k_compact_wave<W, Cfg<W>::TSW>, CW_THREADS, 256 * 3);
+            CDBG_LAUNCH((k_compact_wave<W, Cfg<W>::TSW>), std::min<uint64_t>((NPL + CW_THREADS / 64 - 1) / (CW_THREADS / 64), wgrid), CW_THREADS, s, wp);
+            c->st.n_launch_compact = NPL;
+            HIPCK(hipStreamSynchronize(s));
+            CK(read_u32(c->big_count.p, &nbig));
+        }
+        if (nbig) {                                          // tier 1: a workgroup per bucket, LDS table of TS slots
             CK(c->big_list2.alloc(nbig, false)); CK(c->big_count2.alloc(4, true));
-            CompactParams k2 = kp;
-            k2.part_list = c->big_list.p; k2.n_items = nbig; k2.big_list = c->big_list2.p; k2.big_count = c->big_count2.p;
-            CDBG_LAUNCH((k_compact<W, Cfg<W>::TSK2, false>), std::min<uint64_t>(nbig, PERSISTENT_GRID), COMPACT_THREADS, s, k2);
+            CompactParams k1 = kp;
+            k1.part_list = c->big_list.p; k1.n_items = nbig; k1.big_list = c->big_list2.p; k1.big_count = c->big_count2.p;
+            CDBG_LAUNCH((k_compact<W, TS, false>), std::min<uint64_t>(nbig, PERSISTENT_GRID), COMPACT_THREADS, s, k1);
             HIPCK(hipStreamSynchronize(s));
             CK(read_u32(c->big_count2.p, &nbig));
         }
+        if (nbig) {                                          // tier 2: the deferred buckets with a table twice the size
+            HIPCK(hipMemsetAsync(c->big_count.p, 0, 4 * sizeof(uint32_t), s));
+            CompactParams k2 = kp;
+            k2.part_list = c->big_list2.p; k2.n_items = nbig; k2.big_list = c->big_list.p; k2.big_count = c->big_count.p;
+            CDBG_LAUNCH((k_compact<W, Cfg<W>::TSK2, false>), std::min<uint64_t>(nbig, PERSISTENT_GRID), COMPACT_THREADS, s, k2);
+            HIPCK(hipStreamSynchronize(s));
+            CK(read_u32(c->big_count.p, &nbig));
+        }
         DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_cnt, g_lnk, g_aux;
         if (nbig) {                                          // buckets with more entries than fit LDS
-            std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list2.p, bl.data(), nbig));
+            std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list.p, bl.data(), nbig));
             std::sort(bl.begin(), bl.end());
             std::vector<uint64_t> offs(nbig + 1, 0);
             for (uint32_t i = 0; i < nbig; ++i) {
@@ -609,7 +630,8 @@ int compact_impl(cdbg_ctx* c) {
     c->n_pieces = cur[0]; c->n_piece_bases = cur[1]; c->n_glog = cur[4];
     uint64_t ks[4]; CK(read_u64(c->dstats.p, ks, 4));
 #ifdef CDBG_PROFILE_PHASES
-    { uint64_t ph[8]; CK(read_u64(c->dstats.p + 8, ph, 8)); fprintf(stderr, "k_compact phase ticks: seg_n %llu clear+load %llu classify %llu walk1 %llu cycles+reserve %llu walk2+glue %llu\n", (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3], (unsigned long long)ph[4], (unsigned long long)ph[5]); }
+    { uint64_t ph[9]; CK(read_u64(c->dstats.p + 8, ph, 9)); fprintf(stderr, "k_compact_wave phase cycles (summed over waves): between buckets %llu | load+mins %llu | classify %llu | mutual+terminals %llu | walk1(+cycles) %llu | reserve+confirms %llu | walk2+prefix bases %llu | last bases+glog %llu | reset %llu\n",
+        (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3], (unsigned long long)ph[4], (unsigned long long)ph[5], (unsigned long long)ph[6], (unsigned long long)ph[7], (unsigned long long)ph[8]); }
 #endif
     c->st.n_pieces = ks[3]; c->st.n_glue_open_ends = ks[0]; c->st.n_cycles = ks[2];
     c->st.ms_total += c->st.ms_compact;

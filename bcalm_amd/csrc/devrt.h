@@ -89,7 +89,7 @@ CDBG_DEV uint32_t alignbit_u32(uint32_t hi, uint32_t lo, uint32_t sh) { return _
 #endif
 // value known to be identical in every lane -> scalar register (frees VGPRs, makes the address math scalar)
 #ifdef CDBG_HOSTSIM
-CDBG_DEV uint32_t uni_u32(uint32_t v) { return v; }
+CDBG_DEV uint32_t uni_u32(uint32_t v) { return __shfl(v, 0); }   // (called by all lanes in wave-uniform control flow only)
 #define CDBG_NOINLINE
 #define CDBG_DEV_NOINL inline
 #define CDBG_LDS_BARRIER() __syncthreads()

@@ -1,0 +1,490 @@
+// k_compact_wave.h -- stage 2, first tier: ONE WAVE per minimizer bucket.
+//
+// Same job, same outputs and same junction rules as k_compact (k_compact.h; bcalm2 / graph3 of gatb-core's
+// bcalm_algo; unitig definition
+// /root/reference/bidirected-graphs-in-bcalm2/bidirected-graphs-in-bcalm2.md:83-88).
+//
+// Why a second formulation: at sequencing depth a bucket holds ~150 solid entries.  k_compact gives it a
+// 256-thread workgroup and 13 workgroup barriers; its phase profile (profiles/r02_*) is latency, not work:
+// most lanes idle in every phase and every barrier waits for the slowest wave.  Here a bucket belongs to one
+// wavefront: a phase is 3-5 wave iterations, phases are separated by wave-level ordering only (the LDS executes a
+// wave's instructions in order), four buckets are in flight per workgroup and ~16 per CU.  Per-bucket state is
+// entry-indexed 16-bit words (<= TSW/2 entries), ~10 KB of LDS per wave for one-word k-mers.
+// Buckets with more entries than TSW/2 are deferred to the workgroup-per-bucket tiers of k_compact.
+#pragma once
+#include "k_compact.h"
+
+namespace cdbg {
+
+constexpr int CW_THREADS = 128;                         // 2 independent waves per workgroup (LDS granularity: more waves per CU)
+constexpr uint32_t CW_PIECE_CHUNK = 256, CW_BASES_CHUNK = 1u << 14, CW_GLOG_CHUNK = 512;   // per-WAVE reservations (one device atomic each)
+constexpr uint32_t CW_BATCH = 8;                         // buckets handed out per queue ticket
+constexpr uint16_t CWL_CONF = 1u << 14, CWL_POSTED = 1u << 15;
+constexpr uint16_t CWN_NONE = 0xFFFFu, CWN_FOREIGN = 0xFFFEu;
+
+template <int W, int TSW>
+struct CompactWaveLds {                                 // one per wave
+    static constexpr int EMAX = TSW / 2;
+    uint64_t keys[TSW * W];
+    uint16_t ent[TSW];                                  // slot -> entry
+    uint16_t slot_of[EMAX];                             // entry -> slot
+    uint32_t cnt[EMAX];                                 // count | TRAV_FLAG; after walk 2: (byte offset << 1) | strand
+    uint16_t lnk[2 * EMAX];                             // per end (2 * entry + end): note, then link word
+    uint16_t fin[2 * EMAX];
+    uint16_t pdesc[EMAX], pn[EMAX], pb[EMAX];           // pieces: start end (bit 15: cyclic), k-mers, relative base offset
+    uint8_t vis[EMAX];                                  // bit 0 visited, bit 1 traveller, bit 2 / 3 owns the junction at the left / right end
+    uint16_t term[2 * EMAX];                            // terminal ends of home entries (walk 1 work list)
+    uint32_t np, nb, nb2, nopen, nconf, lw, ncyc, pad, ncov;   // pad: number of terminals
+};
+
+template <int W, int TSW>
+CDBG_DEV uint32_t cw_home(const Kmer<W>& key) {
+    constexpr int LOG = TSW == 1024 ? 10 : TSW == 512 ? 9 : TSW == 256 ? 8 : TSW == 128 ? 7 : -1;
+    static_assert(LOG > 0, "wave table size");
+    return key.hash_lds() >> (32 - LOG);
+}
+// distinct keys only (a bucket's solid entries), so no PENDING protocol: the claimer's lower words are written
+// before any sibling lane of the same iteration compares them (program order inside the iteration)
+template <int W, int TSW>
+CDBG_DEV uint32_t cw_insert(uint64_t* keys, const Kmer<W>& key) {
+    uint32_t s = cw_home<W, TSW>(key);
+    const uint64_t top = key.w[W - 1];
+    bool done = false;
+#pragma clang loop unroll(disable)
+    do {
+        const uint64_t old = atomic_cas_u64(&keys[(uint64_t)s * W + (W - 1)], KEY_EMPTY, top);
+        if (old == KEY_EMPTY) {
+            for (int i = 0; i < W - 1; ++i) keys[(uint64_t)s * W + i] = key.w[i];
+            done = true;
+        }
+        if (!done) s = (s + 1) & (TSW - 1);
+    } while (!done);
+    return s;
+}
+template <int W, int TSW>
+CDBG_DEV uint32_t cw_find(const uint64_t* keys, const Kmer<W>& key) {
+    uint32_t s = cw_home<W, TSW>(key);
+    const uint64_t top = key.w[W - 1];
+    bool found = false, stop;
+#pragma clang loop unroll(disable)
+    do {
+        const uint64_t v = keys[(uint64_t)s * W + (W - 1)];
+        if (v == top) {
+            bool eq = true;
+            for (int i = 0; i < W - 1; ++i) eq &= (keys[(uint64_t)s * W + i] == key.w[i]);
+            found = eq;
+        }
+        stop = found | (v == KEY_EMPTY);
+        s = stop ? s : ((s + 1) & (TSW - 1));
+    } while (!stop);
+    return found ? s : NONE32;
+}
+template <int W, int TSW>
+CDBG_DEV Kmer<W> cw_key(const CompactWaveLds<W, TSW>& L, uint32_t e) {
+    const uint32_t s = L.slot_of[e];
+    Kmer<W> r;
+    for (int i = 0; i < W; ++i) r.w[i] = L.keys[(uint64_t)s * W + i];
+    return r;
+}
+// successors of oriented k-mer u present in the table; returns count, last hit in (entry, enter_end)
+template <int W, int TSW>
+CDBG_DEV int cw_probe_succ(const CompactWaveLds<W, TSW>& L, const Kmer<W>& u, int k, uint32_t& ent, uint32_t& enter_end) {
+    int n = 0;
+    Kmer<W> vb = u; vb.push_right(k, 0);
+    const Kmer<W> rb = u.rc(k).shr(2);
+    const int pos = 2 * (k - 1);
+    for (uint32_t c = 0; c < 4; ++c) {
+        Kmer<W> v = vb; v.w[0] |= (uint64_t)c;
+        Kmer<W> r = rb; r.or_word(pos >> 6, (uint64_t)(3u - c) << (pos & 63));
+        const bool fwd = !(r < v);
+        const uint32_t f = cw_find<W, TSW>(L.keys, fwd ? v : r);
+        if (f != NONE32) { ++n; ent = L.ent[f]; enter_end = fwd ? END_LEFT : END_RIGHT; }
+    }
+    return n;
+}
+
+struct CompactWaveParams {
+    CompactParams c;
+    uint32_t n_buckets;
+    uint32_t* queue;                                    // next bucket to hand out (zeroed by the host)
+};
+// per-wave chunk of one output array (wave-uniform registers)
+struct CwChunk { uint64_t base; uint32_t left; };
+CDBG_DEV uint64_t cw_reserve(CwChunk& ch, uint64_t* cursor, uint32_t need, uint32_t chunk, int lane) {
+    if (need > chunk) {                                  // (cannot happen for the wave tier's bounds; kept for safety)
+        uint64_t b = 0;
+        if (lane == 0) b = atomic_add_u64(cursor, (uint64_t)need);
+        return uni_u64(b);
+    }
+    if (need > ch.left) {
+        uint64_t b = 0;
+        if (lane == 0) b = atomic_add_u64(cursor, (uint64_t)chunk);
+        ch.base = uni_u64(b); ch.left = chunk;
+    }
+    const uint64_t r = ch.base; ch.base += need; ch.left -= need;
+    return r;
+}
+
+// the solid entries of one bucket as loaded, NPER per lane (entry e = lane + 64 j)
+template <int W, int TSW>
+struct CwEntries {
+    static constexpr int NPER = TSW / 2 / 64 > 0 ? TSW / 2 / 64 : 1;
+    uint64_t key[NPER * W]; uint32_t cnt[NPER];
+};
+template <int W, int TSW>
+CDBG_DEV void cw_load_entries(const CompactParams& P, uint64_t so, uint32_t E, int lane, CwEntries<W, TSW>& X) {
+    constexpr int NPER = CwEntries<W, TSW>::NPER;
+#pragma unroll
+    for (int j = 0; j < NPER; ++j) {
+        const uint32_t e = (uint32_t)lane + 64u * (uint32_t)j;
+#pragma unroll
+        for (int i = 0; i < W; ++i) X.key[j * W + i] = 0;
+        X.cnt[j] = 0;
+        if (e < E && E <= (uint32_t)(TSW / 2)) {
+#pragma unroll
+            for (int i = 0; i < W; ++i) X.key[j * W + i] = P.solid_keys[(so + e) * W + i];
+            X.cnt[j] = P.solid_cnt[so + e];
+        }
+    }
+}
+// first probe of one key from a value read earlier (the four successor probes of an end read their home slots together)
+template <int W, int TSW>
+CDBG_DEV uint32_t cw_find_after_first(const uint64_t* keys, const Kmer<W>& key, uint32_t s, uint64_t first_top) {
+    if (first_top == KEY_EMPTY) return NONE32;
+    if (first_top == key.w[W - 1]) {
+        bool eq = true;
+        for (int i = 0; i < W - 1; ++i) eq &= (keys[(uint64_t)s * W + i] == key.w[i]);
+        if (eq) return s;
+    }
+    // occupied by another key: keep probing
+    const uint64_t top = key.w[W - 1];
+    bool found = false, stop;
+    s = (s + 1) & (TSW - 1);
+#pragma clang loop unroll(disable)
+    do {
+        const uint64_t v = keys[(uint64_t)s * W + (W - 1)];
+        if (v == top) {
+            bool eq = true;
+            for (int i = 0; i < W - 1; ++i) eq &= (keys[(uint64_t)s * W + i] == key.w[i]);
+            found = eq;
+        }
+        stop = found | (v == KEY_EMPTY);
+        s = stop ? s : ((s + 1) & (TSW - 1));
+    } while (!stop);
+    return found ? s : NONE32;
+}
+
+// One bucket.  X: its entries (requested one bucket ago); E, so: its segment.
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+#define CDBG_WPH(i) do { const uint64_t t_ = clock64(); acc[4 + (i)] += t_ - acc[15]; acc[15] = t_; } while (0)
+#else
+#define CDBG_WPH(i) do { } while (0)
+#endif
+template <int W, int TSW>
+CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>& L, const uint32_t p, const uint32_t E, const int lane,
+                                  const CwEntries<W, TSW>& X, CwChunk& pc, CwChunk& bc, CwChunk& lc, uint64_t (&acc)[16]) {
+    CDBG_WPH(0);
+    constexpr int NPER = CwEntries<W, TSW>::NPER;
+    const int k = P.k;
+    const uint32_t pg = (p << P.rank_bits) | (uint32_t)P.rank;
+    if (lane == 0) { L.np = 0; L.nb = 0; L.nb2 = 0; L.nopen = 0; L.nconf = 0; L.lw = 0; L.ncyc = 0; L.pad = 0; L.ncov = 0; }
+
+    // ---- load the bucket: home + traveller solid k-mers (the table is empty: the previous bucket emptied its slots) ----
+    uint32_t n_home = 0;
+#pragma unroll
+    for (int j = 0; j < NPER; ++j) {
+        const uint32_t e = (uint32_t)lane + 64u * (uint32_t)j;
+        if (e < E) {
+            Kmer<W> x;
+#pragma unroll
+            for (int i = 0; i < W; ++i) x.w[i] = X.key[j * W + i];
+            const uint32_t cv = X.cnt[j];
+            const uint32_t s = cw_insert<W, TSW>(L.keys, x);
+            L.ent[s] = (uint16_t)e; L.slot_of[e] = (uint16_t)s; L.cnt[e] = cv;
+            uint32_t gl, gr; kmer_junction_mins<W>(x, k, P.m, gl, gr);
+            L.vis[e] = (uint8_t)(((cv & TRAV_FLAG) ? 2u : 0u) | (part_of(gl, P.log_np) == pg ? 4u : 0u) | (part_of(gr, P.log_np) == pg ? 8u : 0u));
+            if (!(cv & TRAV_FLAG)) ++n_home;
+        }
+    }
+    n_home = wave_readlane_u32(wave_incl_sum_u32(n_home), 63);
+    CDBG_WAVE_SYNC();
+    CDBG_WPH(1);
+
+    // ---- classify: every end whose junction this bucket owns notes its unique successor end (or none) ----
+    for (uint32_t it = lane; it < 2 * E; it += 64) {
+        const uint32_t e = it >> 1, end = it & 1u;
+        uint32_t note = CWN_FOREIGN;                     // junction owned elsewhere: glue decides
+        if ((L.vis[e] >> (2 + end)) & 1u) {
+            const Kmer<W> u = orient_out<W>(cw_key<W, TSW>(L, e), end, k);
+            // the four successors u[1:]+c share everything but one base: v = (u << 2) | c, and its reverse complement is
+            // comp(c) in front of rc(u) without its last base.  Their home slots are read together (one LDS round trip).
+            Kmer<W> vb = u; vb.push_right(k, 0);
+            const Kmer<W> rb = u.rc(k).shr(2);
+            const int pos = 2 * (k - 1);
+            Kmer<W> lab[4]; uint32_t hs[4]; uint64_t first[4]; bool fwd[4];
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+                Kmer<W> v = vb; v.w[0] |= (uint64_t)c;
+                Kmer<W> r = rb; r.or_word(pos >> 6, (uint64_t)(3u - c) << (pos & 63));
+                fwd[c] = !(r < v);
+                lab[c] = fwd[c] ? v : r;
+                hs[c] = cw_home<W, TSW>(lab[c]);
+                first[c] = L.keys[(uint64_t)hs[c] * W + (W - 1)];
+            }
+            uint32_t nsucc = 0, y = 0, ye = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < 4; ++c) {
+                const uint32_t f = cw_find_after_first<W, TSW>(L.keys, lab[c], hs[c], first[c]);
+                if (f != NONE32) { ++nsucc; y = L.ent[f]; ye = fwd[c] ? END_LEFT : END_RIGHT; }
+            }
+            note = (nsucc == 1 && y != e) ? (y * 2 + ye) : CWN_NONE;
+        }
+        L.lnk[it] = (uint16_t)note;
+    }
+    CDBG_WAVE_SYNC();
+    CDBG_WPH(2);
+    // a junction is 1-in/1-out exactly when two ends name each other; terminal ends of home entries go on a list
+    for (uint32_t it = lane; it < 2 * E; it += 64) {
+        const uint32_t e = it >> 1;
+        const bool home = !(L.cnt[e] & TRAV_FLAG);
+        const uint32_t note = L.lnk[it];
+        uint32_t link = LNK_DEAD; bool conf = false;
+        if (note == CWN_FOREIGN) link = LNK_OPEN;
+        else if (note != CWN_NONE && L.lnk[note] == it) {
+            const uint32_t y = note >> 1, ye = note & 1u;
+            const bool yhome = !(L.cnt[y] & TRAV_FLAG);
+            if (home && yhome) link = LNK_INTERNAL | (ye << 2) | (y << 3);
+            else {
+                // 1-1 junction with a traveller on at least one side: confirm it for glue, once (a home end is open and
+                // posted anyway: its confirmation rides on that record)
+                if (home || (!yhome && e < y)) { conf = true; if (!home) atomic_add_u32(&L.nconf, 1u); }
+                if (home) link = LNK_OPEN;
+            }
+        }
+        L.fin[it] = (uint16_t)((home ? link : LNK_DEAD) | (conf ? CWL_CONF : 0u));
+    }
+    CDBG_WAVE_SYNC();
+    for (uint32_t it = lane; it < 2 * E; it += 64) {
+        const uint32_t l = L.fin[it];
+        L.lnk[it] = (uint16_t)l;
+        if (!(L.cnt[it >> 1] & TRAV_FLAG) && (l & 3u) != LNK_INTERNAL) {   // terminal end of a home entry
+            const uint32_t ti = atomic_add_u32(&L.pad, 1u);
+            L.term[ti] = (uint16_t)it;
+        }
+    }
+    CDBG_WAVE_SYNC();
+
+    CDBG_WPH(3);
+    // ---- walk 1: every terminal end measures its piece; the smaller terminal id registers it ----
+    const uint32_t nterm = uni_u32(L.pad);
+    for (uint32_t ti = lane; ti < nterm; ti += 64) {
+        const uint32_t it = L.term[ti];
+        uint32_t cur = it >> 1, ex = (it & 1u) ^ 1u, n = 1;
+        for (;;) {
+            const uint32_t l = L.lnk[cur * 2 + ex];
+            if ((l & 3u) != LNK_INTERNAL) break;
+            cur = (l >> 3) & 0x3FFu; ex = ((l >> 2) & 1u) ^ 1u; ++n;
+        }
+        const uint32_t other = cur * 2 + ex;
+        if (it <= other) {
+            const uint32_t li = atomic_add_u32(&L.np, 1u);
+            L.pdesc[li] = (uint16_t)it; L.pn[li] = (uint16_t)n;
+            atomic_add_u32(&L.nb, n + (uint32_t)k - 1u);
+            atomic_add_u32(&L.ncov, n);
+            const uint32_t no = ((L.lnk[it] & 3u) == LNK_OPEN ? 1u : 0u) + ((L.lnk[other] & 3u) == LNK_OPEN ? 1u : 0u);
+            if (no) atomic_add_u32(&L.nopen, no);
+        }
+    }
+    CDBG_WAVE_SYNC();
+    // ---- closed chains entirely inside the bucket (isolated cycles): only when the linear pieces do not cover every
+    // home entry (rare).  Mark what the pieces cover, then cut each remaining cycle at its smallest entry. ----
+    if (uni_u32(L.ncov) != n_home) {
+        const uint32_t np0 = uni_u32(L.np);
+        for (uint32_t li = lane; li < np0; li += 64) {
+            const uint32_t start = L.pdesc[li];
+            uint32_t cur = start >> 1, ex = (start & 1u) ^ 1u;
+            for (uint32_t t = 0, n = L.pn[li]; t < n; ++t) {
+                L.vis[cur] = L.vis[cur] | 1u;
+                if (t + 1 < n) { const uint32_t l = L.lnk[cur * 2 + ex]; cur = (l >> 3) & 0x3FFu; ex = ((l >> 2) & 1u) ^ 1u; }
+            }
+        }
+        CDBG_WAVE_SYNC();
+        for (uint32_t e = lane; e < E; e += 64) {
+            if (L.vis[e] & 3u) continue;                 // traveller, or part of a linear piece
+            uint32_t cur = e, ex = END_RIGHT, n = 0; bool is_min = true;
+            do {
+                const uint32_t l = L.lnk[cur * 2 + ex];
+                cur = (l >> 3) & 0x3FFu; ex = ((l >> 2) & 1u) ^ 1u; ++n;
+                if (cur < e) is_min = false;
+            } while (cur != e);
+            if (is_min) {
+                const uint32_t li = atomic_add_u32(&L.np, 1u);
+                L.pdesc[li] = (uint16_t)((e * 2 + END_LEFT) | 0x8000u);   // cyclic piece starting at e, walking right
+                L.pn[li] = (uint16_t)n;
+                atomic_add_u32(&L.nb, n + (uint32_t)k - 1u);
+                atomic_add_u32(&L.ncyc, 1u);
+            }
+        }
+        CDBG_WAVE_SYNC();
+    }
+
+    CDBG_WPH(4);
+    // ---- output space: piece ids, base bytes, glue-log records from this wave's chunks ----
+    uint32_t np = uni_u32(L.np);
+    const uint32_t nb = uni_u32(L.nb), nconf = uni_u32(L.nconf), nlog = nconf + uni_u32(L.nopen);
+    const uint64_t pbase = cw_reserve(pc, P.piece_cursor, np, CW_PIECE_CHUNK, lane);
+    const uint64_t bbase = cw_reserve(bc, P.bases_cursor, nb, CW_BASES_CHUNK, lane);
+    uint64_t lbase = cw_reserve(lc, P.glog_cursor, nlog, CW_GLOG_CHUNK, lane);
+    bool log_ok = true;
+    if (pbase + np > P.piece_cap || bbase + nb > P.bases_cap) { if (lane == 0) *P.error = 3; np = 0; }
+    if (lbase + nlog > P.glog_cap) { if (lane == 0) *P.error = 5; np = 0; lbase = 0; log_ok = false; }   // never write past the log
+
+    // ---- glue log, part 1: CONFIRM records of junctions whose two k-mers are both travellers here ----
+    if (log_ok && nconf) {
+        for (uint32_t it = lane; it < 2 * E; it += 64) {
+            const uint32_t l = L.lnk[it];
+            if (!(l & CWL_CONF) || (l & 3u) == LNK_OPEN) continue;   // open home ends carry their confirmation themselves
+            const uint64_t o = lbase + atomic_add_u32(&L.lw, 1u);
+            const Kmer<W> jc = canon_junction<W>(orient_out<W>(cw_key<W, TSW>(L, it >> 1), it & 1u, k), k);
+            for (int i = 0; i < W; ++i) P.glog_keys[o * W + i] = jc.w[i];
+            P.glog_tag[o] = GTAG_CONFIRM;
+        }
+    }
+    CDBG_WAVE_SYNC();                                    // walk 2 rewrites the link words this pass reads
+    CDBG_WPH(5);
+    // ---- walk 2: one lane per piece hands every k-mer its byte offset + strand (stored over the k-mer's count, which
+    // is summed here), marks the open ends and writes the piece's first k-1 bases ----
+    uint8_t* const out = P.piece_bases + bbase;
+    for (uint32_t li = lane; li < np; li += 64) {
+        const uint32_t d = L.pdesc[li];
+        const bool cyclic = d & 0x8000u;
+        const uint32_t start = d & 0x7FFFu;
+        const uint32_t s0 = start >> 1, e0 = start & 1u, n = L.pn[li];
+        const uint32_t rel = atomic_add_u32(&L.nb2, n + (uint32_t)k - 1u);
+        uint64_t kc = 0;
+        uint32_t cur = s0, ex = e0 ^ 1u;
+        for (uint32_t t = 0; t < n; ++t) {
+            const uint32_t ab = L.cnt[cur] & ~TRAV_FLAG;
+            const uint32_t l = L.lnk[cur * 2 + ex];
+            kc += (uint64_t)ab;
+            if (P.piece_ab) P.piece_ab[bbase + rel + (uint32_t)k - 1u + t] = ab;
+            L.cnt[cur] = ((rel + (uint32_t)k - 1u + t) << 1) | (ex == END_RIGHT ? 0u : 1u);
+            if (t + 1 < n) { cur = (l >> 3) & 0x3FFu; ex = ((l >> 2) & 1u) ^ 1u; }
+        }
+        const uint64_t pid = pbase + li;
+        P.piece_n[pid] = n; P.piece_kc[pid] = kc; P.piece_boff[pid] = bbase + rel;
+        if (!cyclic) {
+            const uint32_t il = s0 * 2 + e0, ir = cur * 2 + ex;
+            const uint32_t ll = L.lnk[il], lr = L.lnk[ir];
+            if ((ll & 3u) == LNK_OPEN) L.lnk[il] = (uint16_t)(CWL_POSTED | (ll & CWL_CONF) | (li * 2u + 0u));
+            if ((lr & 3u) == LNK_OPEN) L.lnk[ir] = (uint16_t)(CWL_POSTED | (lr & CWL_CONF) | (li * 2u + 1u));
+        }
+        // the first k-1 bases of the piece: the start k-mer, read leaving through the far end of the start terminal
+        const Kmer<W> x0 = cw_key<W, TSW>(L, s0);
+        const Kmer<W> xo = ((e0 ^ 1u) == END_RIGHT) ? x0 : x0.rc(k);
+        for (int i = 0; i < k - 1; ++i) out[rel + (uint32_t)i] = (uint8_t)("ACGT"[xo.base(k, i)]);
+    }
+    CDBG_WAVE_SYNC();
+    CDBG_WPH(6);
+    if (np) {
+        // last base of every home k-mer (one lane per k-mer; no reverse complement needed:
+        // the last base of rc(x) is the complement of the first base of x)
+        for (uint32_t e = lane; e < E; e += 64) {
+            if (L.vis[e] & 2u) continue;                 // traveller copy: belongs to another bucket's piece
+            const uint32_t v = L.cnt[e];
+            const Kmer<W> x = cw_key<W, TSW>(L, e);
+            const uint32_t b = (v & 1u) ? 3u - x.base(k, 0) : x.base(k, k - 1);
+            out[v >> 1] = (uint8_t)("ACGT"[b]);
+        }
+        // ---- glue log, part 2: one record per open piece end ----
+        for (uint32_t it = lane; it < 2 * E; it += 64) {
+            const uint32_t l = L.lnk[it];
+            if (!(l & CWL_POSTED)) continue;
+            const uint64_t o = lbase + atomic_add_u32(&L.lw, 1u);
+            const Kmer<W> jc = canon_junction<W>(orient_out<W>(cw_key<W, TSW>(L, it >> 1), it & 1u, k), k);
+            for (int i = 0; i < W; ++i) P.glog_keys[o * W + i] = jc.w[i];
+            P.glog_tag[o] = (uint32_t)(pbase * 2 + (l & 0x3FFu)) | ((l & CWL_CONF) ? GTAG_CONFBIT : 0u);
+        }
+    }
+    CDBG_WAVE_SYNC();
+#ifdef CDBG_WAVE_DEBUG
+    if (lane == 0) { for (uint32_t it = 0; it < 2 * E; ++it) fprintf(stderr, " [%u cnt %x vis %x lnk %04x fin %04x]", it, L.cnt[it >> 1], L.vis[it >> 1], L.lnk[it], L.fin[it]); fprintf(stderr, "\n"); }
+    if (lane == 0) fprintf(stderr, "bucket %u E %u np %u nconf %u nopen %u lw %u pbase %llu lbase %llu nterm %u ncov %u nhome %u\n", p, E, np, nconf, L.nopen, L.lw, (unsigned long long)pbase, (unsigned long long)lbase, nterm, L.ncov, n_home);
+#endif
+    const uint32_t nopen_posted = np ? uni_u32(L.lw) - (log_ok ? nconf : 0u) : 0u;
+    acc[0] += nopen_posted; acc[1] += log_ok ? nconf : 0u; acc[2] += uni_u32(L.ncyc); acc[3] += np;
+    // hand the table back empty (E slots instead of all TSW) and clear the visited marks
+    CDBG_WPH(7);
+    for (uint32_t e = lane; e < E; e += 64) L.keys[(uint64_t)L.slot_of[e] * W + (W - 1)] = KEY_EMPTY;
+    CDBG_WAVE_SYNC();
+    CDBG_WPH(8);
+}
+
+// Persistent waves pulling batches of buckets from ONE device-wide queue (a returning atomic per batch, requested one
+// batch ahead): the launch stays balanced whatever number of workgroups the hardware really admits per CU (the occupancy
+// query can be one high, MI355X_MICROARCH.md "Residency": a partial second generation would run alone).  Pipeline per
+// wave: queue ticket -> segment descriptor -> entries -> compaction, one bucket apart each; the entries live in two
+// register sets (ping-pong, as in k_count_fast).
+template <int W, int TSW>
+__global__ void __launch_bounds__(CW_THREADS) k_compact_wave(CompactWaveParams WP) {
+    CDBG_SHARED CompactWaveLds<W, TSW> Ls[CW_THREADS / 64];
+    const CompactParams& P = WP.c;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)uni_u32((uint32_t)tid >> 6);
+    CompactWaveLds<W, TSW>& L = Ls[wave];
+    for (uint32_t i = lane; i < (uint32_t)TSW; i += 64) L.keys[(uint64_t)i * W + (W - 1)] = KEY_EMPTY;
+    CDBG_WAVE_SYNC();
+    uint64_t acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+    acc[15] = clock64();
+#endif
+    CwChunk pc{0, 0}, bc{0, 0}, lc{0, 0};
+    const uint32_t nb = WP.n_buckets;
+    // (no lambdas that capture the parameter block by reference: taking its address sends the pointers it holds through
+    //  memory, the compiler then loses their address space and every global access becomes a FLAT one -- which counts
+    //  against lgkmcnt as well, so each LDS wait would also wait for the global loads and stores in flight)
+    uint32_t* const queue = WP.queue;
+    const uint32_t* const seg_n = P.seg_n; const uint64_t* const seg_off = P.seg_off;
+    // One word saturates at ~88 M returning atomics per second (MI355X_MICROARCH.md, "dequeue"): a ticket per bucket
+    // would cap the stage at 4.2 M buckets / 48 ms.  A ticket therefore hands out CW_BATCH consecutive buckets, and the
+    // next ticket is requested when a batch starts.
+    uint32_t q_batch, q_j = 0, q_next_raw;              // id stream: current batch, position in it, next batch (raw: lane 0 only)
+#define CW_TICKET(dst) do { uint32_t t_ = 0; if (lane == 0) t_ = atomic_add_u32(queue, 1u); (dst) = t_; } while (0)
+#define CW_NEXT_ID(dst) do { if (q_j == CW_BATCH) { q_batch = uni_u32(q_next_raw); CW_TICKET(q_next_raw); q_j = 0; } (dst) = q_batch * CW_BATCH + q_j; ++q_j; } while (0)
+#define CW_SEG_LOAD(p_, n_, off_) do { const uint32_t q_ = (p_) < nb ? (p_) : nb - 1u; (n_) = seg_n[q_]; (off_) = seg_off[q_]; } while (0)
+    CwEntries<W, TSW> X0, X1;
+    uint32_t p_cur, p_nxt, p_nn;                        // buckets: being compacted, entries requested, descriptor requested
+    { uint32_t t; CW_TICKET(t); q_batch = uni_u32(t); CW_TICKET(q_next_raw); }
+    CW_NEXT_ID(p_cur); CW_NEXT_ID(p_nxt); CW_NEXT_ID(p_nn);
+    uint32_t E_cur, segn_nxt; uint64_t sego_nxt;
+    {
+        uint32_t n0; uint64_t o0; CW_SEG_LOAD(p_cur, n0, o0);
+        E_cur = p_cur < nb ? uni_u32(n0) : 0u;
+        cw_load_entries<W, TSW>(P, uni_u64(o0), E_cur, lane, X0);
+    }
+    CW_SEG_LOAD(p_nxt, segn_nxt, sego_nxt);
+#define CW_ONE_BUCKET(Xc, Xn) do {                                                                                         \
+        uint32_t segn_nn; uint64_t sego_nn; CW_SEG_LOAD(p_nn, segn_nn, sego_nn);            /* descriptor two buckets ahead */ \
+        const uint32_t E_nxt = p_nxt < nb ? uni_u32(segn_nxt) : 0u;                                                         \
+        cw_load_entries<W, TSW>(P, uni_u64(sego_nxt), E_nxt, lane, Xn);                     /* entries one bucket ahead */     \
+        if (E_cur > (uint32_t)(TSW / 2)) {                  /* more entries than the wave tier holds: workgroup tiers */        \
+            if (lane == 0) { const uint32_t i_ = atomic_add_u32(P.big_count, 1u); P.big_list[i_] = p_cur; }                 \
+        } else if (E_cur) compact_bucket_wave<W, TSW>(P, L, p_cur, E_cur, lane, Xc, pc, bc, lc, acc);                       \
+        p_cur = p_nxt; E_cur = E_nxt; p_nxt = p_nn; segn_nxt = segn_nn; sego_nxt = sego_nn;                                 \
+        CW_NEXT_ID(p_nn);                                                                                                   \
+    } while (0)
+    while (p_cur < nb) {
+        CW_ONE_BUCKET(X0, X1);
+        if (p_cur >= nb) break;
+        CW_ONE_BUCKET(X1, X0);
+    }
+#undef CW_ONE_BUCKET
+#undef CW_SEG_LOAD
+#undef CW_TICKET
+#undef CW_NEXT_ID
+    if (lane == 0) for (int i = 0; i < 4; ++i) if (acc[i]) atomic_add_u64(&P.stats[i], acc[i]);
+#if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
+    if (lane == 0) for (int i = 4; i < 13; ++i) atomic_add_u64(&P.stats[4 + i], acc[i]);
+#endif
+}
+
+}  // namespace cdbg

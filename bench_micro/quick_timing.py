@@ -7,7 +7,7 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 31
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 cfg, L = (3, 150) if k <= 31 else (4, 150) if k <= 63 else (5, 1000)
 for n_reads in [int(x) for x in sys.argv[1].split(",")]:
-    g = bcalm_amd.Graph(k, 2, lib=lib)
+    g = bcalm_amd.Graph(k, 2, lib=lib, log2_partitions=int(os.environ.get('CDBG_LOG_NP', -1)), minimizer_size=int(os.environ.get('CDBG_M', 0)))
     g.generate_reads(n_reads, L, cfg)
     for rep in range(reps):
         t1 = time.time(); g.run(); t2 = time.time()
