@@ -23,7 +23,7 @@ class CdbgError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("k", C.c_int), ("abundance_min", C.c_int), ("minimizer_size", C.c_int),
                 ("log2_partitions", C.c_int), ("device_id", C.c_int), ("world_size", C.c_int),
-                ("rank", C.c_int), ("all_abundance_counts", C.c_int)]
+                ("rank", C.c_int), ("all_abundance_counts", C.c_int), ("emit_replicated", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -32,7 +32,7 @@ class Stats(C.Structure):
         "n_solid_travellers", "n_pieces", "n_glue_open_ends", "n_glue_joined", "n_unitigs",
         "unitig_bases", "n_big_partitions", "n_cycles")] + [
         ("minimizer_size", C.c_int), ("log2_partitions", C.c_int), ("kmer_words", C.c_int)] + [
-        (n, C.c_float) for n in ("ms_scan_hist", "ms_scan_emit", "ms_count", "ms_compact", "ms_glue", "ms_total")] + [
+        (n, C.c_float) for n in ("ms_scan_hist", "ms_scan_emit", "ms_count", "ms_compact", "ms_glue", "ms_total", "ms_exchange")] + [
         (n, C.c_uint64) for n in ("n_launch_scan", "n_launch_count", "n_launch_compact", "n_multipass_partitions")]
 
     def as_dict(self):
@@ -41,9 +41,10 @@ class Stats(C.Structure):
 
 EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
            "cdbg_generate_reads", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
-           "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats",
+           "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats", "cdbg_digest",
            "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end", "cdbg_glue_join", "cdbg_glue_links_export", "cdbg_glue_links_import",
-           "cdbg_exchange_sizes_packed", "cdbg_exchange_export_packed", "cdbg_exchange_add_packed"]
+           "cdbg_exchange_sizes_packed", "cdbg_exchange_export_packed", "cdbg_exchange_add_packed",
+           "cdbg_set_transport", "cdbg_comm_unique_id", "cdbg_comm_init_rccl", "cdbg_comm_bytes"]
 
 
 def _share_hip_runtime_with_torch() -> None:
@@ -87,6 +88,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_num_unitigs.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     lib.cdbg_fetch_unitigs.argtypes = [vp, u64, u64, C.c_char_p, C.POINTER(u64), C.POINTER(u64)]
     lib.cdbg_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.cdbg_digest.argtypes = [vp, C.POINTER(u64)]
     lib.cdbg_fetch_unitig_abundances.argtypes = [vp, u64, u64, C.POINTER(C.c_uint32), C.POINTER(u64)]
     lib.cdbg_link.argtypes = [vp]
     lib.cdbg_num_links.argtypes = [vp, C.POINTER(u64)]
@@ -102,6 +104,10 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_exchange_add_packed.argtypes = [vp, u64, u64, u64, u64, vp, vp, vp, vp, vp]
     lib.cdbg_glue_links_export.argtypes = [vp, vp, u64]
     lib.cdbg_glue_links_import.argtypes = [vp, vp, u64]
+    lib.cdbg_set_transport.argtypes = [vp, vp]
+    lib.cdbg_comm_unique_id.argtypes = [vp]
+    lib.cdbg_comm_init_rccl.argtypes = [vp, C.c_char_p]
+    lib.cdbg_comm_bytes.argtypes = [vp, C.POINTER(u64)]
     return lib
 
 
@@ -113,10 +119,11 @@ class Graph:
 
     def __init__(self, k: int, abundance_min: int = 2, minimizer_size: int = 0, log2_partitions: int = -1,
                  device_id: int = 0, world_size: int = 1, rank: int = 0, lib: C.CDLL | None = None,
-                 all_abundance_counts: bool = False):
+                 all_abundance_counts: bool = False, emit_replicated: bool = False):
         self.lib = lib or load()
         self.k = k
-        p = Params(k, abundance_min, minimizer_size, log2_partitions, device_id, world_size, rank, 1 if all_abundance_counts else 0)
+        p = Params(k, abundance_min, minimizer_size, log2_partitions, device_id, world_size, rank, 1 if all_abundance_counts else 0,
+                   1 if emit_replicated else 0)
         self._h = C.c_void_p()
         self._ck(self.lib.cdbg_create(C.byref(p), C.byref(self._h)))
 
@@ -261,6 +268,18 @@ class Graph:
         s = Stats()
         self._ck(self.lib.cdbg_stats(self._h, C.byref(s)))
         return s.as_dict()
+
+    def comm_bytes(self):
+        """bytes this rank sent + received through the transport since the last reset()"""
+        n = C.c_uint64()
+        self._ck(self.lib.cdbg_comm_bytes(self._h, C.byref(n)))
+        return n.value
+
+    def digest(self):
+        """device-side digests of the result: {kc_sum, solid_count_sum, set_digest, kmers_in_unitigs}"""
+        out = (C.c_uint64 * 4)()
+        self._ck(self.lib.cdbg_digest(self._h, out))
+        return {"kc_sum": out[0], "solid_count_sum": out[1], "set_digest": out[2], "kmers_in_unitigs": out[3]}
 
     def solid_kmers(self):
         n = C.c_uint64()

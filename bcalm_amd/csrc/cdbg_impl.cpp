@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "k_links.h"
+#include "comm.h"
 #include "k_count_fast.h"
 #include "k_compact_wave.h"
 
@@ -169,6 +170,17 @@ struct cdbg_ctx {
     uint64_t n_unitigs = 0, unitig_total = 0;
     DBuf<uint32_t> piece_ab, unitig_ab;          // -all-abundance-counts
     DBuf<uint64_t> link_off; DBuf<uint32_t> link_to; uint64_t n_links = 0; bool linked = false;
+    DBuf<uint4> rank_a, rank_b; DBuf<uint32_t> rank_flag;
+    // multi-GPU: transport (RCCL or caller-supplied) and the record exchange buffers
+    cdbg_transport tr{}; bool have_tr = false; uint64_t comm_bytes = 0;
+    bool force_multi = false;                            // CDBG_FORCE_MULTI: run the multi-rank code path with one rank (tests)
+#ifndef CDBG_HOSTSIM
+    RcclComm* rccl = nullptr;
+#endif
+    DBuf<uint32_t> xcnt; DBuf<uint64_t> xoff, xbase, xrecs;
+    uint64_t piece_lo = 0, piece_hi = 0;                 // this rank's piece ids inside the merged arrays (owner-sharded emission)
+    bool xchg_done = false;                              // the glue exchange of this run has happened
+    DBuf<uint8_t> xg[5], xsend;    // list-ranking state (kept: a step must not allocate once the first step's buffers exist)
 };
 
 namespace {
@@ -262,7 +274,7 @@ struct Timer {
 // ---------------------------------------------------------------------------------------
 // configuration (DSK's "configure" role, row a5): partitions and minimizer length from volume
 // ---------------------------------------------------------------------------------------
-void configure(cdbg_ctx* c) {
+void configure(cdbg_ctx* c, uint64_t total_bytes) {
     const int W = c->W;
     const int ts = W == 1 ? TS_COUNT_1 : W == 2 ? TS_COUNT_2 : TS_COUNT_4;
     // mean k-mer occurrences per partition: ~0.3 distinct per occurrence at sequencing depth fills the
@@ -271,11 +283,13 @@ void configure(cdbg_ctx* c) {
 #define CDBG_OCC_NUM 3
 #define CDBG_OCC_DEN 2
 #endif
-    const uint64_t target_occ = (uint64_t)ts * CDBG_OCC_NUM / CDBG_OCC_DEN;
+    // (four-word k-mers: at k = 127 three quarters of the k-mers of reads with 1 % errors are distinct, so a partition
+    //  must hold fewer occurrences for its distinct k-mers to fit the one-pass table)
+    const uint64_t target_occ = W == 4 ? (uint64_t)ts * 3 / 5 : (uint64_t)ts * CDBG_OCC_NUM / CDBG_OCC_DEN;
     int log_np = c->log_np_override >= 0 ? c->log_np_override : c->prm.log2_partitions;
     if (log_np < 0) {
         log_np = 0;
-        while (log_np < 24 && ((uint64_t)1 << log_np) * target_occ < c->nbytes) ++log_np;
+        while (log_np < 24 && ((uint64_t)1 << log_np) * target_occ < total_bytes) ++log_np;
     }
     if (log_np < c->rank_bits) log_np = c->rank_bits;
     if (log_np > 26) log_np = 26;
@@ -305,14 +319,26 @@ int count_impl(cdbg_ctx* c) {
     constexpr int TS = Cfg<W>::TSC;
     CK(upload_pending(c));
     if (!c->reads.p || c->nbytes == 0) return fail(CDBG_E_STATE, "no reads: call cdbg_push_reads/cdbg_push_text/cdbg_generate_reads first");
-    configure(c);
+    // multi-GPU: the reads are sharded over the ranks; every rank must choose the same partitioning, so the input
+    // volume that drives configure() is the sum over the ranks
+    const bool multi = c->prm.world_size > 1 || c->force_multi;
+    const int world = c->prm.world_size;
+    uint64_t total_bytes = c->nbytes;
+    if (multi) {
+        if (!c->have_tr) return fail(CDBG_E_STATE, "world_size %d but no transport: call cdbg_comm_init_rccl or cdbg_set_transport first", world);
+        std::vector<uint64_t> all(world); const uint64_t mine = c->nbytes;
+        if (c->tr.all_gather_u64(c->tr.user, &mine, all.data(), 1) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
+        total_bytes = 0; for (uint64_t v : all) total_bytes += v;
+    }
+    configure(c, total_bytes);
     const uint64_t NPL = c->n_local_parts;
+    const uint64_t NPS = multi ? (NPL << c->rank_bits) : NPL;    // partition slots the scan fills: all of them when the reads are sharded
     hipStream_t s = c->stream;
     Timer t_total; CK(t_total.start(s));
 
-    CK(c->part_count.alloc(NPL, true));
-    CK(c->part_off.alloc(NPL + 1, false));
-    CK(c->part_cursor.alloc(NPL, false));
+    CK(c->part_count.alloc(NPS, true));
+    CK(c->part_off.alloc(NPS + 1, false));
+    CK(c->part_cursor.alloc(NPS, false));
     CK(c->dstats.alloc(32, true));
     CK(c->derr.alloc(4, true));
     CK(c->cursors.alloc(8, true));
@@ -322,6 +348,7 @@ int count_impl(cdbg_ctx* c) {
     sp.k = c->k; sp.m = c->m; sp.log_np = c->log_np; sp.rank_bits = c->rank_bits; sp.rank = c->prm.rank;
     sp.part_count = c->part_count.p; sp.part_cursor = c->part_cursor.p; sp.records = nullptr; sp.stats = c->dstats.p;
     sp.tile_stride = 1; sp.tile_offset = 0; sp.error = c->derr.p;
+    sp.emit_all = multi ? 1u : 0u; sp.npl = (uint32_t)NPL;
     // instruction-lean scan when the window fits registers; generic LDS-doubling scan otherwise
     const bool fast_scan = c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX;
     const uint64_t tiles = fast_scan ? (c->nbytes + SCANF_TILE - 1) / SCANF_TILE : (c->nbytes + SCAN_TILE - 1) / SCAN_TILE;
@@ -331,21 +358,16 @@ int count_impl(cdbg_ctx* c) {
          if (fast_scan && W == 1 && c->k - c->m == 15) CDBG_LAUNCH((k_scan_fast<W, MODE, W == 1 ? 15 : 0>), std::min<uint64_t>((GRID), resident_grid(k_scan_fast<W, MODE, W == 1 ? 15 : 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp); \
          else if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE, 0>), std::min<uint64_t>((GRID), resident_grid(k_scan_fast<W, MODE, 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);  \
          else CDBG_LAUNCH((k_scan<W, MODE>), std::min<uint64_t>((GRID), resident_grid(k_scan<W, MODE>, SCAN_THREADS, SCAN_GRID)), SCAN_THREADS, s, sp); } while (0)
-    auto exscan = [&](const uint32_t* counts) -> int {       // counts -> part_off (exclusive), part_off[NPL] = total
-        const uint64_t nb = (NPL + EXSCAN_BLOCK - 1) / EXSCAN_BLOCK;
-        CK(c->exscan_tmp.alloc(nb + 1, false));
-        CDBG_LAUNCH(k_exscan_sums, nb, EXSCAN_THREADS, s, counts, c->exscan_tmp.p, NPL);
-        CDBG_LAUNCH(k_exscan_top, 1, EXSCAN_THREADS, s, c->exscan_tmp.p, nb, c->part_off.p + NPL);
-        CDBG_LAUNCH(k_exscan_apply, nb, EXSCAN_THREADS, s, counts, (const uint64_t*)c->exscan_tmp.p, c->part_off.p, NPL);
-        return CDBG_OK;
+    auto exscan = [&](const uint32_t* counts) -> int {       // counts -> part_off (exclusive), part_off[NPS] = total
+        return exscan_u32(c, counts, c->part_off.p, NPS);
     };
 
     // Record placement.  exact : histogram pass + emit pass at exact offsets (two scans, zero slack).
     //                    capped: ONE scan into fixed-capacity partition regions sized from a sampled
     //                            histogram; the rare records that do not fit go to a spill list and their
     //                            partitions are repaired (gathered contiguously) before counting.
-    bool capped = tiles > 8192;
-    if (const char* e = getenv("CDBG_SCAN_MODE")) { if (!strcmp(e, "exact")) capped = false; else if (!strcmp(e, "capped")) capped = true; }
+    bool capped = tiles > 8192 && !multi;                    // (sharded reads: the exact layout is what travels -- no slack on the wire)
+    if (const char* e = getenv("CDBG_SCAN_MODE"); e && !multi) { if (!strcmp(e, "exact")) capped = false; else if (!strcmp(e, "capped")) capped = true; }
     uint64_t n_records = 0, hs[2] = {0, 0};
     uint32_t part_cap = 0; uint64_t n_spill = 0;
     std::vector<uint32_t> spill_parts;                       // spilled partitions (sorted), capped mode
@@ -412,22 +434,62 @@ int count_impl(cdbg_ctx* c) {
     }
     if (!capped) {
         sp.tile_stride = 1; sp.part_cap = 0;
-        HIPCK(hipMemsetAsync(c->part_count.p, 0, NPL * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
         // pass 1: histogram of records per partition
         CK(t.start(s));
         LAUNCH_SCAN(SCAN_HIST, tiles);
         CK(exscan(c->part_count.p));
         CK(t.stop(&c->st.ms_scan_hist));
-        CK(read_u64(c->part_off.p + NPL, &n_records));
+        CK(read_u64(c->part_off.p + NPS, &n_records));
         CK(read_u64(c->dstats.p, hs, 2));
         // pass 2: emit records at exact offsets
         CK(c->records.alloc(std::max<uint64_t>(n_records, 1) * RW, false));
         CK(t.start(s));
-        CDBG_LAUNCH(k_copy_u64, (NPL + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_cursor.p, NPL);
+        CDBG_LAUNCH(k_copy_u64, (NPS + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_cursor.p, NPS);
         sp.records = c->records.p;
         LAUNCH_SCAN(SCAN_EMIT, tiles);
         CK(t.stop(&c->st.ms_scan_emit));
+    }
+    if (multi) {
+        // ---- record exchange: block r of the record array (the partitions rank r owns) goes to rank r ----
+        Timer tx; CK(tx.start(s));
+        CK(c->xcnt.alloc((uint64_t)world * NPL, false)); CK(c->xoff.alloc((uint64_t)world * (NPL + 1), false)); CK(c->xbase.alloc(world, false));
+        std::vector<uint64_t> so(world), sc(world), ro(world), rc(world);
+        // per-partition counts first (equal blocks of NPL counts)
+        for (int r = 0; r < world; ++r) { so[r] = (uint64_t)r * NPL * 4; sc[r] = NPL * 4; ro[r] = so[r]; rc[r] = sc[r]; }
+        HIPCK(hipStreamSynchronize(s));
+        if (c->tr.all_to_all_v(c->tr.user, c->part_count.p, so.data(), sc.data(), c->xcnt.p, ro.data(), rc.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_to_all_v (counts) failed");
+        c->comm_bytes += 2 * (uint64_t)(world - 1) * NPL * 4;
+        // where the records of sender s start inside its block, per partition; block sizes
+        std::vector<uint64_t> xb(world + 1, 0);
+        for (int r = 0; r < world; ++r) {
+            CK(exscan_u32(c, c->xcnt.p + (uint64_t)r * NPL, c->xoff.p + (uint64_t)r * (NPL + 1), NPL));
+            uint64_t tot = 0; CK(read_u64(c->xoff.p + (uint64_t)r * (NPL + 1) + NPL, &tot));
+            xb[r + 1] = xb[r] + tot;
+        }
+        HIPCK(hipMemcpy(c->xbase.p, xb.data(), world * sizeof(uint64_t), hipMemcpyHostToDevice));
+        CK(c->xrecs.alloc(std::max<uint64_t>(xb[world], 1) * RW, false));
+        for (int r = 0; r < world; ++r) {
+            uint64_t b[1], e[1]; CK(read_u64(c->part_off.p + (uint64_t)r * NPL, b)); CK(read_u64(c->part_off.p + (uint64_t)(r + 1) * NPL, e));
+            so[r] = b[0] * RW * 8; sc[r] = (e[0] - b[0]) * RW * 8;
+            ro[r] = xb[r] * RW * 8; rc[r] = (xb[r + 1] - xb[r]) * RW * 8;
+            if (r != c->prm.rank) c->comm_bytes += sc[r] + rc[r];
+        }
+        if (c->tr.all_to_all_v(c->tr.user, c->records.p, so.data(), sc.data(), c->xrecs.p, ro.data(), rc.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_to_all_v (records) failed");
+        // merge the blocks: partition lp = its segments in sender order
+        CK(c->part_count.alloc(NPL, false)); CK(c->part_off.alloc(NPL + 1, false));
+        SumCountParams scp{ c->xcnt.p, world, NPL, c->part_count.p };
+        CDBG_LAUNCH(k_sum_counts, (NPL + 255) / 256, 256, s, scp);
+        CK(exscan_u32(c, c->part_count.p, c->part_off.p, NPL));
+        n_records = xb[world];
+        CK(c->records.alloc(std::max<uint64_t>(n_records, 1) * RW, false));
+        HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+        MergeRecParams mp{ c->xcnt.p, c->xoff.p, c->xbase.p, world, NPL, RW, c->xrecs.p, c->part_off.p, c->records.p, c->dstats.p };
+        CDBG_LAUNCH(k_merge_records, std::min<uint64_t>((NPL + 3) / 4, 8192), 256, s, mp);
+        HIPCK(hipStreamSynchronize(s));
+        CK(read_u64(c->dstats.p, hs, 2));
+        float msx = 0; CK(tx.stop(&msx)); c->st.ms_exchange += msx;
     }
 #undef LAUNCH_SCAN
 #ifdef CDBG_PROFILE_PHASES
@@ -681,16 +743,60 @@ int glue_join_impl(cdbg_ctx* c, bool sharded) {
     return CDBG_OK;
 }
 
+// ---- multi-GPU glue exchange, driven by the library through the context's transport: every rank's pieces (lengths,
+// abundance sums, bases packed 4 per byte, no offsets) and junction log are all-gathered and merged in rank order
+// (cdbg_exchange_*); the junction hash-join is sharded by key hash and its result, one partner id per piece end, is
+// combined with ONE MAX all-reduce (every end is set by exactly one rank) ----
+int glue_exchange(cdbg_ctx* c) {
+    const int world = c->prm.world_size, W = c->W;
+    hipStream_t s = c->stream;
+    Timer t; CK(t.start(s));
+    uint64_t mine[4]; CK(cdbg_exchange_sizes_packed(c, mine));          // pieces, bases once unpacked, glue-log records, packed bytes
+    std::vector<uint64_t> all((size_t)world * 4);
+    if (c->tr.all_gather_u64(c->tr.user, mine, all.data(), 4) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
+    auto col = [&](int r, int j) { return all[(size_t)r * 4 + j]; };
+    // the five arrays: piece_n (u32), piece_kc (u64), packed bases, glue keys (u64 x W), glue tags (u32)
+    const uint64_t item[5] = { 4, 8, 1, 8ull * W, 4 }; const int which[5] = { 0, 0, 3, 2, 2 };
+    std::vector<std::vector<uint64_t>> roff(5, std::vector<uint64_t>(world)), rcnt(5, std::vector<uint64_t>(world));
+    DBuf<uint8_t>& sendbuf = c->xsend;
+    for (int a = 0; a < 5; ++a) {
+        uint64_t tot = 0;
+        for (int r = 0; r < world; ++r) { rcnt[a][r] = col(r, which[a]) * item[a]; roff[a][r] = tot; tot += (rcnt[a][r] + 15) / 16 * 16; }
+        CK(c->xg[a].alloc(tot + 16, false));
+        const uint64_t nb = rcnt[a][c->prm.rank];
+        CK(sendbuf.alloc(nb + 16, false));
+        if (a == 2) CK(cdbg_exchange_export_packed(c, sendbuf.p, nb + 16));
+        else CK(cdbg_exchange_export(c, a == 0 ? 0 : a == 1 ? 1 : a == 3 ? 4 : 5, sendbuf.p, nb + 16));
+        if (c->tr.all_gather_v(c->tr.user, sendbuf.p, nb, c->xg[a].p, roff[a].data(), rcnt[a].data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_v failed");
+        for (int r = 0; r < world; ++r) if (r != c->prm.rank) c->comm_bytes += nb + rcnt[a][r];
+    }
+    uint64_t tp = 0, tb = 0, tl = 0;
+    for (int r = 0; r < world; ++r) { if (r == c->prm.rank) c->piece_lo = tp; tp += col(r, 0); if (r == c->prm.rank) c->piece_hi = tp; tb += col(r, 1); tl += col(r, 2); }
+    CK(cdbg_exchange_begin(c, tp, tb, tl));
+    for (int r = 0; r < world; ++r)
+        CK(cdbg_exchange_add_packed(c, col(r, 0), col(r, 1), col(r, 3), col(r, 2), c->xg[0].p + roff[0][r], c->xg[1].p + roff[1][r],
+                                    c->xg[2].p + roff[2][r], c->xg[3].p + roff[3][r], c->xg[4].p + roff[4][r]));
+    CK(cdbg_exchange_end(c));
+    // sharded junction join
+    uint64_t n_ends = 0; CK(cdbg_glue_join(c, &n_ends));
+    if (c->tr.all_reduce_max_i32(c->tr.user, c->link.p, n_ends) != 0) return fail(CDBG_E_INTERNAL, "transport all_reduce_max_i32 failed");
+    c->comm_bytes += 2 * n_ends * 4 * (uint64_t)(world - 1) / (uint64_t)world;          // (ring all-reduce volume per rank)
+    float ms = 0; CK(t.stop(&ms)); c->st.ms_exchange += ms;
+    c->xchg_done = true;
+    return CDBG_OK;
+}
+
 template <int W>
 int glue_impl(cdbg_ctx* c) {
     if (c->stage < 2) return fail(CDBG_E_STATE, "cdbg_glue before cdbg_compact");
+    if ((c->prm.world_size > 1 || c->force_multi) && c->have_tr && !c->xchg_done && !c->joined) CK(glue_exchange(c));   // multi-GPU: pieces + junction log of all ranks
     if (!c->joined) CK(glue_join_impl<W>(c, false));         // (cdbg_glue_join ran it already in the sharded flow)
     hipStream_t s = c->stream;
     const uint64_t NP = c->n_pieces;
     const uint32_t NS = (uint32_t)(2 * NP);
     const float ms_join = c->st.ms_glue;
     Timer t; CK(t.start(s));
-    DBuf<uint32_t> flag; DBuf<uint4> st_a, st_b;
+    DBuf<uint32_t>& flag = c->rank_flag; DBuf<uint4>& st_a = c->rank_a; DBuf<uint4>& st_b = c->rank_b;
     CK(st_a.alloc(NS, false)); CK(st_b.alloc(NS, false));
     CK(flag.alloc(4, true));
     HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
@@ -756,6 +862,8 @@ int glue_impl(cdbg_ctx* c) {
         hp.n_states = NS; hp.k = c->k; hp.link = link_p; hp.st = fa_st; hp.hinfo = (fa_st == st_a.p) ? st_b.p : st_a.p;
         hp.unitig_off = c->unitig_off.p; hp.unitig_len = c->unitig_len.p; hp.unitig_kc = c->unitig_kc.p;
         hp.unitig_cap = ucap; hp.out_cap = ocap; hp.n_unitigs = c->cursors.p + 2; hp.out_cursor = c->cursors.p + 3; hp.error = c->derr.p;
+        hp.own_lo = 0; hp.own_hi = NS;
+        if (c->prm.world_size > 1 && !c->prm.emit_replicated && c->xchg_done) { hp.own_lo = (uint32_t)(2 * c->piece_lo); hp.own_hi = (uint32_t)(2 * c->piece_hi); }
         CDBG_LAUNCH(k_unitig_heads, (NS + HEADS_PER_WG - 1) / HEADS_PER_WG, GLUE_THREADS, s, hp);
         EmitParams ep{};
         ep.n_pieces = (uint32_t)NP; ep.k = c->k; ep.st = fa_st; ep.hinfo = hp.hinfo;
@@ -849,13 +957,19 @@ int cdbg_create(const cdbg_params* p, cdbg_ctx** out) {
 
 void cdbg_destroy(cdbg_ctx* c) {
     if (!c) return;
+    (void)hipSetDevice(c->prm.device_id);
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     ingest_release(c);
+#ifndef CDBG_HOSTSIM
+    if (c->rccl) { c->rccl->destroy(); delete c->rccl; c->rccl = nullptr; }
+#endif
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 int cdbg_push_reads(cdbg_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads) {
     if (!c || !bases || !offsets) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 0 || c->reads_final) return fail(CDBG_E_STATE, "reads must be pushed before the first stage");
     for (uint64_t i = 0; i < n_reads; ++i) {
         if (offsets[i + 1] < offsets[i]) return fail(CDBG_E_PARAM, "offsets not monotone at read %llu", (unsigned long long)i);
@@ -866,6 +980,7 @@ int cdbg_push_reads(cdbg_ctx* c, const char* bases, const uint64_t* offsets, uin
 }
 int cdbg_push_text(cdbg_ctx* c, const char* text, uint64_t nbytes) {
     if (!c || (!text && nbytes)) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 0 || c->reads_final) return fail(CDBG_E_STATE, "reads must be pushed before the first stage");
     CK(ingest_append(c, text, nbytes));
     CK(ingest_append(c, "\n", 1));
@@ -873,6 +988,7 @@ int cdbg_push_text(cdbg_ctx* c, const char* text, uint64_t nbytes) {
 }
 int cdbg_generate_reads(cdbg_ctx* c, uint64_t first_read, uint64_t n_reads, uint64_t total_reads, uint64_t read_len, int cfg) {
     if (!c) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 0 || c->reads_final || c->n_dev || c->pin_fill) return fail(CDBG_E_STATE, "reads already present");
     if (!n_reads || !read_len || total_reads < n_reads) return fail(CDBG_E_PARAM, "bad synthetic read set");
     const uint64_t n = n_reads * (read_len + 1);
@@ -888,6 +1004,7 @@ int cdbg_generate_reads(cdbg_ctx* c, uint64_t first_read, uint64_t n_reads, uint
 }
 int cdbg_read_text(cdbg_ctx* c, uint64_t first_byte, uint64_t nbytes, char* out) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     CK(upload_pending(c));
     if (first_byte + nbytes > c->nbytes) return fail(CDBG_E_PARAM, "range beyond the resident text");
     HIPCK(hipMemcpy(out, c->reads.p + first_byte, nbytes, hipMemcpyDeviceToHost));
@@ -903,6 +1020,7 @@ int cdbg_read_text(cdbg_ctx* c, uint64_t first_byte, uint64_t nbytes, char* out)
 static int count_dispatch(cdbg_ctx* c) { DISPATCH_W(count_impl) }
 int cdbg_count(cdbg_ctx* c) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 0) return fail(CDBG_E_STATE, "cdbg_count called twice");
     CK(count_dispatch(c));
     // Compaction handles a bucket in LDS up to 1024 entries (2 x TSK / 2); beyond that it falls back to tables in HBM,
@@ -911,10 +1029,16 @@ int cdbg_count(cdbg_ctx* c) {
     // bucket can be several times what the compaction tiers hold.  One look at the exact number after counting:
     // if the mean is above 300 entries, count again with enough partitions for ~150 per bucket (scan + count are
     // cheap next to the fallback), unless the caller fixed the partition count.
-    const uint64_t per_bucket = (c->st.n_solid + c->st.n_solid_travellers) / std::max<uint64_t>(c->n_local_parts, 1);
-    // (single rank only: with several ranks the decision would have to be taken collectively -- every rank must use the
-    // same partitioning -- and each rank sees only its own shard's counts)
-    if (c->prm.world_size == 1 && c->prm.log2_partitions < 0 && c->log_np_override < 0 && per_bucket > 300 && c->log_np < 26) {
+    // (several ranks: the decision is taken on the sum over the ranks -- every rank must use the same partitioning)
+    uint64_t entries = c->st.n_solid + c->st.n_solid_travellers, parts = std::max<uint64_t>(c->n_local_parts, 1);
+    if (c->prm.world_size > 1 || c->force_multi) {
+        std::vector<uint64_t> all(c->prm.world_size);
+        if (c->tr.all_gather_u64(c->tr.user, &entries, all.data(), 1) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
+        entries = 0; for (uint64_t v : all) entries += v;
+        parts *= (uint64_t)c->prm.world_size;
+    }
+    const uint64_t per_bucket = entries / parts;
+    if (c->prm.log2_partitions < 0 && c->log_np_override < 0 && per_bucket > 300 && c->log_np < 26) {
         int extra = 1; while ((per_bucket >> extra) > 150 && c->log_np + extra < 26) ++extra;
         const float first_ms = c->st.ms_total;
         c->log_np_override = c->log_np + extra;
@@ -924,13 +1048,14 @@ int cdbg_count(cdbg_ctx* c) {
     }
     return CDBG_OK;
 }
-int cdbg_compact(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(compact_impl) }
-int cdbg_glue(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(glue_impl) }
+int cdbg_compact(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); (void)hipSetDevice(c->prm.device_id); DISPATCH_W(compact_impl) }
+int cdbg_glue(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); (void)hipSetDevice(c->prm.device_id); DISPATCH_W(glue_impl) }
 // ---- multi-GPU: sharded junction join.  After cdbg_exchange_end every rank holds the union of the glue records;
 // instead of every rank joining all of them, cdbg_glue_join joins this rank's share of the junctions, the caller
 // MAX-all-reduces the int32 link arrays (cdbg_glue_links_export / _import) and cdbg_glue then ranks and emits ----
 int cdbg_glue_join(cdbg_ctx* c, uint64_t* n_ends) {
     if (!c || !n_ends) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_glue_join needs a compacted, not yet glued context");
     int rc;
     switch (c->W) { case 1: rc = glue_join_impl<1>(c, true); break; case 2: rc = glue_join_impl<2>(c, true); break; default: rc = glue_join_impl<4>(c, true); }
@@ -939,6 +1064,7 @@ int cdbg_glue_join(cdbg_ctx* c, uint64_t* n_ends) {
 }
 int cdbg_glue_links_export(cdbg_ctx* c, void* dst_dev, uint64_t nbytes) {
     if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (!c->joined) return fail(CDBG_E_STATE, "cdbg_glue_links_export before cdbg_glue_join");
     const uint64_t have = 2 * c->n_pieces * sizeof(uint32_t);
     if (nbytes < have) return fail(CDBG_E_PARAM, "link buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)have);
@@ -948,6 +1074,7 @@ int cdbg_glue_links_export(cdbg_ctx* c, void* dst_dev, uint64_t nbytes) {
 }
 int cdbg_glue_links_import(cdbg_ctx* c, const void* src_dev, uint64_t nbytes) {
     if (!c || !src_dev) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (!c->joined) return fail(CDBG_E_STATE, "cdbg_glue_links_import before cdbg_glue_join");
     const uint64_t have = 2 * c->n_pieces * sizeof(uint32_t);
     if (nbytes < have) return fail(CDBG_E_PARAM, "link buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)have);
@@ -956,14 +1083,16 @@ int cdbg_glue_links_import(cdbg_ctx* c, const void* src_dev, uint64_t nbytes) {
     return CDBG_OK;
 }
 int cdbg_run(cdbg_ctx* c) { CK(cdbg_count(c)); CK(cdbg_compact(c)); return cdbg_glue(c); }
-int cdbg_link(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); DISPATCH_W(link_impl) }
+int cdbg_link(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); (void)hipSetDevice(c->prm.device_id); DISPATCH_W(link_impl) }
 int cdbg_num_links(cdbg_ctx* c, uint64_t* n) {
     if (!c || !n) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (!c->linked) return fail(CDBG_E_STATE, "cdbg_num_links before cdbg_link");
     *n = c->n_links; return CDBG_OK;
 }
 int cdbg_fetch_links(cdbg_ctx* c, uint64_t* end_off, uint32_t* link_to) {
     if (!c || !end_off) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (!c->linked) return fail(CDBG_E_STATE, "cdbg_fetch_links before cdbg_link");
     HIPCK(hipMemcpy(end_off, c->link_off.p, (2 * c->n_unitigs + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (c->n_links && link_to) HIPCK(hipMemcpy(link_to, c->link_to.p, c->n_links * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -971,18 +1100,22 @@ int cdbg_fetch_links(cdbg_ctx* c, uint64_t* end_off, uint32_t* link_to) {
 }
 int cdbg_reset(cdbg_ctx* c) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     c->stage = 0; c->st = cdbg_stats_t{};
     c->n_solid_entries = c->n_pieces = c->n_piece_bases = c->n_unitigs = c->unitig_total = 0; c->linked = false; c->n_links = 0; c->joined = false;
+    c->xchg_done = false; c->comm_bytes = 0; c->piece_lo = c->piece_hi = 0;
     return CDBG_OK;                                  // reads and every device buffer stay resident
 }
 
 int cdbg_num_solid(cdbg_ctx* c, uint64_t* n) {
     if (!c || !n) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage < 1) return fail(CDBG_E_STATE, "cdbg_num_solid before cdbg_count");
     *n = c->st.n_solid; return CDBG_OK;
 }
 int cdbg_fetch_solid(cdbg_ctx* c, char* kmers, uint32_t* counts, uint64_t capacity, uint64_t* n_written) {
     if (!c || !kmers || !counts || !n_written) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage < 1) return fail(CDBG_E_STATE, "cdbg_fetch_solid before cdbg_count");
     if (capacity < c->st.n_solid) return fail(CDBG_E_PARAM, "capacity %llu < %llu solid k-mers", (unsigned long long)capacity, (unsigned long long)c->st.n_solid);
     const uint64_t S = c->st.n_solid, E = c->n_solid_entries;
@@ -1003,11 +1136,13 @@ int cdbg_fetch_solid(cdbg_ctx* c, char* kmers, uint32_t* counts, uint64_t capaci
 }
 int cdbg_num_unitigs(cdbg_ctx* c, uint64_t* n, uint64_t* total_bases) {
     if (!c || !n) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_num_unitigs before cdbg_glue");
     *n = c->n_unitigs; if (total_bases) *total_bases = c->unitig_total; return CDBG_OK;
 }
 int cdbg_fetch_unitigs(cdbg_ctx* c, uint64_t first, uint64_t n, char* seq_buf, uint64_t* seq_off, uint64_t* kc) {
     if (!c || !seq_buf || !seq_off || !kc) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_fetch_unitigs before cdbg_glue");
     if (first + n > c->n_unitigs) return fail(CDBG_E_PARAM, "unitig range out of bounds");
     if (!n) { seq_off[0] = 0; return CDBG_OK; }
@@ -1033,6 +1168,7 @@ int cdbg_fetch_unitigs(cdbg_ctx* c, uint64_t first, uint64_t n, char* seq_buf, u
 // of caller-provided device buffers) and merged in rank order, after which cdbg_glue runs on the union ----
 int cdbg_exchange_sizes(cdbg_ctx* c, uint64_t out[3]) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->prm.all_abundance_counts) return fail(CDBG_E_PARAM, "-all-abundance-counts is single-GPU only in this version");
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
     out[0] = c->n_pieces; out[1] = c->n_piece_bases; out[2] = c->n_glog;
@@ -1040,6 +1176,7 @@ int cdbg_exchange_sizes(cdbg_ctx* c, uint64_t out[3]) {
 }
 int cdbg_exchange_export(cdbg_ctx* c, int what, void* dst_dev, uint64_t nbytes) {
     if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_export before cdbg_compact");
     const void* src = nullptr; uint64_t have = 0;
     switch (what) {
@@ -1058,6 +1195,7 @@ int cdbg_exchange_export(cdbg_ctx* c, int what, void* dst_dev, uint64_t nbytes) 
 }
 int cdbg_exchange_begin(cdbg_ctx* c, uint64_t total_pieces, uint64_t total_bases, uint64_t total_glog) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_begin before cdbg_compact");
     // the merged arrays are swapped with the context's own in cdbg_exchange_end: give them at least the same
     // capacity, so that a re-run after cdbg_reset finds arrays that are large enough and never reallocates
@@ -1090,6 +1228,7 @@ int cdbg_exchange_add(cdbg_ctx* c, uint64_t n_pieces, uint64_t n_bases, uint64_t
 // out) and the per-piece base offsets do not travel at all -- the receiver recomputes them from the piece lengths ----
 int cdbg_exchange_sizes_packed(cdbg_ctx* c, uint64_t out[4]) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->prm.all_abundance_counts) return fail(CDBG_E_PARAM, "-all-abundance-counts is single-GPU only in this version");
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
     hipStream_t s = c->stream;
@@ -1120,6 +1259,7 @@ int cdbg_exchange_sizes_packed(cdbg_ctx* c, uint64_t out[4]) {
 }
 int cdbg_exchange_export_packed(cdbg_ctx* c, void* dst_dev, uint64_t nbytes) {
     if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 2 || !c->xp_bases.p) return fail(CDBG_E_STATE, "cdbg_exchange_export_packed before cdbg_exchange_sizes_packed");
     if (nbytes < c->xp_bytes) return fail(CDBG_E_PARAM, "export buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)c->xp_bytes);
     if (c->xp_bytes) HIPCK(hipMemcpyAsync(dst_dev, c->xp_bases.p, c->xp_bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -1164,6 +1304,7 @@ int cdbg_exchange_add_packed(cdbg_ctx* c, uint64_t n_pieces, uint64_t n_bases, u
 }
 int cdbg_exchange_end(cdbg_ctx* c) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (!c->mg_open) return fail(CDBG_E_STATE, "cdbg_exchange_end without cdbg_exchange_begin");
     c->piece_n.swap(c->mg_n); c->piece_kc.swap(c->mg_kc); c->piece_boff.swap(c->mg_boff);
     c->piece_bases.swap(c->mg_bases); c->glog_keys.swap(c->mg_gkeys); c->glog_tag.swap(c->mg_gtag);
@@ -1185,6 +1326,7 @@ int cdbg_exchange_end(cdbg_ctx* c) {
 
 int cdbg_fetch_unitig_abundances(cdbg_ctx* c, uint64_t first, uint64_t n, uint32_t* ab, uint64_t* ab_off) {
     if (!c || !ab || !ab_off) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_fetch_unitig_abundances before cdbg_glue");
     if (!c->prm.all_abundance_counts) return fail(CDBG_E_STATE, "context was created without all_abundance_counts");
     if (first + n > c->n_unitigs) return fail(CDBG_E_PARAM, "unitig range out of bounds");
@@ -1203,8 +1345,53 @@ int cdbg_fetch_unitig_abundances(cdbg_ctx* c, uint64_t first, uint64_t n, uint32
     ab_off[n] = w;
     return CDBG_OK;
 }
+int cdbg_set_transport(cdbg_ctx* c, const cdbg_transport* t) {
+    if (!c || !t || !t->all_gather_u64 || !t->all_to_all_v || !t->all_gather_v || !t->all_reduce_max_i32) return fail(CDBG_E_PARAM, "null transport");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
+    c->tr = *t; c->have_tr = true; c->force_multi = getenv("CDBG_FORCE_MULTI") != nullptr; return CDBG_OK;
+}
+int cdbg_comm_unique_id(void* out) {
+    if (!out) return fail(CDBG_E_PARAM, "null argument");
+#ifdef CDBG_HOSTSIM
+    return fail(CDBG_E_NODEVICE, "no RCCL in the simulator build");
+#else
+    std::string err; RcclApi& A = rccl_api();
+    if (!A.load(err)) return fail(CDBG_E_NODEVICE, "%s", err.c_str());
+    RcclApi::UniqueId id; const int rc = A.GetUniqueId(&id);
+    if (rc != 0) return fail(CDBG_E_NODEVICE, "ncclGetUniqueId: %s", A.GetErrorString(rc));
+    memcpy(out, &id, sizeof id); return CDBG_OK;
+#endif
+}
+int cdbg_comm_init_rccl(cdbg_ctx* c, const void* uid) {
+    if (!c || !uid) return fail(CDBG_E_PARAM, "null argument");
+#ifdef CDBG_HOSTSIM
+    return fail(CDBG_E_NODEVICE, "no RCCL in the simulator build");
+#else
+    HIPCK(hipSetDevice(c->prm.device_id));
+    if (c->rccl) { c->rccl->destroy(); delete c->rccl; c->rccl = nullptr; }
+    c->rccl = new RcclComm();
+    if (!c->rccl->init(uid, c->prm.world_size, c->prm.rank, c->stream)) { const std::string e = c->rccl->err; delete c->rccl; c->rccl = nullptr; return fail(CDBG_E_NODEVICE, "RCCL: %s", e.c_str()); }
+    c->tr = c->rccl->transport(); c->have_tr = true; c->force_multi = getenv("CDBG_FORCE_MULTI") != nullptr;
+    return CDBG_OK;
+#endif
+}
+int cdbg_comm_bytes(cdbg_ctx* c, uint64_t* out) { if (!c || !out) return fail(CDBG_E_PARAM, "null argument"); *out = c->comm_bytes; return CDBG_OK; }
+int cdbg_digest(cdbg_ctx* c, uint64_t out[4]) {
+    if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
+    if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_digest before cdbg_glue");
+    DBuf<uint64_t> d; CK(d.alloc(4, true));
+    DigestParams dp{ c->n_unitigs, c->k, c->unitig_off.p, c->unitig_len.p, c->unitig_kc.p, c->unitig_bases.p,
+                     c->seg_off.p, c->seg_n.p, c->solid_cnt.p, c->n_local_parts, d.p };
+    if (c->n_unitigs) CDBG_LAUNCH(k_digest_unitigs, std::min<uint64_t>((c->n_unitigs + 255) / 256, 1u << 16), 256, c->stream, dp);
+    CDBG_LAUNCH(k_digest_solid, std::min<uint64_t>((c->n_local_parts + 255) / 256, 1u << 16), 256, c->stream, dp);
+    HIPCK(hipStreamSynchronize(c->stream));
+    CK(read_u64(d.p, out, 4));
+    return CDBG_OK;
+}
 int cdbg_stats(cdbg_ctx* c, cdbg_stats_t* out) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     *out = c->st; return CDBG_OK;
 }
 

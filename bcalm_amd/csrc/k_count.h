@@ -591,4 +591,41 @@ __global__ void k_repair_gather(RepairParams P) {
         P.out[o0 + nreg + i] = P.spill_recs[(uint64_t)P.order[s0 + i / P.RW] * P.RW + i % P.RW];
 }
 
+
+// ---- multi-GPU (reads sharded over the ranks): merge the record blocks received from every rank ----
+// Sender s delivered, for each of this rank's partitions lp, xcnt[s][lp] records, sorted by lp, at record index
+// xbase[s] + xoff[s][lp] of the receive buffer.  Partition lp of the merged array = its segments in sender order.
+struct SumCountParams { const uint32_t* xcnt; int world; uint64_t npl; uint32_t* total; };
+__global__ void k_sum_counts(SumCountParams P) {
+    const uint64_t lp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lp >= P.npl) return;
+    uint32_t t = 0;
+    for (int s = 0; s < P.world; ++s) t += P.xcnt[(uint64_t)s * P.npl + lp];
+    P.total[lp] = t;
+}
+struct MergeRecParams {
+    const uint32_t* xcnt; const uint64_t* xoff; const uint64_t* xbase; int world; uint64_t npl; int RW;
+    const uint64_t* xrecs; const uint64_t* part_off; uint64_t* out; uint64_t* stats;   // stats[0] member k-mers, [1] traveller members
+};
+__global__ void k_merge_records(MergeRecParams P) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint64_t members = 0, trav = 0;
+    for (uint64_t lp = wave; lp < P.npl; lp += n_waves) {
+        uint64_t dst = P.part_off[lp] * P.RW;
+        for (int s = 0; s < P.world; ++s) {
+            const uint64_t n = (uint64_t)P.xcnt[(uint64_t)s * P.npl + lp] * P.RW;
+            const uint64_t* src = P.xrecs + (P.xbase[s] + P.xoff[(uint64_t)s * (P.npl + 1) + lp]) * P.RW;
+            for (uint64_t i = lane; i < n; i += 64) {
+                const uint64_t w = src[i];
+                P.out[dst + i] = w;
+                if (i % P.RW == 0) { members += w & 0xFFu; trav += ((w >> 8) & 1u) + ((w >> 9) & 1u); }
+            }
+            dst += n;
+        }
+    }
+    members = wave_sum_u64(members); trav = wave_sum_u64(trav);
+    if (lane == 0) { if (members) atomic_add_u64(&P.stats[0], members); if (trav) atomic_add_u64(&P.stats[1], trav); }
+}
+
 }  // namespace cdbg

@@ -138,6 +138,7 @@ struct HeadParams {
     uint64_t* unitig_off; uint32_t* unitig_len; uint64_t* unitig_kc;
     uint64_t unitig_cap, out_cap;
     uint64_t* n_unitigs; uint64_t* out_cursor; uint32_t* error;
+    uint32_t own_lo, own_hi;       // multi-GPU, owner-sharded emission: only heads e with own_lo <= e < own_hi get a unitig here
 };
 // One workgroup per HEADS_PER_WG consecutive states (HEADS_ITEMS per lane): the heads of the workgroup get
 // consecutive unitig ids and output space from ONE device reservation; positions inside the batch come from a
@@ -158,7 +159,10 @@ __global__ void k_unitig_heads(HeadParams P) {
         len[i] = 0;
         if (e < P.n_states && P.link[e] == NONE32) {
             const uint4 v = P.st[e];
-            if (v.y != 0 && v.z > P.st[e ^ 1u].z) { len[i] = v.y + (uint32_t)P.k - 1u; ++cnt; sum += len[i]; }
+            if (v.y != 0 && v.z > P.st[e ^ 1u].z) {
+                if (e >= P.own_lo && e < P.own_hi) { len[i] = v.y + (uint32_t)P.k - 1u; ++cnt; sum += len[i]; }
+                else { uint4 h; h.x = NONE32; h.y = 0; h.z = 0; h.w = 0; P.hinfo[e] = h; }   // another rank's unitig: its pieces are skipped by k_emit
+            }
         }
     }
     // exclusive scan of (cnt, sum) over the workgroup: wave shuffles, then the wave totals through LDS

@@ -80,4 +80,46 @@ __global__ void k_link_fill(LinkParams P) {
     for (uint32_t i = 0; i < c; ++i) P.link_to[o + i] = P.lk_ends[s * 8 + other * 4 + i];
 }
 
+
+// ---- result digests (cdbg_digest): size-independent checks at sizes no oracle can follow ----
+// Per unitig an orientation-independent 64-bit hash: polynomial hashes of the sequence and of its reverse complement,
+// combined symmetrically, mixed with KC; the set digest is the SUM over unitigs (order independent).  tests/ hold the
+// same formula in Python and pin it against the oracle's unitigs on small inputs.
+struct DigestParams {
+    uint64_t n_unitigs; int k;
+    const uint64_t* unitig_off; const uint32_t* unitig_len; const uint64_t* unitig_kc; const uint8_t* bases;
+    const uint64_t* seg_off; const uint32_t* seg_n; const uint32_t* solid_cnt; uint64_t n_parts;
+    uint64_t* out;                 // [0] sum KC  [1] sum of solid (home) counts  [2] set digest  [3] sum (LN - k + 1)
+};
+CDBG_DEV uint32_t digest_code(uint8_t c) { return ((c >> 1) ^ (c >> 2)) & 3u; }   // A0 C1 G2 T3 (kmer.h base_code)
+__global__ void k_digest_unitigs(DigestParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t kc_sum = 0, dig = 0, km_sum = 0;
+    for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < P.n_unitigs; u += stride) {
+        const uint8_t* b = P.bases + P.unitig_off[u];
+        const uint32_t n = P.unitig_len[u];
+        const uint64_t B = 0x100000001B3ULL;
+        uint64_t hf = 0, hr = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            hf = hf * B + (uint64_t)(digest_code(b[i]) + 1u);
+            hr = hr * B + (uint64_t)(3u - digest_code(b[n - 1 - i]) + 1u);
+        }
+        const uint64_t kc = P.unitig_kc[u];
+        dig += mix64((hf + hr) ^ mix64(hf * hr + kc));
+        kc_sum += kc; km_sum += (uint64_t)n - (uint64_t)P.k + 1u;
+    }
+    kc_sum = wave_sum_u64(kc_sum); dig = wave_sum_u64(dig); km_sum = wave_sum_u64(km_sum);
+    if ((threadIdx.x & 63) == 0) { atomic_add_u64(&P.out[0], kc_sum); atomic_add_u64(&P.out[2], dig); atomic_add_u64(&P.out[3], km_sum); }
+}
+__global__ void k_digest_solid(DigestParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t s = 0;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P.n_parts; p += stride) {
+        const uint64_t so = P.seg_off[p];
+        for (uint32_t e = 0, n = P.seg_n[p]; e < n; ++e) { const uint32_t c = P.solid_cnt[so + e]; if (!(c & TRAV_FLAG)) s += c; }
+    }
+    s = wave_sum_u64(s);
+    if ((threadIdx.x & 63) == 0 && s) atomic_add_u64(&P.out[1], s);
+}
+
 }  // namespace cdbg

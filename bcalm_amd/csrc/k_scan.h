@@ -63,6 +63,7 @@ struct ScanParams {
     // part_fill[p] counts the records offered; records beyond the capacity go to the spill list
     uint32_t part_cap; uint32_t* part_fill;
     uint64_t* spill_recs; uint32_t* spill_part; uint64_t* spill_cursor; uint64_t spill_cap; uint32_t* error;
+    uint32_t emit_all, npl;      // multi-GPU with sharded reads: emit every partition, slot = owner * npl + local partition
 };
 constexpr int SCAN_HIST = 0, SCAN_EMIT = 1, SCAN_EMIT_CAPPED = 2;
 
@@ -228,8 +229,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
         if (!((stt[bit >> 6] >> (bit & 63)) & 1ULL)) continue;
         const uint32_t gq = g[jq];
         const uint32_t part = part_of(gq, P.log_np);
-        if ((part & rank_mask) != (uint32_t)P.rank) continue;
-        const uint32_t lpart = part >> P.rank_bits;
+        // own partitions only (every rank scans the same text), or -- reads sharded over the ranks -- all partitions, laid
+        // out owner-major ([owner][local partition]) so that each owner's block of the record array is contiguous
+        if (!P.emit_all && (part & rank_mask) != (uint32_t)P.rank) continue;
+        const uint32_t lpart = P.emit_all ? (part & rank_mask) * P.npl + (part >> P.rank_bits) : part >> P.rank_bits;
         // run end: next break bit after `bit`
         int e;
         {

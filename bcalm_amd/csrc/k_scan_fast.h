@@ -194,8 +194,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
         const int s = sl[i];                                // run = junctions [s, e] in q space
         const uint32_t g0 = kg[scanf_pad(s)];
         const uint32_t part = part_of(g0, P.log_np);
-        if ((part & rank_mask) != (uint32_t)P.rank) continue;
-        const uint32_t lpart = part >> P.rank_bits;
+        // own partitions only (every rank scans the same text), or -- reads sharded over the ranks -- all partitions, laid
+        // out owner-major ([owner][local partition]) so that each owner's block of the record array is contiguous
+        if (!P.emit_all && (part & rank_mask) != (uint32_t)P.rank) continue;
+        const uint32_t lpart = P.emit_all ? (part & rank_mask) * P.npl + (part >> P.rank_bits) : part >> P.rank_bits;
         int e;
         {
             int nb = s + 1;

@@ -1,70 +1,124 @@
-"""Multi-GPU glue exchange: one process per GPU, torch.distributed (backend "nccl" = RCCL over
-xGMI on the GPU box; "gloo" in the CPU tests with the simulator library).
+"""Multi-GPU set-up: one process per GPU.
 
-Minimizer partitions are sharded over the ranks (cdbg_params.world_size / rank): every rank scans
-the same resident reads and counts / compacts only the partitions it owns.  What has to cross
-ranks are the glue records: pieces (length, abundance, bases packed 4 per byte) and the glue log
-(junction key, piece-end id / CONFIRM).  They are gathered with all_gather_into_tensor and merged in rank order
-by libcdbg (cdbg_exchange_*).  The junction hash-join over the union is sharded by key hash
-(cdbg_glue_join) and its result, one partner id per piece end, is combined with a MAX all-reduce;
-every rank then ranks the chains and emits, and holds the complete unitig set.  torch only moves
-bytes here; all compute stays in the HIP library.
+The data path lives in libcdbg.so (include/cdbg.h, "Multi-GPU"): a context with world_size > 1 shards
+the reads over the ranks, all-to-all-v's the super-k-mer records to the partition owners, all-gathers
+the pieces + junction log, joins the junctions sharded by key hash, and every rank emits the unitigs
+whose first piece it owns.  The bytes move through the context's TRANSPORT:
+
+  * `init_rccl(graph, dist)`      the product path: RCCL inside libcdbg.so (ncclSend/ncclRecv all-to-all-v,
+                                  ncclAllGather, ncclAllReduce over xGMI).  torch.distributed is used for ONE thing:
+                                  broadcasting rank 0's 128-byte ncclUniqueId.
+  * `TorchTransport(dist)`        the four transport functions implemented with torch.distributed on HOST memory
+                                  (gloo): what the CPU tests plug into the kernel-logic simulator, whose "device"
+                                  pointers are host pointers.  Never used on a GPU.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
-
-def _gather_bytes(dist, device, world, graph, nbytes_per_rank, export):
-    """all-gather one variable-length byte array (padded to the longest rank); -> (tensor, stride)"""
-    pad = max(max(nbytes_per_rank), 16)
-    pad = (pad + 15) // 16 * 16
-    send = torch.empty(pad, dtype=torch.uint8, device=device)
-    export(send.data_ptr(), pad)
-    recv = torch.empty(world * pad, dtype=torch.uint8, device=device)
-    dist.all_gather_into_tensor(recv, send)
-    return recv, pad
+U64P = C.POINTER(C.c_uint64)
+FN_AG64 = C.CFUNCTYPE(C.c_int, C.c_void_p, U64P, U64P, C.c_int)
+FN_A2AV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, U64P, U64P, C.c_void_p, U64P, U64P)
+FN_AGV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, U64P, U64P)
+FN_ARMAX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
 
 
-def exchange_glue(graph, dist, device, W: int, sharded_join: bool = True):
-    """all-gather every rank's pieces + glue log and merge them into `graph` (stage: compacted).
-    On the wire per rank: piece lengths (u32), piece abundance sums (u64), piece bases packed 4 per byte with the
-    reservation gaps squeezed out (no base offsets: the receiver recomputes them), glue-log keys and tags."""
-    world = dist.get_world_size()
-    device = torch.device(device)
-    mine = torch.tensor(graph.exchange_sizes_packed(), dtype=torch.int64, device=device)      # pieces, bases, glog, packed bytes
-    sizes = torch.empty(world * 4, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(sizes, mine)
-    sizes = sizes.view(world, 4).cpu().tolist()
-    col = lambda j: [int(sizes[r][j]) for r in range(world)]
-    parts = [
-        _gather_bytes(dist, device, world, graph, [n * 4 for n in col(0)], lambda p, n: graph.exchange_export(0, p, n)),          # piece_n
-        _gather_bytes(dist, device, world, graph, [n * 8 for n in col(0)], lambda p, n: graph.exchange_export(1, p, n)),          # piece_kc
-        _gather_bytes(dist, device, world, graph, col(3), lambda p, n: graph.exchange_export_packed(p, n)),                        # packed bases
-        _gather_bytes(dist, device, world, graph, [n * 8 * W for n in col(2)], lambda p, n: graph.exchange_export(4, p, n)),      # glog keys
-        _gather_bytes(dist, device, world, graph, [n * 4 for n in col(2)], lambda p, n: graph.exchange_export(5, p, n)),          # glog tags
-    ]
-    if device.type == "cuda":
-        torch.cuda.synchronize(device)                   # collectives run on torch's stream, libcdbg on its own
-    totals = [sum(col(j)) for j in range(3)]
-    graph.exchange_begin(*totals)
-    for r in range(world):
-        ptrs = [recv.data_ptr() + r * pad for recv, pad in parts]
-        graph.exchange_add_packed(int(sizes[r][0]), int(sizes[r][1]), int(sizes[r][3]), int(sizes[r][2]), ptrs)
-    gathered = parts
-    graph.exchange_end()
-    info = {"pieces": totals[0], "piece_bases": totals[1], "glue_records": totals[2],
-            "bytes_gathered": sum(recv.numel() for recv, _ in gathered)}
-    del gathered
-    if sharded_join and world > 1:
-        # every rank hash-joins 1/world of the junctions; the link arrays (one int32 per piece end, -1 = not
-        # joined by this rank) are combined with ONE all-reduce(MAX): each end is set by exactly one rank
-        n = graph.glue_join()
-        links = torch.empty(max(n, 1), dtype=torch.int32, device=device)
-        graph.glue_links_export(links.data_ptr(), n * 4)
-        dist.all_reduce(links, op=dist.ReduceOp.MAX)
-        if device.type == "cuda":
-            torch.cuda.synchronize(device)
-        graph.glue_links_import(links.data_ptr(), n * 4)
-        info["link_bytes_reduced"] = n * 4
-    return info
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather_u64", FN_AG64), ("all_to_all_v", FN_A2AV),
+                ("all_gather_v", FN_AGV), ("all_reduce_max_i32", FN_ARMAX)]
+
+
+def init_rccl(graph, dist, device=None):
+    """RCCL communicator inside libcdbg for `graph` (created with world_size / rank); collective over `dist`'s group."""
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if dist.get_rank() == 0:
+        buf = (C.c_uint8 * 128)()
+        graph._ck(graph.lib.cdbg_comm_unique_id(buf))
+        uid = torch.tensor(list(buf), dtype=torch.uint8)
+    if device is not None:
+        uid = uid.to(device)
+    dist.broadcast(uid, src=0)
+    raw = bytes(uid.cpu().tolist())
+    graph._ck(graph.lib.cdbg_comm_init_rccl(graph._h, raw))
+
+
+def _host_tensor(ptr, nbytes):
+    """zero-copy uint8 view of host memory (the simulator's 'device' buffers)"""
+    if not nbytes:
+        return torch.empty(0, dtype=torch.uint8)
+    return torch.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=torch.uint8)
+
+
+class TorchTransport:
+    """cdbg_transport over torch.distributed point-to-point / collectives on host memory (gloo). Keep the object
+    alive as long as the graph uses it (it owns the ctypes callbacks)."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.error = None
+        self._cbs = (FN_AG64(self._ag64), FN_A2AV(self._a2av), FN_AGV(self._agv), FN_ARMAX(self._armax))
+        self.struct = Transport(None, *self._cbs)
+
+    def attach(self, graph):
+        graph._ck(graph.lib.cdbg_set_transport(graph._h, C.byref(self.struct)))
+        graph._transport = self                          # keep-alive
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except Exception as e:                           # a Python exception must not unwind through C
+            self.error = e
+            return -1
+
+    def _ag64(self, user, send, recv, n):
+        def run():
+            mine = torch.tensor([send[i] for i in range(n)], dtype=torch.int64)
+            out = [torch.empty(n, dtype=torch.int64) for _ in range(self.world)]
+            self.dist.all_gather(out, mine)
+            for r in range(self.world):
+                for i in range(n):
+                    recv[r * n + i] = int(out[r][i]) & 0xFFFFFFFFFFFFFFFF
+        return self._guard(run)
+
+    def _exchange(self, sends, recvs):
+        """sends[r] / recvs[r]: uint8 tensors for / from rank r (own slot: local copy)"""
+        ops = []
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            if sends[r].numel():
+                ops.append(self.dist.P2POp(self.dist.isend, sends[r].clone(), r))
+            if recvs[r].numel():
+                ops.append(self.dist.P2POp(self.dist.irecv, recvs[r], r))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        if recvs[self.rank].numel():
+            recvs[self.rank].copy_(sends[self.rank])
+
+    def _a2av(self, user, send, soff, scnt, recv, roff, rcnt):
+        def run():
+            sends = [_host_tensor(send + soff[r], scnt[r]) for r in range(self.world)]
+            recvs = [_host_tensor(recv + roff[r], rcnt[r]) for r in range(self.world)]
+            self._exchange(sends, recvs)
+        return self._guard(run)
+
+    def _agv(self, user, send, nbytes, recv, roff, rcnt):
+        def run():
+            mine = _host_tensor(send, nbytes)
+            sends = [mine for _ in range(self.world)]
+            recvs = [_host_tensor(recv + roff[r], rcnt[r]) for r in range(self.world)]
+            self._exchange(sends, recvs)
+        return self._guard(run)
+
+    def _armax(self, user, dev, n):
+        def run():
+            if n:
+                t = _host_tensor(dev, n * 4).view(torch.int32)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return self._guard(run)

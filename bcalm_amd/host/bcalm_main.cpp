@@ -11,12 +11,14 @@
 // this file is the replacement for bcalm_1::execute()/Functor (src/bcalm_1.cpp:49-97).
 #include <zlib.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cdbg.h"
@@ -29,7 +31,7 @@ namespace {
 
 struct Options {
     std::string in, out;
-    int k = 31, amin = 2, m = 0, device = 0, log_np = -1;
+    int k = 31, amin = 2, m = 0, device = 0, log_np = -1, n_gpus = 1;
     bool gfa = false, verbose = false, all_ab = false;
     std::string solid_out;
 };
@@ -51,6 +53,7 @@ Options parse(int argc, char** argv) {
         else if (a == "-minimizer-size") o.m = atoi(need("-minimizer-size"));
         else if (a == "-device") o.device = atoi(need("-device"));
         else if (a == "-log2-partitions") o.log_np = atoi(need("-log2-partitions"));
+        else if (a == "-nb-gpus") o.n_gpus = atoi(need("-nb-gpus"));   // the GPU path's counterpart of -nb-cores: GPUs of this node (power of two)
         else if (a == "-gfa") o.gfa = true;
         else if (a == "-all-abundance-counts") o.all_ab = true;        // README.md:74-80
         else if (a == "-solid-kmers-out") o.solid_out = need("-solid-kmers-out");   // hidden in the reference (bcalm_1.cpp:37)
@@ -73,7 +76,7 @@ std::string base_name(const std::string& path) {          // strip directory and
 }
 
 // FASTA / FASTQ, plain or gzip (zlib reads both), one call to cdbg_push_text per chunk
-void read_sequences(const std::string& path, cdbg_ctx* ctx, uint64_t& n_seq, uint64_t& n_bases) {
+void read_sequences(const std::string& path, const std::vector<cdbg_ctx*>& ctxs, size_t& next_ctx, uint64_t& n_seq, uint64_t& n_bases) {
     gzFile f = gzopen(path.c_str(), "rb");
     if (!f) usage_error("cannot open input file " + path);
     gzbuffer(f, 1 << 20);
@@ -82,7 +85,9 @@ void read_sequences(const std::string& path, cdbg_ctx* ctx, uint64_t& n_seq, uin
     int fmt = 0, fq_line = 0;                   // fmt: 0 unknown, 1 FASTA, 2 FASTQ
     auto flush = [&]() {
         if (chunk.empty()) return;
-        if (cdbg_push_text(ctx, chunk.data(), chunk.size()) != 0) usage_error(cdbg_last_error());
+        // (several GPUs: the reads are sharded -- whole chunks of complete sequences go to the contexts in turn)
+        if (cdbg_push_text(ctxs[next_ctx], chunk.data(), chunk.size()) != 0) usage_error(cdbg_last_error());
+        next_ctx = (next_ctx + 1) % ctxs.size();
         chunk.clear();
     };
     bool partial = false;                       // previous gzgets returned an unterminated piece
@@ -100,7 +105,7 @@ void read_sequences(const std::string& path, cdbg_ctx* ctx, uint64_t& n_seq, uin
             if (starts_line && n && line[0] == '>') { if (!chunk.empty() && chunk.back() != '\n') chunk.push_back('\n'); ++n_seq; }
             else if (!(starts_line && n && line[0] == ';')) { chunk.append(line.data(), n); n_bases += n; }
         }
-        if (chunk.size() > (48u << 20) && (chunk.back() == '\n')) flush();
+        if (chunk.size() > (ctxs.size() > 1 ? (4u << 20) : (48u << 20)) && (chunk.back() == '\n')) flush();
     }
     gzclose(f);
     if (!chunk.empty() && chunk.back() != '\n') chunk.push_back('\n');
@@ -135,29 +140,54 @@ int main(int argc, char** argv) {
         const std::string prefix = o.out.empty() ? base_name(o.in) : o.out;
         auto t0 = std::chrono::steady_clock::now();
 
-        cdbg_params p{}; p.k = o.k; p.abundance_min = o.amin; p.minimizer_size = o.m; p.log2_partitions = o.log_np;
-        p.device_id = o.device; p.world_size = 1; p.rank = 0; p.all_abundance_counts = o.all_ab ? 1 : 0;
-        cdbg_ctx* ctx = nullptr;
-        check(cdbg_create(&p, &ctx));
-        uint64_t n_seq = 0, n_bases = 0;
+        if (o.n_gpus < 1 || (o.n_gpus & (o.n_gpus - 1))) usage_error("-nb-gpus must be a power of two");
+        const int world = o.n_gpus;
+        // one context per GPU; with several GPUs the reads are sharded over them and the contexts talk over RCCL inside
+        // libcdbg (include/cdbg.h "Multi-GPU"); rank 0 emits the complete unitig set (emit_replicated) and writes the file
+        std::vector<cdbg_ctx*> ctxs(world, nullptr);
+        for (int r = 0; r < world; ++r) {
+            cdbg_params p{}; p.k = o.k; p.abundance_min = o.amin; p.minimizer_size = o.m; p.log2_partitions = o.log_np;
+            p.device_id = world > 1 ? r : o.device; p.world_size = world; p.rank = r; p.all_abundance_counts = o.all_ab ? 1 : 0;
+            p.emit_replicated = 1;
+            check(cdbg_create(&p, &ctxs[r]));
+        }
+        cdbg_ctx* ctx = ctxs[0];
+        if (world > 1) {
+            unsigned char uid[128]; check(cdbg_comm_unique_id(uid));
+            std::vector<std::thread> th; std::atomic<int> bad{0}; std::vector<std::string> errs(world);
+            for (int r = 0; r < world; ++r) th.emplace_back([&, r]() { if (cdbg_comm_init_rccl(ctxs[r], uid) != 0) { errs[r] = cdbg_last_error(); ++bad; } });
+            for (auto& t : th) t.join();
+            if (bad) for (auto& e : errs) if (!e.empty()) usage_error(e);
+        }
+        uint64_t n_seq = 0, n_bases = 0; size_t next_ctx = 0;
         if (looks_like_file_list(o.in)) {
             gzFile f = gzopen(o.in.c_str(), "rb"); char buf[4096];
-            while (gzgets(f, buf, sizeof buf)) { size_t n = strlen(buf); while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) buf[--n] = 0; if (n) read_sequences(buf, ctx, n_seq, n_bases); }
+            while (gzgets(f, buf, sizeof buf)) { size_t n = strlen(buf); while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) buf[--n] = 0; if (n) read_sequences(buf, ctxs, next_ctx, n_seq, n_bases); }
             gzclose(f);
-        } else read_sequences(o.in, ctx, n_seq, n_bases);
+        } else read_sequences(o.in, ctxs, next_ctx, n_seq, n_bases);
         auto t1 = std::chrono::steady_clock::now();
-        check(cdbg_count(ctx));
+        // the stages are collective: one host thread per GPU
+        auto all_ranks = [&](int (*stage)(cdbg_ctx*)) {
+            if (world == 1) { check(stage(ctx)); return; }
+            std::vector<std::thread> th; std::atomic<int> bad{0}; std::vector<std::string> errs(world);
+            for (int r = 0; r < world; ++r) th.emplace_back([&, r]() { if (stage(ctxs[r]) != 0) { errs[r] = cdbg_last_error(); ++bad; } });
+            for (auto& t : th) t.join();
+            if (bad) for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
+        };
+        all_ranks(cdbg_count);
         if (!o.solid_out.empty()) {                          // solid k-mer dump: "<canonical k-mer> <abundance>" per line
-            uint64_t ns = 0, got = 0; check(cdbg_num_solid(ctx, &ns));
-            std::vector<char> km((ns + 1) * (size_t)(o.k + 1)); std::vector<uint32_t> cnt(ns + 1);
-            check(cdbg_fetch_solid(ctx, km.data(), cnt.data(), ns, &got));
             FILE* sf = fopen(o.solid_out.c_str(), "w");
             if (!sf) usage_error("cannot write " + o.solid_out);
-            for (uint64_t i = 0; i < got; ++i) fprintf(sf, "%s %u\n", km.data() + i * (size_t)(o.k + 1), cnt[i]);
+            for (int r = 0; r < world; ++r) {                // (every rank holds the solid k-mers of its partitions)
+                uint64_t ns = 0, got = 0; check(cdbg_num_solid(ctxs[r], &ns));
+                std::vector<char> km((ns + 1) * (size_t)(o.k + 1)); std::vector<uint32_t> cnt(ns + 1);
+                check(cdbg_fetch_solid(ctxs[r], km.data(), cnt.data(), ns, &got));
+                for (uint64_t i = 0; i < got; ++i) fprintf(sf, "%s %u\n", km.data() + i * (size_t)(o.k + 1), cnt[i]);
+            }
             fclose(sf);
         }
-        check(cdbg_compact(ctx));
-        check(cdbg_glue(ctx));
+        all_ranks(cdbg_compact);
+        all_ranks(cdbg_glue);
         cdbg_stats_t st; check(cdbg_stats(ctx, &st));
         uint64_t nu = 0, tb = 0; check(cdbg_num_unitigs(ctx, &nu, &tb));
         std::vector<char> seq(tb + 1); std::vector<uint64_t> off(nu + 1), kc(nu ? nu : 1);
@@ -206,7 +236,7 @@ int main(int argc, char** argv) {
         printf("GPU: scan %.2f+%.2f ms, count %.2f ms, compact %.2f ms, glue %.2f ms; H2D+stages+D2H %.2f s; write %.2f s\n",
                st.ms_scan_hist, st.ms_scan_emit, st.ms_count, st.ms_compact, st.ms_glue, sec(t1, t2), sec(t2, t3));
         printf("unitigs written to %s\n", fa.c_str());
-        cdbg_destroy(ctx);
+        for (cdbg_ctx* x : ctxs) cdbg_destroy(x);
     } catch (const std::exception& e) {
         printf("EXCEPTION: %s\n", e.what());
         return EXIT_FAILURE;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- reads -> unitigs throughput on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--cfg 3|4|5]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one full pass of the hot path (count -> compact -> glue) over one resident
@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r01_h_pmc_hbm_traffic_per_kernel.csv")
+PMC_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_per_kernel.csv")
 
 
 def pmc_traffic(kernel_key):
@@ -61,9 +61,9 @@ def alg_bytes(k, st, n_reads, read_len):
     per_kernel = {
         "k_scan<hist>": A1,                    # reads every ASCII base once
         "k_scan<emit>": A1 + A2 / 2,           # reads bases again, writes the super-k-mer records
-        "k_count": A2 / 2 + A3 / 2,            # reads records, writes solid (k-mer, count)
-        "k_compact": A3 / 2 + A4 / 2,          # reads solid k-mers, writes pieces + glue records
-        "glue(k_glue_resolve+k_rank_*+k_emit)": A4 / 2 + A5,
+        "k_count_fast": A2 / 2 + A3 / 2,       # reads records, writes solid (k-mer, count)   (+ k_count for multi-pass partitions)
+        "k_compact_wave": A3 / 2 + A4 / 2,     # reads solid k-mers, writes pieces + glue records   (+ k_compact for big buckets)
+        "glue(k_glue_build+k_glue_resolve+k_rank_*+k_emit)": A4 / 2 + A5,
     }
     return per_kernel, A1 + A2 + A3 + A4 + A5
 
@@ -154,20 +154,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=int(os.environ.get("CDBG_BENCH_READS", 100_000_000)),
-                    help="reads per GPU (BASELINE config 3: 100M); smaller values are dev runs, not the metric")
-    ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--cfg", type=int, default=3, choices=[3, 4, 5],
+                    help="BASELINE config: 3 = 100 M x 150 bp, k = 31 (the metric's config, fits one GPU); 4 = k = 55 and 5 = k = 127 are 8-GPU "
+                         "configs: at N = 1 the bench runs the share of ONE of the eight GPUs (125 M x 150 bp / 6.25 M x 1 kbp)")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU; default: the config's (smaller values are dev runs, not the metric)")
+    ap.add_argument("--read-len", type=int, default=None)
+    ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--abundance-min", type=int, default=2)
-    ap.add_argument("--cfg", type=int, default=3)
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)   # child of cpu_baseline: one scalar run, prints 'distinct seconds'
     ap.add_argument("--mode", choices=["sharded", "independent"], default="sharded",
-                    help="N>1: sharded = ONE graph, minimizer partitions split over the ranks, glue records exchanged with an RCCL "
-                         "all-gather (strong scaling); independent = one read set per rank, no collective (weak scaling)")
+                    help="N>1: sharded = ONE graph over --reads reads: reads and minimizer partitions split over the ranks, records and glue "
+                         "data exchanged over RCCL inside libcdbg (strong scaling); independent = one read set per rank, no collective (weak scaling)")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded (collective) code path even with one rank (testing)")
     a = ap.parse_args()
+    CFG = {3: dict(k=31, read_len=150, reads=100_000_000, name="BASELINE config 3"),
+           4: dict(k=55, read_len=150, reads=125_000_000, name="BASELINE config 4, the share of one of its 8 GPUs (1 G reads / 8)"),
+           5: dict(k=127, read_len=1000, reads=6_250_000, name="BASELINE config 5, the share of one of its 8 GPUs (50 M reads / 8)")}[a.cfg]
+    a.k = a.k or CFG["k"]; a.read_len = a.read_len or CFG["read_len"]
+    a.reads = a.reads or int(os.environ.get("CDBG_BENCH_READS", CFG["reads"]))
     if a.cpu_worker:
         d, dt = _cpu_worker((a.k, a.abundance_min, a.read_len, a.cfg, a.cpu_sample_reads))
         print(d, dt)
@@ -200,21 +206,23 @@ def main():
     lib = bcalm_amd.load()                      # raises without the HIP extension: no fallback
     sharded = (world > 1 or a.force_dist) and a.mode == "sharded"
     if sharded:
-        # ONE graph over `--reads` reads: every rank holds the reads, owns the minimizer partitions
-        # p with p % world == rank, counts and compacts them, then the glue records (pieces + junction
-        # log) are all-gathered over RCCL/xGMI and every rank glues the union.
+        # ONE graph over `--reads` reads, entirely inside libcdbg (include/cdbg.h "Multi-GPU"): every rank holds a
+        # contiguous 1/N shard of the read set, scans it, all-to-all-v's the super-k-mer records to the partition owners
+        # (RCCL ncclSend/ncclRecv), counts + compacts its partitions, all-gathers pieces + junction log, joins sharded,
+        # ranks, and emits the unitigs whose first piece it owns.  torch.distributed only carries the ncclUniqueId.
         from bcalm_amd import dist as cdist
+        if a.force_dist and world == 1:
+            os.environ["CDBG_FORCE_MULTI"] = "1"
         g = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank, world_size=world, rank=rank)
-        g.generate_reads(a.reads, a.read_len, a.cfg)
-        W = 1 if a.k <= 31 else 2 if a.k <= 63 else 4
-        dev = torch.device("cuda", local_rank)
+        cdist.init_rccl(g, dist, device=torch.device("cuda", local_rank))
+        share = (a.reads + world - 1) // world
+        first = rank * share
+        g.generate_reads(max(0, min(share, a.reads - first)), a.read_len, a.cfg, first_read=first, total_reads=a.reads)
 
         def step():
-            g.count()
-            g.compact()
-            info = cdist.exchange_glue(g, dist, dev, W)
-            g.glue()
-            return info
+            g.run()
+            return {"transport": "RCCL inside libcdbg.so (all-to-all-v of records, all-gather of pieces + junction log, MAX all-reduce of partner ids)",
+                    "bytes_sent_plus_received_by_rank0": g.comm_bytes()}
     else:
         # N == 1, or --mode independent: every rank runs the full path on its own read set
         g = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank)
@@ -236,7 +244,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     st = None
-    acc = {x: 0.0 for x in ("ms_scan_hist", "ms_scan_emit", "ms_count", "ms_compact", "ms_glue", "ms_total")}
+    acc = {x: 0.0 for x in ("ms_scan_hist", "ms_scan_emit", "ms_count", "ms_compact", "ms_glue", "ms_total", "ms_exchange")}
     xinfo = None
     for i in range(a.steps):
         xinfo = step()
@@ -248,6 +256,28 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     n_distinct = st["n_distinct"]
+    # ---- the bench checks its own output (outside the timed region): size-independent invariants at full size ----
+    dig_last = g.digest()
+    checks = {}
+    if not sharded:
+        g.reset(); step()
+        checks["set_digest_equal_across_two_steps"] = g.digest()["set_digest"] == dig_last["set_digest"]
+    tot = {"n_occurrences": st["n_occurrences"], "n_solid": st["n_solid"], "n_unitigs": st["n_unitigs"], "unitig_bases": st["unitig_bases"],
+           "kc_sum": dig_last["kc_sum"], "solid_count_sum": dig_last["solid_count_sum"], "kmers_in_unitigs": dig_last["kmers_in_unitigs"],
+           "set_digest": dig_last["set_digest"]}
+    if sharded and dist is not None:
+        # every rank holds the unitigs it owns: sums (and the additive set digest) over the ranks describe the whole graph
+        keys = sorted(tot)
+        v = torch.tensor([(tot[x] + (1 << 63)) % (1 << 64) - (1 << 63) for x in keys], device="cuda", dtype=torch.int64)   # two's complement: wraps like uint64
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        tot = {x: int(v[i].item()) % (1 << 64) for i, x in enumerate(keys)}
+    exp_occ = a.reads * (a.read_len - a.k + 1)                   # synthetic reads carry no N: every position is a k-mer
+    if sharded or world == 1:
+        checks["n_occurrences == R*(L-k+1)"] = tot["n_occurrences"] == exp_occ
+    checks["sum(LN-k+1) == n_solid"] = tot["kmers_in_unitigs"] == tot["n_solid"]
+    checks["sum(KC) == sum(solid counts)"] = tot["kc_sum"] == tot["solid_count_sum"]
+    checks["unitig_bases == n_solid + U*(k-1)"] = tot["unitig_bases"] == tot["kmers_in_unitigs"] + tot["n_unitigs"] * (a.k - 1)
+    dig_last = dict(dig_last, set_digest=tot["set_digest"], kc_sum=tot["kc_sum"], kmers_in_unitigs=tot["kmers_in_unitigs"])
 
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -261,8 +291,8 @@ def main():
 
     if rank == 0:
         per_kernel, alg_total = alg_bytes(a.k, st, a.reads, a.read_len)
-        ms = {"k_scan<hist>": acc["ms_scan_hist"], "k_scan<emit>": acc["ms_scan_emit"], "k_count": acc["ms_count"],
-              "k_compact": acc["ms_compact"], "glue(k_glue_resolve+k_rank_*+k_emit)": acc["ms_glue"]}
+        ms = {"k_scan<hist>": acc["ms_scan_hist"], "k_scan<emit>": acc["ms_scan_emit"], "k_count_fast": acc["ms_count"],
+              "k_compact_wave": acc["ms_compact"], "glue(k_glue_build+k_glue_resolve+k_rank_*+k_emit)": acc["ms_glue"]}
         dom = max(ms, key=lambda x: ms[x])
         dom_ms = ms[dom] / a.steps
         achieved = per_kernel[dom] / (dom_ms * 1e-3) / 1e9
@@ -275,21 +305,23 @@ def main():
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: synthetic %d x %d bp reads %s, k=%d, abundance-min %d, 1%% substitutions, 30x coverage"
-                                   % (a.reads, a.read_len, "in total (one graph)" if sharded else "per GPU", a.k, a.abundance_min),
+            "config": {"workload": "%s: synthetic %d x %d bp reads %s, k=%d, abundance-min %d, 1%% substitutions, 30x coverage"
+                                   % (CFG["name"], a.reads, a.read_len, "in total (one graph)" if sharded else "per GPU", a.k, a.abundance_min),
                        "timing_boundary": "reads resident in HBM (ASCII) -> unitigs + KC resident in HBM; includes the stages' host syncs",
                        "multi_gpu": ("single GPU" if world == 1 else
-                                     "sharded: minimizer partitions split over ranks, replicated scan, RCCL all-gather of glue records, glue on the union"
+                                     "sharded: reads split over the ranks, RCCL all-to-all-v of super-k-mer records to the partition owners, all-gather of pieces + junction log, sharded junction join, owner-sharded emission (one graph; set_digest comparable with the N=1 line)"
                                      if sharded else "independent read sets per rank (no collective)"),
                        "exchange": xinfo,
                        "minimizer_size": st["minimizer_size"], "log2_partitions": st["log2_partitions"]},
-            "counts": {x: st[x] for x in ("n_occurrences", "n_distinct", "n_solid", "n_pieces", "n_unitigs", "n_records", "n_big_partitions")},
+            "counts": {x: st[x] for x in ("n_occurrences", "n_distinct", "n_solid", "n_pieces", "n_unitigs", "n_records", "n_big_partitions", "n_multipass_partitions")},
+            "checks": checks, "checks_passed": all(checks.values()),
+            "digest": {"set_digest": "%016x" % dig_last["set_digest"], "kc_sum": dig_last["kc_sum"], "kmers_in_unitigs": dig_last["kmers_in_unitigs"]},
             "stage_ms": {x: acc[x] / a.steps for x in acc},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic({"k_count": "k_count<", "k_compact": "k_compact<", "k_scan<emit>": "k_scan_fast<1, 2",
-                                                 "k_scan<hist>": "k_scan_fast<1, 0"}.get(dom, "k_glue_build")),
-                         "traffic_source": "profiles/r01_h_pmc_hbm_traffic_per_kernel.csv (separate rocprofv3 --pmc passes)",
+                         "traffic": pmc_traffic({"k_count_fast": "k_count_fast<", "k_compact_wave": "k_compact_wave<", "k_scan<emit>": "k_scan_fast<1, 2",
+                                                 "k_scan<hist>": "k_scan_fast<1, 0"}.get(dom, "k_glue_build")) if a.cfg == 3 else None,
+                         "traffic_source": "profiles/r02_pmc_hbm_traffic_per_kernel.csv (separate rocprofv3 --pmc passes of this bench at config 3)",
                          "alg_bytes_per_launch": per_kernel[dom], "avg_launch_ms": dom_ms,
                          "pipeline": {"alg_bytes": alg_total, "gpu_ms": gpu_ms,
                                       "achieved": alg_total / (gpu_ms * 1e-3) / 1e9,
@@ -298,6 +330,10 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.k, a.abundance_min, a.read_len, a.cfg, a.cpu_sample_reads)
         json_out.write(json.dumps(out) + "\n"); json_out.flush()
+        if not out["checks_passed"]:
+            sys.stderr.write("bench.py: OUTPUT CHECK FAILED: %r\n" % checks)
+            g.close()
+            sys.exit(3)
     g.close()
     if dist is not None:
         dist.barrier()

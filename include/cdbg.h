@@ -38,6 +38,8 @@ typedef struct cdbg_params {
     int world_size;           /* GPUs sharing the minimizer space (power of two); 1 = single GPU */
     int rank;                 /* this context owns partitions p with p % world_size == rank */
     int all_abundance_counts; /* -all-abundance-counts (README.md:74-80): keep the abundance of every k-mer of every unitig */
+    int emit_replicated;      /* world_size > 1: 0 = every rank emits the unitigs whose first piece it owns (the union over the
+                                 ranks is the graph); 1 = every rank emits the complete set (the CLI's rank 0 writes one file) */
 } cdbg_params;
 
 typedef struct cdbg_stats_t {
@@ -57,6 +59,7 @@ typedef struct cdbg_stats_t {
     uint64_t n_cycles;            /* circular unitigs cut open (in-bucket + across buckets) */
     int minimizer_size, log2_partitions, kmer_words;
     float ms_scan_hist, ms_scan_emit, ms_count, ms_compact, ms_glue, ms_total;
+    float ms_exchange;            /* multi-GPU: time inside the record and glue exchanges (transport + merge kernels) */
     uint64_t n_launch_scan, n_launch_count, n_launch_compact;   /* workgroups launched */
     uint64_t n_multipass_partitions; /* partitions whose distinct k-mers did not fit one LDS pass (multi-pass kernel) */
 } cdbg_stats_t;
@@ -95,7 +98,42 @@ int cdbg_run(cdbg_ctx* ctx);
  * be run again (benchmark steps) without allocator traffic */
 int cdbg_reset(cdbg_ctx* ctx);
 
-/* Multi-GPU (one process per GPU, minimizer partitions sharded by cdbg_params.world_size/rank; every
+/* ---- Multi-GPU: one context per GPU (one process per GPU, or one host thread per GPU in one process) ----
+ * The reference has nothing here (GraphUnitigsTemplate<span>::create is one shared-memory call, src/bcalm_1.cpp:57);
+ * the design is SURVEY.md section 8(e) X1.  Every rank holds a SHARD of the reads.  cdbg_run / cdbg_count /
+ * cdbg_compact / cdbg_glue of a context with world_size > 1 perform, through the context's transport:
+ *   count   scan the own reads into super-k-mer records of ALL minimizer partitions, all-to-all-v the records to the
+ *           partition owners (partition p belongs to rank p % world_size), count the own partitions
+ *   compact the own buckets (no exchange: the owner of a junction holds every solid k-mer adjacent to it)
+ *   glue    all-gather the pieces (lengths, abundance sums, bases 2 bit packed) and the junction log; hash-join of the
+ *           junctions sharded by key hash, partner ids combined with one MAX all-reduce; chains ranked on every rank;
+ *           every rank emits the unitigs whose first piece it owns (emit_replicated = 0)
+ * The transport moves bytes between DEVICE buffers of the ranks.  Built in: RCCL (ncclSend/ncclRecv all-to-all-v,
+ * ncclAllGather, ncclAllReduce over xGMI), bound at run time from librccl.so.1:
+ *   cdbg_comm_unique_id   rank 0 creates the 128-byte id; the caller distributes it (MPI, torch.distributed, a file)
+ *   cdbg_comm_init_rccl   every rank, after cdbg_create on its device
+ * or caller-supplied functions (cdbg_set_transport; the CPU tests use gloo and an in-process loop-back).
+ * All four functions are collective: every rank calls them in the same order; they return 0 on success.
+ *   all_gather_u64  host buffers: n words from every rank, rank order
+ *   all_to_all_v    device buffers: send_cnt[r] bytes at send_off[r] go to rank r; recv_cnt[s] bytes from rank s land at recv_off[s]
+ *   all_gather_v    device buffers: nbytes of every rank (recv_cnt[s], known from an all_gather_u64) at recv_off[s]
+ *   all_reduce_max_i32  in place on a device buffer of n int32 */
+typedef struct cdbg_transport {
+    void* user;
+    int (*all_gather_u64)(void* user, const uint64_t* send, uint64_t* recv, int n);
+    int (*all_to_all_v)(void* user, const void* send_dev, const uint64_t* send_off, const uint64_t* send_cnt,
+                        void* recv_dev, const uint64_t* recv_off, const uint64_t* recv_cnt);
+    int (*all_gather_v)(void* user, const void* send_dev, uint64_t nbytes, void* recv_dev, const uint64_t* recv_off, const uint64_t* recv_cnt);
+    int (*all_reduce_max_i32)(void* user, void* dev, uint64_t n);
+} cdbg_transport;
+int cdbg_set_transport(cdbg_ctx* ctx, const cdbg_transport* t);
+int cdbg_comm_unique_id(void* out_128_bytes);
+int cdbg_comm_init_rccl(cdbg_ctx* ctx, const void* unique_id_128_bytes);
+/* bytes this rank sent + received through the transport since cdbg_reset (bench.py reports them) */
+int cdbg_comm_bytes(cdbg_ctx* ctx, uint64_t* out);
+
+/* Lower-level pieces of the glue exchange, kept for callers that move the bytes themselves and for tests: */
+/* (one process per GPU, minimizer partitions sharded by cdbg_params.world_size/rank; every
  * rank scans the same reads and counts / compacts only its own partitions).  After cdbg_compact the
  * pieces and glue records of all ranks are gathered -- the caller moves the bytes with an RCCL
  * all-gather (torch.distributed); this library only copies device-to-device -- and merged in rank order:
@@ -145,6 +183,11 @@ int cdbg_fetch_unitigs(cdbg_ctx* ctx, uint64_t first, uint64_t n, char* seq_buf,
  * (the `ab:Z:` vector of /root/reference/README.md:74-80) */
 int cdbg_fetch_unitig_abundances(cdbg_ctx* ctx, uint64_t first, uint64_t n, uint32_t* ab, uint64_t* ab_off);
 int cdbg_stats(cdbg_ctx* ctx, cdbg_stats_t* out);
+/* Digests of the resident result, computed on the device (bench.py checks them at sizes no oracle follows):
+ * out[0] = sum of KC over the unitigs, out[1] = sum of the solid k-mers' counts (must equal out[0]),
+ * out[2] = order- and orientation-independent digest of the set {(unitig, KC)} (formula: k_links.h k_digest_unitigs;
+ * pinned against the oracle's unitigs in tests/), out[3] = sum of (LN - k + 1) (must equal n_solid). */
+int cdbg_digest(cdbg_ctx* ctx, uint64_t out[4]);
 
 /* Edges between unitigs (the `L:<+/->:<id>:<+/->` tokens of /root/reference/README.md:62-72; GFA `L`
  * lines of scripts/convertToGFA.py:103-112).  After cdbg_glue: cdbg_link builds them on the GPU.

@@ -52,3 +52,28 @@ def config2_genome(oracle):
         pos = 500_000 + 60_000 * i
         g0[pos:pos + 1300] = seg
     return bytes(g0) + b"\n"
+
+
+M64 = (1 << 64) - 1
+
+
+def _mix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M64
+    return x ^ (x >> 31)
+
+
+def set_digest(unitigs):
+    """the formula of cdbg_digest (bcalm_amd/csrc/k_links.h k_digest_unitigs) over [(sequence, KC)]"""
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    B = 0x100000001B3
+    tot = 0
+    for s, kc in unitigs:
+        hf = hr = 0
+        n = len(s)
+        for i in range(n):
+            hf = (hf * B + code[s[i]] + 1) & M64
+            hr = (hr * B + (3 - code[s[n - 1 - i]]) + 1) & M64
+        tot = (tot + _mix64(((hf + hr) & M64) ^ _mix64(((hf * hr) + kc) & M64))) & M64
+    return tot

@@ -1,7 +1,8 @@
-"""world_size-2 CPU test (gloo) of the multi-process path bench.py uses for N > 1:
-each rank runs the full path on its own read set, then MAX-reduces the time and
-SUM-reduces the distinct k-mer count; plus the minimizer-sharded counting mode
-(world_size/rank in cdbg_params) checked for an exact 2-way split of the k-mer set."""
+"""Multi-process CPU tests (gloo, world 2 / 4 / 8) of the multi-GPU data path of libcdbg: reads SHARDED over the
+ranks, super-k-mer records all-to-all-v'd to the partition owners, pieces + junction log all-gathered, junction
+join sharded by key hash + MAX all-reduce, owner-sharded emission.  The library is the kernel-logic simulator
+(same source as the HIP build); the transport is bcalm_amd.dist.TorchTransport over gloo on host memory.  Also
+bench.py's weak-scaling reductions (MAX of the time, SUM of the distinct k-mers)."""
 import os
 import sys
 
@@ -15,85 +16,32 @@ import oracle_lib
 ROOT = oracle_lib.ROOT
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import hostsim_lib
-    from bcalm_amd import api
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    lib = hostsim_lib.load()
-    orc = oracle_lib.load()
-    # (a) bench.py's N>1 mode: disjoint read sets, no data-path collective
-    text = orc.synth_reads(120, 150, 3 + 16 * rank)
-    g = api.Graph(31, 2, lib=lib)
-    g.push_text(text); g.run()
-    st = g.stats(); canon = oracle_lib.canonical_set(orc, g.unitigs(), 31); g.close()
-    exp = orc.run(text, 31, 2)
-    ok = canon == exp["unitigs"]
-    t = torch.tensor([0.5 + rank], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    n = torch.tensor([st["n_distinct"]], dtype=torch.int64); dist.all_reduce(n, op=dist.ReduceOp.SUM)
-    # (b) minimizer-sharded counting of ONE read set: the two ranks' solid sets partition the oracle's
-    shared = orc.synth_reads(150, 150, 3)
-    g = api.Graph(31, 2, lib=lib, log2_partitions=5, world_size=world, rank=rank)
-    g.push_text(shared); g.count()
-    mine = g.solid_kmers(); g.close()
-    gathered = [None] * world
-    dist.all_gather_object(gathered, mine)
-    full = sorted(x for part in gathered for x in part)
-    exp2 = orc.run(shared, 31, 2, want_solid=True)
-    # (c) single-graph mode: sharded count + compact, all-gather of glue records, glue on the union
-    from bcalm_amd import dist as cdist
-    g = api.Graph(31, 2, lib=lib, log2_partitions=6, world_size=world, rank=rank)
-    g.push_text(shared); g.count(); g.compact()
-    info = cdist.exchange_glue(g, dist, torch.device("cpu"), 1)
-    g.glue()
-    canon2 = oracle_lib.canonical_set(orc, g.unitigs(), 31); g.close()
-    ok_graph = canon2 == exp2["unitigs"] and info["glue_records"] > 0 and info["link_bytes_reduced"] > 0
-    # (d) the same with the junction join NOT sharded (every rank joins all glue records inside cdbg_glue), and
-    #     a larger graph through the sharded join with repeated steps (reset keeps every buffer)
-    g = api.Graph(31, 2, lib=lib, log2_partitions=6, world_size=world, rank=rank)
-    g.push_text(shared); g.count(); g.compact()
-    cdist.exchange_glue(g, dist, torch.device("cpu"), 1, sharded_join=False)
-    g.glue()
-    ok_graph = ok_graph and oracle_lib.canonical_set(orc, g.unitigs(), 31) == exp2["unitigs"]
-    for _ in range(2):
-        g.reset(); g.count(); g.compact()
-        cdist.exchange_glue(g, dist, torch.device("cpu"), 1)
-        g.glue()
-        ok_graph = ok_graph and oracle_lib.canonical_set(orc, g.unitigs(), 31) == exp2["unitigs"]
+def _shard(text, world, rank):
+    """reads r with r % world == rank, as text"""
+    reads = [x for x in text.decode().split("\n") if x]
+    return ("\n".join(reads[rank::world]) + "\n").encode()
+
+
+def _run_sharded(api, cdist, lib, orc, text, k, amin, world, rank, steps=1, **kw):
+    g = api.Graph(k, amin, lib=lib, world_size=world, rank=rank, **kw)
+    cdist.TorchTransport(dist).attach(g)
+    g.push_text(_shard(text, world, rank))
+    out = None
+    for i in range(steps):
+        if i:
+            g.reset()
+        g.run()
+        mine = g.unitigs(); st = g.stats(); nbytes = g.comm_bytes()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (mine, st["n_distinct"], st["n_solid"], st["n_occurrences"]))
+        out = {"union": sorted((orc.canonical_unitig(s, k), int(kc)) for part in gathered for s, kc in part[0]),
+               "mine": mine, "distinct": sum(p[1] for p in gathered), "solid": sum(p[2] for p in gathered),
+               "occ": sum(p[3] for p in gathered), "comm_bytes": nbytes, "per_rank": [len(p[0]) for p in gathered]}
     g.close()
-    big = orc.synth_reads(600, 150, 4)
-    exp3 = orc.run(big, 21, 1)
-    g = api.Graph(21, 1, lib=lib, log2_partitions=8, world_size=world, rank=rank)
-    g.push_text(big); g.count(); g.compact()
-    cdist.exchange_glue(g, dist, torch.device("cpu"), 1)
-    g.glue()
-    ok_graph = ok_graph and oracle_lib.canonical_set(orc, g.unitigs(), 21) == exp3["unitigs"]
-    g.close()
-    q.put((rank, ok, float(t.item()), int(n.item()), st["n_distinct"], full == exp2["solid"], len(mine), ok_graph))
-    dist.destroy_process_group()
+    return out
 
 
-def test_two_rank_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=300) for _ in procs)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    assert all(r[1] for r in res), "per-rank parity failed"
-    assert res[0][2] == res[1][2] == 1.5                      # MAX over ranks
-    assert res[0][3] == res[1][3] == res[0][4] + res[1][4]    # SUM of distinct k-mers
-    assert all(r[5] for r in res), "sharded k-mer sets do not partition the oracle's set"
-    assert res[0][6] > 0 and res[1][6] > 0
-    assert all(r[7] for r in res), "sharded single-graph mode (all-gather + merge + glue) differs from the oracle"
-
-
-def _worker_graph(rank, world, port, q):
+def _worker(rank, world, port, q, cases):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import hostsim_lib
@@ -101,46 +49,68 @@ def _worker_graph(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = hostsim_lib.load()
     orc = oracle_lib.load()
-    ok = True
-    for k, amin, n_reads, cfg in ((31, 2, 200, 3), (55, 1, 120, 4)):
-        text = orc.synth_reads(n_reads, 150, cfg)
+    ok = []
+    for case in cases:
+        k, amin, n_reads, read_len, cfg, kw = case
+        text = orc.synth_reads(n_reads, read_len, cfg)
         exp = orc.run(text, k, amin)
-        g = api.Graph(k, amin, lib=lib, log2_partitions=7, world_size=world, rank=rank)
-        g.push_text(text); g.count(); g.compact()
-        cdist.exchange_glue(g, dist, torch.device("cpu"), 1 if k <= 31 else 2)
-        g.glue()
-        ok = ok and oracle_lib.canonical_set(orc, g.unitigs(), k) == exp["unitigs"]
-        g.close()
+        got = _run_sharded(api, cdist, lib, orc, text, k, amin, world, rank, steps=kw.pop("steps", 1), **kw)
+        if kw.get("emit_replicated"):
+            # every rank holds the complete set
+            ok.append(oracle_lib.canonical_set(orc, got["mine"], k) == exp["unitigs"])
+        else:
+            # the union over the ranks is the graph: every unitig emitted by exactly one rank
+            ok.append(got["union"] == exp["unitigs"])
+        ok.append(got["distinct"] == exp["stats"]["distinct"] and got["solid"] == exp["stats"]["solid"] and got["occ"] == exp["stats"]["occurrences"])
+        ok.append(got["comm_bytes"] > 0)
+    # bench.py's reductions for N > 1
+    t = torch.tensor([0.5 + rank], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok.append(float(t.item()) == 0.5 + world - 1)
     q.put((rank, ok))
     dist.destroy_process_group()
 
 
-def test_eight_rank_sharded_join_gloo():
-    """the world size of the full node: 8 ranks, partitions split eight ways (3 rank bits), eight-way sharded join"""
+def _launch(world, cases, port_base, timeout):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker_graph, args=(r, 8, port, q)) for r in range(8)]
+    port = port_base + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, cases)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=600) for _ in procs)
+    res = sorted(q.get(timeout=timeout) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert len(res) == 8 and all(r[1] for r in res), res
+    assert len(res) == world
+    for rank, ok in res:
+        assert all(ok), (rank, ok)
 
 
-def test_four_rank_sharded_join_gloo():
-    """4 ranks: partitions split four ways, glue records all-gathered, junction join sharded by key hash and
-    combined with the MAX all-reduce; one- and two-word k-mers"""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker_graph, args=(r, 4, port, q)) for r in range(4)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=400) for _ in procs)
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    assert all(r[1] for r in res), res
+def test_two_rank_gloo():
+    """world 2: one-, two- and four-word k-mers, automatic and forced partition counts, repeated steps (reset keeps the
+    buffers), emit_replicated (every rank ends with the whole graph: what the multi-GPU CLI's rank 0 writes)"""
+    _launch(2, [(31, 2, 300, 150, 3, {"steps": 2}), (31, 1, 150, 150, 3, {"log2_partitions": 6}),
+                (55, 2, 200, 150, 4, {"log2_partitions": 5}), (127, 1, 40, 600, 5, {"log2_partitions": 4}),
+                (31, 2, 200, 150, 3, {"emit_replicated": True})], 29500, 600)
+
+
+def test_four_rank_gloo():
+    _launch(4, [(31, 2, 400, 150, 3, {}), (55, 1, 160, 150, 4, {"log2_partitions": 7}), (127, 2, 80, 500, 5, {"log2_partitions": 5})], 31500, 600)
+
+
+def test_eight_rank_gloo():
+    """the world size of the full node: partitions split eight ways (3 rank bits), eight-way sharded join"""
+    _launch(8, [(31, 2, 400, 150, 3, {"log2_partitions": 7}), (55, 1, 160, 150, 4, {"log2_partitions": 7})], 33500, 900)
+
+
+def test_multi_rank_needs_a_transport():
+    """a context with world_size > 1 and no transport refuses to count (no silent single-rank result)"""
+    import hostsim_lib
+    from bcalm_amd import api
+    lib = hostsim_lib.load()
+    g = api.Graph(31, 2, lib=lib, world_size=2, rank=0)
+    g.push_text(b"ACGTACGTTGCATGCATGCATTTGACCAGTACCAGGGATTTACCA\n")
+    with pytest.raises(api.CdbgError) as e:
+        g.count()
+    assert "transport" in str(e.value)
+    g.close()

@@ -165,3 +165,18 @@ def test_real_cli_binary_on_gpu(oracle, tmp_path):
     assert r.returncode == 1 and "EXCEPTION: Specifiy -in" in r.stdout
     r = subprocess.run([BCALM, "-in", "/nonexistent.fa"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "EXCEPTION:" in r.stdout
+
+
+def test_result_digest_on_gpu(oracle, oracle_1m, hip):
+    """the digests bench.py asserts at config-3 size, against the same formula on the oracle's unitigs (1 M reads)"""
+    import bcalm_amd
+    from parity import set_digest
+    text, exp = oracle_1m
+    g = bcalm_amd.Graph(31, 2, lib=hip)
+    g.push_text(text); g.run()
+    d = g.digest(); st = g.stats()
+    g.reset(); g.run()
+    d2 = g.digest(); g.close()
+    assert d["set_digest"] == set_digest(exp["unitigs"]) == d2["set_digest"]
+    assert d["kc_sum"] == d["solid_count_sum"] == sum(kc for _, kc in exp["unitigs"])
+    assert d["kmers_in_unitigs"] == st["n_solid"] == exp["stats"]["solid"]

@@ -121,37 +121,79 @@ def test_no_device_fallback_symbols(hip):
         assert hasattr(hip, sym)
 
 
-def test_exchange_path_single_rank_nccl(oracle, hip):
-    """the multi-GPU glue exchange (RCCL all-gather + merge + glue on the union) with a 1-rank
-    'nccl' group: exercises the device-tensor / D2D / merge-kernel path that N>1 uses"""
-    import torch
+def test_multi_gpu_path_single_rank_rccl(oracle, hip, monkeypatch):
+    """the multi-GPU code path of the library with a ONE-rank RCCL communicator (CDBG_FORCE_MULTI): librccl bound at run
+    time, ncclCommInitRank, the all-gathers / all-reduce through RCCL, record exchange + merge kernels, glue exchange,
+    sharded join, owner-filtered emission; result against the oracle, repeated steps"""
     import torch.distributed as dist
     import bcalm_amd
     from bcalm_amd import dist as cdist
+    monkeypatch.setenv("CDBG_FORCE_MULTI", "1")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", RANK="0", WORLD_SIZE="1")
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    dist.init_process_group("gloo", rank=0, world_size=1)          # (carries the ncclUniqueId only)
     try:
-        text = oracle.synth_reads(30000, 150, 3)
-        exp = oracle.run(text, 31, 2)
-        g = bcalm_amd.Graph(31, 2, lib=hip, world_size=1, rank=0)
-        g.push_text(text); g.count(); g.compact()
-        info = cdist.exchange_glue(g, dist, torch.device("cuda", 0), 1)
-        # the sharded-join leg (dist.py runs it for world > 1): join, int32 link array through an RCCL MAX all-reduce
-        n = g.glue_join()
-        links = torch.empty(n, dtype=torch.int32, device="cuda:0")
-        g.glue_links_export(links.data_ptr(), n * 4)
-        dist.all_reduce(links, op=dist.ReduceOp.MAX)
-        torch.cuda.synchronize()
-        assert int((links >= 0).sum().item()) > 0 and int(links.max().item()) < n
-        g.glue_links_import(links.data_ptr(), n * 4)
-        g.glue()
-        canon = oracle_lib.canonical_set(oracle, g.unitigs(), 31)
-        g.close()
-        assert info["glue_records"] > 0
-        assert canon == exp["unitigs"]
+        for k, n, L, cfg in ((31, 30000, 150, 3), (55, 10000, 150, 4)):
+            text = oracle.synth_reads(n, L, cfg)
+            exp = oracle.run(text, k, 2)
+            g = bcalm_amd.Graph(k, 2, lib=hip, world_size=1, rank=0)
+            cdist.init_rccl(g, dist)
+            g.push_text(text)
+            for step in range(2):
+                if step:
+                    g.reset()
+                g.run()
+                st = g.stats()
+                assert oracle_lib.canonical_set(oracle, g.unitigs(), k) == exp["unitigs"]
+                assert st["n_distinct"] == exp["stats"]["distinct"] and st["ms_exchange"] > 0
+            g.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k,amin,n_reads,read_len,cfg,kw", [
+    (2, 31, 2, 300000, 150, 3, {}), (4, 31, 1, 60000, 150, 3, {"log2_partitions": 12}),
+    (2, 55, 2, 100000, 150, 4, {}), (2, 127, 2, 8000, 1000, 5, {}), (2, 31, 2, 100000, 150, 3, {"emit_replicated": True})])
+def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, read_len, cfg, kw):
+    """the complete N-rank data path on the real device: N contexts on GPU 0 driven by N host threads, reads sharded,
+    records / pieces / junction log / partner ids moved by an in-process loop-back transport (tests/loopback.py: RCCL
+    refuses two ranks on one GPU).  The union of the ranks' unitigs must be the oracle's set, each unitig exactly once."""
+    import threading
+    import bcalm_amd
+    from loopback import hip_loopback
+    text = oracle.synth_reads(n_reads, read_len, cfg)
+    exp = oracle.run(text, k, amin)
+    reads = [x for x in text.decode().split("\n") if x]
+    hub = hip_loopback(world)
+    out = [None] * world
+    def rank_main(r):
+        try:
+            g = bcalm_amd.Graph(k, amin, lib=hip, world_size=world, rank=r, **kw)
+            ep = hub.endpoint(r); ep.attach(g)
+            g.push_text(("\n".join(reads[r::world]) + "\n").encode())
+            g.run()
+            out[r] = (g.unitigs(), g.stats(), g.comm_bytes(), ep.error)
+            g.close()
+        except Exception as e:                   # noqa: BLE001
+            out[r] = e
+            hub.barrier.abort()
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(600)
+    for r in range(world):
+        assert not isinstance(out[r], Exception), out[r]
+        assert out[r] is not None and out[r][3] is None, out[r]
+    if kw.get("emit_replicated"):
+        for r in range(world):
+            assert oracle_lib.canonical_set(oracle, out[r][0], k) == exp["unitigs"]
+    else:
+        union = sorted((oracle.canonical_unitig(s, k), int(kc)) for r in range(world) for s, kc in out[r][0])
+        assert union == exp["unitigs"]
+        assert all(len(out[r][0]) > 0 for r in range(world))
+    assert sum(out[r][1]["n_distinct"] for r in range(world)) == exp["stats"]["distinct"]
+    assert sum(out[r][1]["n_solid"] for r in range(world)) == exp["stats"]["solid"]
+    assert all(out[r][2] > 0 for r in range(world))
 
 
 @pytest.mark.parametrize("part_cap", [None, "64"])
@@ -237,89 +279,6 @@ def test_parity_one_million_reads(oracle, oracle_1m, hip):
     st = g.stats(); g.close()
     assert st["n_distinct"] == exp["stats"]["distinct"] and st["n_solid"] == exp["stats"]["solid"]
     assert got == exp["unitigs"]
-
-
-def test_two_rank_flow_on_one_device(oracle, hip):
-    """the complete N = 2 data path on the real device, ranks emulated one after the other on GPU 0 (RCCL refuses two
-    ranks on one GPU): partitions split two ways, glue records exchanged through cdbg_exchange_* with device buffers,
-    junction join sharded by key hash, link arrays combined with an element-wise MAX, rank + emit on both; the two
-    ranks must end with the same unitig set as the single-rank run and the oracle"""
-    import torch
-    import bcalm_amd
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0); torch.zeros(1, device=dev)     # torch's HIP runtime initialises before libcdbg's first call here
-    text = oracle.synth_reads(300000, 150, 3)
-    exp = oracle.run(text, 31, 2)
-    world = 2
-    gs = []
-    for r in range(world):
-        g = bcalm_amd.Graph(31, 2, lib=hip, world_size=world, rank=r)
-        g.push_text(text); g.count(); g.compact()
-        gs.append(g)
-    sizes = [g.exchange_sizes() for g in gs]
-    kinds = [(0, 4, 0), (1, 8, 0), (2, 8, 0), (3, 1, 1), (4, 8, 2), (5, 4, 2)]        # (export kind, bytes per item, which size)
-    bufs = []                                                                          # bufs[r][kind] = device tensor
-    for r, g in enumerate(gs):
-        row = []
-        for kind, item, which in kinds:
-            nb = max(int(sizes[r][which]) * item, 16)
-            t = torch.empty(nb, dtype=torch.uint8, device=dev)
-            g.exchange_export(kind, t.data_ptr(), nb)
-            row.append(t)
-        bufs.append(row)
-    totals = [sum(int(sizes[r][j]) for r in range(world)) for j in range(3)]
-    links = []
-    for g in gs:
-        g.exchange_begin(*totals)
-        for r in range(world):
-            g.exchange_add(int(sizes[r][0]), int(sizes[r][1]), int(sizes[r][2]), [t.data_ptr() for t in bufs[r]])
-        g.exchange_end()
-        n = g.glue_join()
-        t = torch.empty(n, dtype=torch.int32, device=dev)
-        g.glue_links_export(t.data_ptr(), n * 4)
-        links.append(t)
-    assert links[0].numel() == links[1].numel() == 2 * totals[0]
-    both = (links[0] >= 0) & (links[1] >= 0)
-    assert int(both.sum().item()) == 0, "an end was joined by both ranks"
-    assert int((links[0] >= 0).sum().item()) > 0 and int((links[1] >= 0).sum().item()) > 0
-    merged = torch.maximum(links[0], links[1])
-    torch.cuda.synchronize()
-    sets = []
-    for g in gs:
-        g.glue_links_import(merged.data_ptr(), merged.numel() * 4)
-        g.glue()
-        sets.append(oracle_lib.canonical_set(oracle, g.unitigs(), 31))
-        g.close()
-    assert sets[0] == sets[1] == exp["unitigs"]
-    # the packed exchange (2-bit bases, no offsets on the wire: what bcalm_amd/dist.py ships) through the same emulation
-    gs = []
-    for r in range(world):
-        g = bcalm_amd.Graph(31, 2, lib=hip, world_size=world, rank=r)
-        g.push_text(text); g.count(); g.compact()
-        gs.append(g)
-    psizes = [g.exchange_sizes_packed() for g in gs]
-    assert all(ps[3] * 3 < ps[1] for ps in psizes)            # packed bytes ~ bases / 4 (+ padding)
-    pbufs = []
-    for r, g in enumerate(gs):
-        row = []
-        for kind, nb in ((0, psizes[r][0] * 4), (1, psizes[r][0] * 8), (None, psizes[r][3]), (4, psizes[r][2] * 8), (5, psizes[r][2] * 4)):
-            t = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
-            if kind is None:
-                g.exchange_export_packed(t.data_ptr(), t.numel())
-            else:
-                g.exchange_export(kind, t.data_ptr(), t.numel())
-            row.append(t)
-        pbufs.append(row)
-    ptot = [sum(psizes[r][j] for r in range(world)) for j in range(3)]
-    g = gs[0]
-    g.exchange_begin(*ptot)
-    for r in range(world):
-        g.exchange_add_packed(psizes[r][0], psizes[r][1], psizes[r][3], psizes[r][2], [t.data_ptr() for t in pbufs[r]])
-    g.exchange_end()
-    g.glue()                                                  # unsharded join on the union
-    assert oracle_lib.canonical_set(oracle, g.unitigs(), 31) == exp["unitigs"]
-    for g in gs:
-        g.close()
 
 
 def test_one_giant_partition_statistics(oracle, hip):
