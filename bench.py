@@ -120,6 +120,21 @@ def cpu_baseline(k, amin, read_len, cfg, sample_reads):
                     "sample": f"{sample_reads} x {read_len} bp synthetic reads through {ref} in {dt:.1f} s"}
         except Exception:
             pass                                             # fall through to the port
+    if k <= 31:
+        # the multithreaded shared-table restatement (oracle/cpu_mt.cpp: std::thread x all cores, ONE input, one lock-free
+        # table; SURVEY.md section 8 d ii), pinned against the oracle in tests/test_oracle.py
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        orc = oracle_lib.load()
+        cores = os.cpu_count() or 1
+        text = orc.synth_reads(sample_reads, read_len, cfg)
+        r = oracle_lib.cpu_mt_run(text, k, amin, cores)
+        return {"value": r["distinct"] / r["s_total"], "unit": "kmers/s", "cores": cores, "kind": "port",
+                "seconds": {"count": r["s_count"], "solid_table": r["s_solid"], "unitigs": r["s_unitigs"], "total": r["s_total"]},
+                "set_digest": "%016x" % r["set_digest"], "distinct": r["distinct"], "solid": r["solid"], "unitigs": r["unitigs"],
+                "sample": f"{sample_reads} x {read_len} bp synthetic reads (same generator, its own 30x genome), {r['distinct']} distinct k-mers, "
+                          f"{cores} threads on one shared lock-free table, reads -> unitigs in {r['s_total']:.2f} s; multithreaded CPU restatement "
+                          f"of the spec (oracle/cpu_mt.cpp), NOT BCALM 2 (its gatb-core sources are absent)"}
     cores = max(1, min(os.cpu_count() or 1, 32))
     t0 = time.time()
     res = []
@@ -161,7 +176,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--abundance-min", type=int, default=2)
-    ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=None, help="reads of the CPU baseline's sample (default: 10 M for k <= 31, 400 K per process otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)   # child of cpu_baseline: one scalar run, prints 'distinct seconds'
     ap.add_argument("--mode", choices=["sharded", "independent"], default="sharded",
@@ -174,6 +189,7 @@ def main():
            5: dict(k=127, read_len=1000, reads=6_250_000, name="BASELINE config 5, the share of one of its 8 GPUs (50 M reads / 8)")}[a.cfg]
     a.k = a.k or CFG["k"]; a.read_len = a.read_len or CFG["read_len"]
     a.reads = a.reads or int(os.environ.get("CDBG_BENCH_READS", CFG["reads"]))
+    a.cpu_sample_reads = a.cpu_sample_reads or (10_000_000 if a.k <= 31 else 400_000)
     if a.cpu_worker:
         d, dt = _cpu_worker((a.k, a.abundance_min, a.read_len, a.cfg, a.cpu_sample_reads))
         print(d, dt)
@@ -328,7 +344,17 @@ def main():
                                       "frac": alg_total / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.k, a.abundance_min, a.read_len, a.cfg, a.cpu_sample_reads)
+            out["cpu_baseline"] = cb = cpu_baseline(a.k, a.abundance_min, a.read_len, a.cfg, a.cpu_sample_reads)
+            if "set_digest" in cb:
+                # the same sample through the GPU path: CPU restatement and HIP kernels must agree on the whole unitig set
+                g2 = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank)
+                g2.generate_reads(a.cpu_sample_reads, a.read_len, a.cfg)
+                g2.run()
+                d2 = g2.digest(); s2 = g2.stats(); g2.close()
+                cb["gpu_same_sample"] = {"set_digest": "%016x" % d2["set_digest"], "distinct": s2["n_distinct"], "unitigs": s2["n_unitigs"], "gpu_ms": s2["ms_total"]}
+                cb["cpu_gpu_sets_equal"] = cb["set_digest"] == cb["gpu_same_sample"]["set_digest"] and cb["distinct"] == s2["n_distinct"] and cb["unitigs"] == s2["n_unitigs"]
+                out["checks"]["cpu restatement and GPU agree on the baseline sample (set digest)"] = cb["cpu_gpu_sets_equal"]
+                out["checks_passed"] = all(out["checks"].values())
         json_out.write(json.dumps(out) + "\n"); json_out.flush()
         if not out["checks_passed"]:
             sys.stderr.write("bench.py: OUTPUT CHECK FAILED: %r\n" % checks)

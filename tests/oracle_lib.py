@@ -11,8 +11,9 @@ SO = os.path.join(ODIR, "_build", "liboracle.so")
 
 
 def build():
-    src_m = max(os.path.getmtime(os.path.join(ODIR, f)) for f in ("cdbg_oracle.c", "oracle_impl.h", "cdbg_oracle.h"))
-    if not os.path.exists(SO) or os.path.getmtime(SO) < src_m:
+    src_m = max(os.path.getmtime(os.path.join(ODIR, f)) for f in ("cdbg_oracle.c", "oracle_impl.h", "cdbg_oracle.h", "cpu_mt.cpp"))
+    mt = os.path.join(ODIR, "_build", "libcpu_mt.so")
+    if not os.path.exists(SO) or os.path.getmtime(SO) < src_m or not os.path.exists(mt):
         subprocess.check_call(["make", "-C", ODIR, "-s"])
     return SO
 
@@ -85,6 +86,20 @@ class Oracle:
 
 def load():
     return Oracle(C.CDLL(build()))
+
+
+def cpu_mt_run(text, k, amin, threads):
+    """oracle/cpu_mt.cpp: the multithreaded CPU restatement (k <= 31) -> dict of counts, set digest and seconds"""
+    build()
+    lib = C.CDLL(os.path.join(ODIR, "_build", "libcpu_mt.so"))
+    lib.cpu_mt_run.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    out = (C.c_uint64 * 8)(); secs = (C.c_double * 4)()
+    data = text if isinstance(text, bytes) else text.encode()
+    rc = lib.cpu_mt_run(data, len(data), k, amin, threads, out, secs)
+    if rc != 0:
+        raise ValueError("cpu_mt_run: unsupported k")
+    return {"occurrences": out[0], "distinct": out[1], "solid": out[2], "unitigs": out[3], "kc_sum": out[4], "set_digest": out[5],
+            "unitig_bases": out[6], "s_count": secs[0], "s_solid": secs[1], "s_unitigs": secs[2], "s_total": secs[3]}
 
 
 def canonical_set(oracle, unitigs, k):

@@ -144,3 +144,17 @@ def test_reference_checker_accepts_oracle_unitigs(oracle, tmp_path, key):
     assert re.search(r"ERRONEOUS kmers:\s*0\b", final), final
     assert re.search(r"MISSING kmers:\s*0\b", final), final
     assert "REPEATED" not in final
+
+
+@pytest.mark.parametrize("k,amin,n_reads,cfg,threads", [(31, 2, 4000, 3, 4), (21, 1, 2000, 2, 3), (27, 3, 3000, 3, 8)])
+def test_cpu_mt_baseline_matches_oracle(oracle, k, amin, n_reads, cfg, threads):
+    """oracle/cpu_mt.cpp (bench.py's multithreaded CPU baseline) against the oracle: counts, KC sum and the set digest"""
+    from parity import set_digest
+    text = oracle.synth_reads(n_reads, 150, cfg)
+    exp = oracle.run(text, k, amin)
+    got = oracle_lib.cpu_mt_run(text, k, amin, threads)
+    assert got["occurrences"] == exp["stats"]["occurrences"] and got["distinct"] == exp["stats"]["distinct"]
+    assert got["solid"] == exp["stats"]["solid"] and got["unitigs"] == exp["stats"]["unitigs"]
+    assert got["kc_sum"] == sum(kc for _, kc in exp["unitigs"])
+    assert got["set_digest"] == set_digest(exp["unitigs"])
+    assert got["unitig_bases"] == exp["total_bases"]
