@@ -153,7 +153,8 @@ struct cdbg_ctx {
     uint64_t n_solid_entries = 0;                // home + traveller solid entries
 
     DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
-    DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;
+    DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;   // (fallback junction table)
+    DBuf<uint32_t> jfill, jtags; DBuf<uint64_t> jkeys;       // join buckets
     DBuf<uint64_t> glog_keys; DBuf<uint32_t> glog_tag; uint64_t glog_cap = 0, n_glog = 0;
     uint64_t n_pieces = 0, n_piece_bases = 0;
 
@@ -593,10 +594,7 @@ int compact_impl(cdbg_ctx* c) {
     const uint64_t NPL = c->n_local_parts;
     const uint64_t S = c->st.n_solid;
     Timer t; CK(t.start(s));
-    // glue table: at most one junction per solid traveller entry
-    CK(glue_table_slots(2 * c->st.n_solid_travellers + 64, &c->glue_cap));
-    CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false));
-    CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
+    // (the junction join works from the glue LOG; its tables are built in cdbg_glue)
     CK(c->cursors.alloc(8, false));
 
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -615,10 +613,6 @@ int compact_impl(cdbg_ctx* c) {
         if (c->prm.all_abundance_counts) CK(c->piece_ab.alloc(bcap, false));
         HIPCK(hipMemsetAsync(c->cursors.p, 0, 8 * sizeof(uint64_t), s));
         HIPCK(hipMemsetAsync(c->glog_tag.p, 0xFF, c->glog_cap * sizeof(uint32_t), s));
-        HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), s));
-        HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
-        HIPCK(hipMemsetAsync(c->glue_b.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
-        HIPCK(hipMemsetAsync(c->glue_conf.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->big_count.p, 0, 4 * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
@@ -629,8 +623,7 @@ int compact_impl(cdbg_ctx* c) {
         kp.piece_n = c->piece_n.p; kp.piece_kc = c->piece_kc.p; kp.piece_boff = c->piece_boff.p; kp.piece_bases = c->piece_bases.p;
         kp.piece_ab = c->prm.all_abundance_counts ? c->piece_ab.p : nullptr;
         kp.piece_cap = pcap; kp.bases_cap = bcap; kp.piece_cursor = c->cursors.p; kp.bases_cursor = c->cursors.p + 1;
-        kp.glue_keys = c->glue_keys.p; kp.glue_a = c->glue_a.p; kp.glue_b = c->glue_b.p;
-        kp.glue_conf = c->glue_conf.p; kp.glue_mask = c->glue_cap - 1;
+        kp.glue_keys = nullptr; kp.glue_a = nullptr; kp.glue_b = nullptr; kp.glue_conf = nullptr; kp.glue_mask = 0;
         kp.glog_keys = c->glog_keys.p; kp.glog_tag = c->glog_tag.p; kp.glog_cap = c->glog_cap; kp.glog_cursor = c->cursors.p + 4;
         kp.big_list = c->big_list.p; kp.big_count = c->big_count.p; kp.error = c->derr.p; kp.stats = c->dstats.p;
         kp.n_items = (uint32_t)NPL;
@@ -718,24 +711,45 @@ int glue_join_impl(cdbg_ctx* c, bool sharded) {
     HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
     HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
     const uint32_t world = sharded ? (uint32_t)c->prm.world_size : 1u;
-    if (world > 1) {                                         // a table for this rank's share of the junctions
-        CK(glue_table_slots((c->n_glog + c->n_glog / 4) / world + (c->n_glog >> 6) + 1024, &c->glue_cap));
+    const uint64_t n_mine = c->n_glog / world + (world > 1 ? (c->n_glog >> 6) + 1024 : 0);      // records this rank joins (estimate when sharded)
+    bool bucketed = getenv("CDBG_GLUE_TABLE") == nullptr && c->n_glog > 0;
+    if (bucketed) {
+        // bucketed join (k_glue.h): scatter the log into buckets of ~JB_CAP / 2 records, one wave joins a bucket in LDS
+        int log_jb = 0; while (((uint64_t)(JB_CAP / 2) << log_jb) < n_mine && log_jb < 26) ++log_jb;
+        const uint64_t JB = 1ull << log_jb;
+        CK(c->jfill.alloc(JB, false)); CK(c->jkeys.alloc(JB * JB_CAP * W, false)); CK(c->jtags.alloc(JB * JB_CAP, false));
+        HIPCK(hipMemsetAsync(c->jfill.p, 0, JB * sizeof(uint32_t), s));
+        JoinScatterParams sp{ c->glog_keys.p, c->glog_tag.p, c->n_glog, log_jb, c->jfill.p, c->jkeys.p, c->jtags.p, c->derr.p,
+                              world - 1, world > 1 ? (uint32_t)c->prm.rank : 0u };
+        CDBG_LAUNCH((k_join_scatter<W>), std::min<uint64_t>((c->n_glog + GLUE_THREADS - 1) / GLUE_THREADS, 1u << 16), GLUE_THREADS, s, sp);
+        JoinBucketParams bp{ c->jfill.p, c->jkeys.p, c->jtags.p, (uint32_t)JB, c->link.p, c->dstats.p };
+        CDBG_LAUNCH((k_join_bucket<W>), std::min<uint64_t>((JB + 3) / 4, 256 * 16), JB_THREADS, s, bp);
+        HIPCK(hipStreamSynchronize(s));
+        uint32_t e = 0; CK(read_u32(c->derr.p, &e));
+        if (e == 8) {                                        // a bucket overflowed (cannot happen with a sound hash): global table instead
+            bucketed = false;
+            HIPCK(hipMemsetAsync(c->link.p, 0xFF, (size_t)std::max<uint32_t>(NS, 1) * sizeof(uint32_t), s));
+            HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+            HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
+        }
+    }
+    if (!bucketed && c->n_glog) {
+        // fallback: one junction table in HBM (at most one junction per glue record)
+        CK(glue_table_slots(n_mine + n_mine / 4 + 1024, &c->glue_cap));
         CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false));
         CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
         HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), s));
         HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->glue_b.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->glue_conf.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
-    }
-    {   // build the junction table from the glue log (dense lanes => device atomics at throughput)
         GlueBuildParams bp{ c->glog_keys.p, c->glog_tag.p, c->n_glog, c->glue_keys.p, c->glue_a.p, c->glue_b.p, c->glue_conf.p, c->glue_cap - 1,
                             world - 1, world > 1 ? (uint32_t)c->prm.rank : 0u };
-        if (c->n_glog) CDBG_LAUNCH((k_glue_build<W>), std::min<uint64_t>((c->n_glog + GLUE_THREADS - 1) / GLUE_THREADS, MAX_GRID), GLUE_THREADS, s, bp);
+        CDBG_LAUNCH((k_glue_build<W>), std::min<uint64_t>((c->n_glog + GLUE_THREADS - 1) / GLUE_THREADS, MAX_GRID), GLUE_THREADS, s, bp);
+        GlueResolveParams gp{};
+        gp.keys = c->glue_keys.p; gp.a = c->glue_a.p; gp.b = c->glue_b.p; gp.conf = c->glue_conf.p;
+        gp.cap = c->glue_cap; gp.W = W; gp.link = c->link.p; gp.stats = c->dstats.p;
+        CDBG_LAUNCH(k_glue_resolve, std::min<uint64_t>((c->glue_cap + GLUE_THREADS - 1) / GLUE_THREADS, GLUE_RESOLVE_GRID), GLUE_THREADS, s, gp);
     }
-    GlueResolveParams gp{};
-    gp.keys = c->glue_keys.p; gp.a = c->glue_a.p; gp.b = c->glue_b.p; gp.conf = c->glue_conf.p;
-    gp.cap = c->glue_cap; gp.W = W; gp.link = c->link.p; gp.stats = c->dstats.p;
-    CDBG_LAUNCH(k_glue_resolve, std::min<uint64_t>((c->glue_cap + GLUE_THREADS - 1) / GLUE_THREADS, GLUE_RESOLVE_GRID), GLUE_THREADS, s, gp);
     float ms = 0; CK(t.stop(&ms));
     CK(check_device_error(c, "glue join"));
     uint64_t gs = 0; CK(read_u64(c->dstats.p, &gs));
@@ -1310,16 +1324,6 @@ int cdbg_exchange_end(cdbg_ctx* c) {
     c->piece_bases.swap(c->mg_bases); c->glog_keys.swap(c->mg_gkeys); c->glog_tag.swap(c->mg_gtag);
     c->n_pieces = c->mg_np; c->n_piece_bases = c->mg_nb; c->n_glog = c->mg_nl; c->glog_cap = c->mg_cap_l;
     c->mg_open = false;
-    // junction table for the union: at most one junction per glue record (typically 2-3 records per
-    // junction, so 1.25 x records keeps the load factor below one half in practice and below 0.8 always)
-    const int W = c->W;
-    CK(glue_table_slots(c->n_glog + c->n_glog / 4 + 64, &c->glue_cap));
-    CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false));
-    CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
-    HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), c->stream));
-    HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), c->stream));
-    HIPCK(hipMemsetAsync(c->glue_b.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), c->stream));
-    HIPCK(hipMemsetAsync(c->glue_conf.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
     return CDBG_OK;
 }

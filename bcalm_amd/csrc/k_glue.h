@@ -52,6 +52,112 @@ __global__ void k_glue_resolve(GlueResolveParams P) {
     if ((threadIdx.x & 63) == 0 && joined) atomic_add_u64(&P.stats[0], (uint64_t)joined);
 }
 
+// ---- (1') bucketed junction join: the default path ----
+// k_glue_build pays ~2.2 device atomics per log record into a table of 2^28 slots spread over 5 GB: every atomic is an
+// HBM read-modify-write (25 GB of traffic for a 1.7 GB log; profiles/r02a_*).  Here the log is first scattered into
+// JOIN BUCKETS of <= JB_CAP records by a hash of the junction key (one device atomic on a bucket counter -- an
+// L2-resident array -- and one plain store per record), then ONE WAVE joins each bucket in an LDS table of 2 JB_CAP slots
+// and writes the mutual links.  The global-table kernels above remain the fallback (a bucket that overflows).
+constexpr uint32_t JB_CAP = 256;                        // records per join bucket
+constexpr int JB_THREADS = 256;                         // 4 independent waves per workgroup
+struct JoinScatterParams {
+    const uint64_t* glog_keys; const uint32_t* glog_tag; uint64_t n_records; int log_jb;
+    uint32_t* jfill; uint64_t* jkeys; uint32_t* jtags; uint32_t* error;
+    uint32_t shard_mask, shard_rank;                    // multi-GPU sharded join (see GlueBuildParams)
+};
+template <int W>
+__global__ void k_join_scatter(JoinScatterParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n_records; i += stride) {
+        const uint32_t tag = P.glog_tag[i];
+        if (tag == GTAG_EMPTY) continue;
+        Kmer<W> jc;
+        for (int j = 0; j < W; ++j) jc.w[j] = P.glog_keys[i * W + j];
+        if (P.shard_mask && (mix32(jc.hash()) & P.shard_mask) != P.shard_rank) continue;
+        const uint32_t b = P.log_jb ? jc.hash_lds() >> (32 - P.log_jb) : 0u;
+        const uint32_t pos = atomic_add_u32(&P.jfill[b], 1u);
+        if (pos >= JB_CAP) { *P.error = 8; continue; }   // (the host falls back to the global table)
+        const uint64_t o = (uint64_t)b * JB_CAP + pos;
+        for (int j = 0; j < W; ++j) P.jkeys[o * W + j] = jc.w[j];
+        P.jtags[o] = tag;
+    }
+}
+template <int W>
+struct JoinWaveLds { uint64_t keys[2 * JB_CAP * W]; uint32_t a[2 * JB_CAP], b[2 * JB_CAP], conf[2 * JB_CAP]; };
+struct JoinBucketParams {
+    const uint32_t* jfill; const uint64_t* jkeys; const uint32_t* jtags; uint32_t n_buckets;
+    uint32_t* link; uint64_t* stats;                    // stats[0] junctions joined
+};
+template <int W>
+__global__ void __launch_bounds__(JB_THREADS) k_join_bucket(JoinBucketParams P) {
+    CDBG_SHARED JoinWaveLds<W> Ls[JB_THREADS / 64];
+    constexpr uint32_t TSJ = 2 * JB_CAP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)uni_u32((uint32_t)tid >> 6);
+    JoinWaveLds<W>& L = Ls[wave];
+    for (uint32_t i = lane; i < TSJ; i += 64) { L.keys[(uint64_t)i * W + (W - 1)] = KEY_EMPTY; L.a[i] = 0; L.b[i] = 0; L.conf[i] = 0; }
+    CDBG_WAVE_SYNC();
+    uint32_t joined = 0;
+    const uint32_t n_waves = gridDim.x * (JB_THREADS / 64);
+    for (uint32_t bk = blockIdx.x * (JB_THREADS / 64) + (uint32_t)wave; bk < P.n_buckets; bk += n_waves) {
+        uint32_t n = uni_u32(P.jfill[bk]); if (n > JB_CAP) n = JB_CAP;
+        const uint64_t base = (uint64_t)bk * JB_CAP;
+        // insert the bucket's records: find-or-insert the junction, then post the end / the confirmation
+        for (uint32_t i = lane; i < n; i += 64) {
+            Kmer<W> jc;
+            for (int j = 0; j < W; ++j) jc.w[j] = P.jkeys[(base + i) * W + j];
+            const uint32_t tag = P.jtags[base + i];
+            const uint64_t top = jc.w[W - 1];
+            uint32_t s = (jc.hash() >> 7) & (TSJ - 1);   // (bits other than the ones that chose the bucket)
+            bool done = false;
+#pragma clang loop unroll(disable)
+            do {
+                // the same junction arrives in 2-3 records, possibly in sibling lanes of one iteration.  Multi-word keys:
+                // the claimer marks the slot PENDING, writes the lower words and publishes inside the same iteration; a
+                // sibling that meets PENDING looks again (single exit: see ktable_insert)
+                uint64_t* const claim = &L.keys[(uint64_t)s * W + (W - 1)];
+                const uint64_t old = atomic_cas_u64(claim, KEY_EMPTY, W == 1 ? top : (top | KEY_PENDING));
+                bool advance = true;
+                if (old == KEY_EMPTY) {
+                    if (W > 1) {
+                        for (int j = 0; j < W - 1; ++j) L.keys[(uint64_t)s * W + j] = jc.w[j];
+                        __threadfence_block();
+                        atomic_exch_u64(claim, top);
+                    }
+                    done = true; advance = false;
+                } else if ((old & ~KEY_PENDING) == top) {
+                    if (W > 1 && (old & KEY_PENDING)) { CDBG_SPIN_YIELD(); advance = false; }
+                    else {
+                        bool eq = true;
+                        for (int j = 0; j < W - 1; ++j) eq &= (L.keys[(uint64_t)s * W + j] == jc.w[j]);
+                        if (eq) { done = true; advance = false; }
+                    }
+                }
+                if (advance) s = (s + 1) & (TSJ - 1);
+            } while (!done);
+            if (tag == GTAG_CONFIRM) atomic_or_u32(&L.conf[s], 1u);
+            else {
+                const uint32_t v = ((tag & ~GTAG_CONFBIT) + 1u) | (tag & GTAG_CONFBIT);
+                if (atomic_cas_u32(&L.a[s], 0u, v) != 0u) atomic_cas_u32(&L.b[s], 0u, v);
+            }
+        }
+        CDBG_WAVE_SYNC();
+        // a junction with two ends, confirmed 1-1 by its owning bucket (a CONFIRM record, or the flag riding on an end)
+        for (uint32_t s = lane; s < TSJ; s += 64) {
+            if (L.keys[(uint64_t)s * W + (W - 1)] == KEY_EMPTY) continue;
+            const uint32_t a = L.a[s], b = L.b[s];
+            if (a && b && (((a | b) & 0x80000000u) || L.conf[s])) {
+                const uint32_t ea = (a & 0x7FFFFFFFu) - 1u, eb = (b & 0x7FFFFFFFu) - 1u;
+                P.link[ea] = eb; P.link[eb] = ea;
+                ++joined;
+            }
+            L.keys[(uint64_t)s * W + (W - 1)] = KEY_EMPTY; L.a[s] = 0; L.b[s] = 0; L.conf[s] = 0;
+        }
+        CDBG_WAVE_SYNC();
+    }
+    const uint64_t j64 = wave_sum_u64(joined);
+    if (lane == 0 && j64) atomic_add_u64(&P.stats[0], j64);
+}
+
 // ---- (2) pointer jumping ----
 // per traversal state one 16-byte record {nxt, acc, tail, minp}: a jump is ONE random 16-byte gather
 // instead of four 4-byte gathers from four arrays
