@@ -33,14 +33,14 @@ class Stats(C.Structure):
         "unitig_bases", "n_big_partitions", "n_cycles")] + [
         ("minimizer_size", C.c_int), ("log2_partitions", C.c_int), ("kmer_words", C.c_int)] + [
         (n, C.c_float) for n in ("ms_scan_hist", "ms_scan_emit", "ms_count", "ms_compact", "ms_glue", "ms_total", "ms_exchange")] + [
-        (n, C.c_uint64) for n in ("n_launch_scan", "n_launch_count", "n_launch_compact", "n_multipass_partitions")]
+        (n, C.c_uint64) for n in ("n_launch_scan", "n_launch_count", "n_launch_compact", "n_multipass_partitions", "n_tiles_overlapped")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
-           "cdbg_generate_reads", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
+           "cdbg_generate_reads", "cdbg_expect_input", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
            "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats", "cdbg_digest",
            "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end", "cdbg_glue_join", "cdbg_glue_links_export", "cdbg_glue_links_import",
            "cdbg_exchange_sizes_packed", "cdbg_exchange_export_packed", "cdbg_exchange_add_packed",
@@ -80,6 +80,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_push_reads.argtypes = [vp, C.c_char_p, C.POINTER(u64), u64]
     lib.cdbg_push_text.argtypes = [vp, C.c_char_p, u64]
     lib.cdbg_generate_reads.argtypes = [vp, u64, u64, u64, u64, i32]
+    lib.cdbg_expect_input.argtypes = [vp, u64]
     lib.cdbg_read_text.argtypes = [vp, u64, u64, C.c_char_p]
     for f in ("cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset"):
         getattr(lib, f).argtypes = [vp]
@@ -152,6 +153,9 @@ class Graph:
     def push_text(self, text):
         b = text if isinstance(text, (bytes, bytearray)) else text.encode()
         self._ck(self.lib.cdbg_push_text(self._h, bytes(b), len(b)))
+
+    def expect_input(self, nbytes):
+        self._ck(self.lib.cdbg_expect_input(self._h, nbytes))
 
     def push_reads(self, reads):
         seqs = [r if isinstance(r, bytes) else r.encode() for r in reads]

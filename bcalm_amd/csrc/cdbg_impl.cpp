@@ -139,10 +139,13 @@ struct cdbg_ctx {
     // Ingest: pushed bytes go through two pinned staging buffers and are copied to the device asynchronously on
     // their own stream while the caller parses the next chunk; the device text grows by doubling.
     static constexpr uint64_t STAGE_BYTES = 32ull << 20;
+    uint64_t stage_bytes = STAGE_BYTES;          // (CDBG_STAGE_BYTES: smaller staging chunks, tests of the streaming scan)
     uint8_t* pin[2] = { nullptr, nullptr }; hipEvent_t pin_ev[2] = {}; bool pin_busy[2] = { false, false };
     int pin_cur = 0; uint64_t pin_fill = 0; hipStream_t copy_stream{};
     uint64_t n_dev = 0;                          // bytes of text already on (or on their way to) the device
     bool reads_final = false;                    // text complete, padded, nbytes set
+    // streaming scan (cdbg_expect_input): tiles already scanned while the input was still arriving
+    uint64_t expect_bytes = 0, ss_done = 0, ss_spill_cap = 0; uint32_t ss_part_cap = 0; bool ss_on = false;
     int log_np_override = -1;                    // set when a first count showed buckets too full for the LDS compaction tiers
     DBuf<uint8_t> reads; uint64_t nbytes = 0, nbytes_padded = 0;
 
@@ -186,9 +189,11 @@ struct cdbg_ctx {
 
 namespace {
 
+int stream_scan_dispatch(cdbg_ctx* c);
 // ---- streaming ingest ----
 int ingest_init(cdbg_ctx* c) {
     if (c->pin[0]) return CDBG_OK;
+    if (const char* e = getenv("CDBG_STAGE_BYTES")) c->stage_bytes = std::min<uint64_t>(cdbg_ctx::STAGE_BYTES, std::max<uint64_t>(64, strtoull(e, nullptr, 10)));
     HIPCK(hipStreamCreate(&c->copy_stream));
     for (int i = 0; i < 2; ++i) {
         if (hipHostMalloc((void**)&c->pin[i], cdbg_ctx::STAGE_BYTES) != hipSuccess) return fail(CDBG_E_NOMEM, "pinned staging buffer (%llu bytes)", (unsigned long long)cdbg_ctx::STAGE_BYTES);
@@ -206,7 +211,9 @@ void ingest_release(cdbg_ctx* c) {
 int ingest_reserve(cdbg_ctx* c, uint64_t need) {
     if (c->reads.p && c->reads.cap >= need) return CDBG_OK;
     uint64_t cap = std::max<uint64_t>(c->reads.cap * 2, 256ull << 20);
+    if (c->expect_bytes) cap = std::max<uint64_t>(cap, c->expect_bytes + c->expect_bytes / 64 + (8ull << 20));   // announced: one allocation
     while (cap < need) cap *= 2;
+    if (c->ss_on) HIPCK(hipStreamSynchronize(c->stream));    // a streaming scan may be reading the old buffer
     DBuf<uint8_t> bigger;
     CK(bigger.alloc(cap, false));
     HIPCK(hipStreamSynchronize(c->copy_stream));             // copies into the old buffer have landed
@@ -225,15 +232,16 @@ int ingest_flush(cdbg_ctx* c) {
     c->n_dev += c->pin_fill; c->pin_fill = 0;
     c->pin_cur = b ^ 1;
     if (c->pin_busy[b ^ 1]) { HIPCK(hipEventSynchronize(c->pin_ev[b ^ 1])); c->pin_busy[b ^ 1] = false; }   // its copy must be done before reuse
+    if (c->expect_bytes && c->prm.world_size == 1 && !c->force_multi) CK(stream_scan_dispatch(c));
     return CDBG_OK;
 }
 int ingest_append(cdbg_ctx* c, const char* src, uint64_t n) {
     CK(ingest_init(c));
     while (n) {
-        const uint64_t room = cdbg_ctx::STAGE_BYTES - c->pin_fill, take = std::min(room, n);
+        const uint64_t room = c->stage_bytes - c->pin_fill, take = std::min(room, n);
         memcpy(c->pin[c->pin_cur] + c->pin_fill, src, take);
         c->pin_fill += take; src += take; n -= take;
-        if (c->pin_fill == cdbg_ctx::STAGE_BYTES) CK(ingest_flush(c));
+        if (c->pin_fill == c->stage_bytes) CK(ingest_flush(c));
     }
     return CDBG_OK;
 }
@@ -314,6 +322,91 @@ int exscan_u32(cdbg_ctx* c, const uint32_t* counts, uint64_t* off, uint64_t n) {
     return CDBG_OK;
 }
 
+// the scan kernel for this k / m / mode on the context's stream (persistent grid: resident workgroups)
+template <int W, int MODE>
+void launch_scan_mode(cdbg_ctx* c, ScanParams& sp, uint64_t grid) {
+    hipStream_t s = c->stream;
+    const bool fast_scan = c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX;
+    sp.n_tiles = grid;
+    if (fast_scan && W == 1 && c->k - c->m == 15) CDBG_LAUNCH((k_scan_fast<W, MODE, W == 1 ? 15 : 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, W == 1 ? 15 : 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);
+    else if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE, 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);
+    else CDBG_LAUNCH((k_scan<W, MODE>), std::min<uint64_t>(grid, resident_grid(k_scan<W, MODE>, SCAN_THREADS, SCAN_GRID)), SCAN_THREADS, s, sp);
+}
+inline uint64_t scan_tile_bytes(const cdbg_ctx* c) { return (c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX) ? (uint64_t)SCANF_TILE : (uint64_t)SCAN_TILE; }
+void scan_params_base(cdbg_ctx* c, ScanParams& sp) {
+    sp.reads = c->reads.p; sp.nbytes = c->nbytes; sp.nbytes_padded = c->nbytes_padded;
+    sp.k = c->k; sp.m = c->m; sp.log_np = c->log_np; sp.rank_bits = c->rank_bits; sp.rank = c->prm.rank;
+    sp.part_count = c->part_count.p; sp.part_cursor = c->part_cursor.p; sp.records = nullptr; sp.stats = c->dstats.p;
+    sp.tile_stride = 1; sp.tile_offset = 0; sp.error = c->derr.p;
+}
+// capacity of a partition region from a sampled histogram (single-pass capped layout)
+void capped_capacities(double mean, uint64_t NPL, uint32_t& part_cap, uint64_t& spill_cap) {
+    part_cap = (uint32_t)(mean * 2.5 + 8.0 * std::sqrt(mean + 1.0) + 16.0);
+    part_cap = (part_cap + 7u) & ~7u;
+    if (const char* e = getenv("CDBG_PART_CAP")) part_cap = (uint32_t)std::max(1, atoi(e));   // test knob: force spills
+    spill_cap = std::max<uint64_t>((uint64_t)(mean * (double)NPL / 32.0), 65536);
+}
+
+// ---------------------------------------------------------------------------------------
+// Streaming scan: with cdbg_expect_input() the library knows the input volume before the last byte has
+// arrived, so partitioning and region capacities are fixed from the first ~128 MB that landed and the single-pass scan
+// runs on the tiles that are complete while the host is still parsing / copying the rest.
+// ---------------------------------------------------------------------------------------
+template <int W>
+int stream_scan_advance(cdbg_ctx* c) {
+    constexpr int RW = RecFmt<W>::RW;
+    hipStream_t s = c->stream;
+    const uint64_t landed = c->n_dev & ~15ull;
+    if (!c->ss_on) {
+        // (test knobs: CDBG_STREAM_MIN_BYTES / CDBG_STREAM_BATCH_TILES shrink the thresholds to simulator sizes)
+        const char* emin = getenv("CDBG_STREAM_MIN_BYTES");
+        const uint64_t min_bytes = emin ? strtoull(emin, nullptr, 10) : (128ull << 20);
+        if (landed < std::min<uint64_t>(c->expect_bytes / 2, min_bytes)) return CDBG_OK;
+        configure(c, c->expect_bytes);
+        const uint64_t TB = scan_tile_bytes(c);
+        const uint64_t tiles_now = landed > TB + 8192 ? (landed - 8192) / TB : 0;
+        const uint64_t tiles_exp = (c->expect_bytes + TB - 1) / TB;
+        if (!emin && (tiles_now < 1024 || tiles_exp <= 8192)) return CDBG_OK;    // small input: count decides
+        if (tiles_now < 1) return CDBG_OK;
+        const uint64_t NPL = c->n_local_parts;
+        CK(c->part_count.alloc(NPL, true)); CK(c->part_off.alloc(NPL + 1, false)); CK(c->part_cursor.alloc(NPL, false));
+        CK(c->dstats.alloc(32, true)); CK(c->derr.alloc(4, true)); CK(c->cursors.alloc(8, true));
+        HIPCK(hipStreamSynchronize(c->copy_stream));                               // the sample reads what has landed
+        ScanParams sp{}; c->nbytes = landed; c->nbytes_padded = landed; scan_params_base(c, sp);
+        const uint64_t stride = std::min<uint64_t>(64, std::max<uint64_t>(1, tiles_now / 2048));
+        const uint64_t ns = (tiles_now + stride - 1) / stride;
+        sp.tile_stride = (uint32_t)stride;
+        launch_scan_mode<W, SCAN_HIST>(c, sp, ns);
+        CK(exscan_u32(c, c->part_count.p, c->part_off.p, NPL));
+        uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPL, &sample_records));
+        const double mean = (double)sample_records * (double)tiles_exp / (double)ns / (double)NPL;
+        capped_capacities(mean, NPL, c->ss_part_cap, c->ss_spill_cap);
+        if ((double)c->ss_part_cap * (double)NPL * RW * 8.0 > 200e9) { c->expect_bytes = 0; return CDBG_OK; }   // would not fit: no streaming
+        CK(c->records.alloc((uint64_t)c->ss_part_cap * NPL * RW, false));
+        CK(c->spill_recs.alloc(c->ss_spill_cap * RW, false)); CK(c->spill_part.alloc(c->ss_spill_cap, false));
+        HIPCK(hipMemsetAsync(c->part_count.p, 0, NPL * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+        c->ss_on = true; c->ss_done = 0;
+    }
+    const uint64_t TB = scan_tile_bytes(c);
+    const uint64_t tiles_now = landed > TB + 8192 ? (landed - 8192) / TB : 0;      // tiles whose halo has landed as well
+    const char* ebt = getenv("CDBG_STREAM_BATCH_TILES");
+    if (tiles_now < c->ss_done + (ebt ? strtoull(ebt, nullptr, 10) : 32768ull)) return CDBG_OK;   // batches of >= 128 MB
+    // the kernel must see the bytes: order the compute stream behind the copies enqueued so far
+    hipEvent_t ev; HIPCK(hipEventCreate(&ev));
+    HIPCK(hipEventRecord(ev, c->copy_stream)); HIPCK(hipStreamWaitEvent(s, ev, 0)); (void)hipEventDestroy(ev);
+    ScanParams sp{}; c->nbytes = landed; c->nbytes_padded = landed; scan_params_base(c, sp);
+    sp.records = c->records.p; sp.part_cap = c->ss_part_cap; sp.part_fill = c->part_count.p;
+    sp.spill_recs = c->spill_recs.p; sp.spill_part = c->spill_part.p; sp.spill_cursor = c->cursors.p + 6; sp.spill_cap = c->ss_spill_cap;
+    sp.tile_offset = (uint32_t)c->ss_done;
+    launch_scan_mode<W, SCAN_EMIT_CAPPED>(c, sp, tiles_now - c->ss_done);
+    c->ss_done = tiles_now;
+    return CDBG_OK;
+}
+int stream_scan_dispatch(cdbg_ctx* c) {
+    switch (c->W) { case 1: return stream_scan_advance<1>(c); case 2: return stream_scan_advance<2>(c); default: return stream_scan_advance<4>(c); }
+}
+
 template <int W>
 int count_impl(cdbg_ctx* c) {
     constexpr int RW = RecFmt<W>::RW;
@@ -331,34 +424,29 @@ int count_impl(cdbg_ctx* c) {
         if (c->tr.all_gather_u64(c->tr.user, &mine, all.data(), 1) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
         total_bytes = 0; for (uint64_t v : all) total_bytes += v;
     }
-    configure(c, total_bytes);
+    if (!c->ss_on) configure(c, total_bytes);             // (a streaming scan fixed the partitioning from the announced volume)
     const uint64_t NPL = c->n_local_parts;
     const uint64_t NPS = multi ? (NPL << c->rank_bits) : NPL;    // partition slots the scan fills: all of them when the reads are sharded
     hipStream_t s = c->stream;
     Timer t_total; CK(t_total.start(s));
 
-    CK(c->part_count.alloc(NPS, true));
-    CK(c->part_off.alloc(NPS + 1, false));
-    CK(c->part_cursor.alloc(NPS, false));
-    CK(c->dstats.alloc(32, true));
-    CK(c->derr.alloc(4, true));
-    CK(c->cursors.alloc(8, true));
+    if (!c->ss_on) {
+        CK(c->part_count.alloc(NPS, true));
+        CK(c->part_off.alloc(NPS + 1, false));
+        CK(c->part_cursor.alloc(NPS, false));
+        CK(c->dstats.alloc(32, true));
+        CK(c->derr.alloc(4, true));
+        CK(c->cursors.alloc(8, true));
+    }
 
     ScanParams sp{};
-    sp.reads = c->reads.p; sp.nbytes = c->nbytes; sp.nbytes_padded = c->nbytes_padded;
-    sp.k = c->k; sp.m = c->m; sp.log_np = c->log_np; sp.rank_bits = c->rank_bits; sp.rank = c->prm.rank;
-    sp.part_count = c->part_count.p; sp.part_cursor = c->part_cursor.p; sp.records = nullptr; sp.stats = c->dstats.p;
-    sp.tile_stride = 1; sp.tile_offset = 0; sp.error = c->derr.p;
+    scan_params_base(c, sp);
     sp.emit_all = multi ? 1u : 0u; sp.npl = (uint32_t)NPL;
     // instruction-lean scan when the window fits registers; generic LDS-doubling scan otherwise
     const bool fast_scan = c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX;
     const uint64_t tiles = fast_scan ? (c->nbytes + SCANF_TILE - 1) / SCANF_TILE : (c->nbytes + SCAN_TILE - 1) / SCAN_TILE;
     c->st.n_launch_scan = tiles;
-#define LAUNCH_SCAN(MODE, GRID)                                                                  \
-    do { sp.n_tiles = (GRID);                                                                    \
-         if (fast_scan && W == 1 && c->k - c->m == 15) CDBG_LAUNCH((k_scan_fast<W, MODE, W == 1 ? 15 : 0>), std::min<uint64_t>((GRID), resident_grid(k_scan_fast<W, MODE, W == 1 ? 15 : 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp); \
-         else if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE, 0>), std::min<uint64_t>((GRID), resident_grid(k_scan_fast<W, MODE, 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);  \
-         else CDBG_LAUNCH((k_scan<W, MODE>), std::min<uint64_t>((GRID), resident_grid(k_scan<W, MODE>, SCAN_THREADS, SCAN_GRID)), SCAN_THREADS, s, sp); } while (0)
+#define LAUNCH_SCAN(MODE, GRID) launch_scan_mode<W, MODE>(c, sp, (GRID))
     auto exscan = [&](const uint32_t* counts) -> int {       // counts -> part_off (exclusive), part_off[NPS] = total
         return exscan_u32(c, counts, c->part_off.p, NPS);
     };
@@ -374,36 +462,47 @@ int count_impl(cdbg_ctx* c) {
     std::vector<uint32_t> spill_parts;                       // spilled partitions (sorted), capped mode
     DBuf<uint64_t> repair_recs, repair_off; DBuf<uint32_t> repair_part;
     Timer t;
+    uint64_t spill_cap = 0;
+    if (c->ss_on) capped = true;                             // tiles [0, ss_done) were scanned while the input was arriving
     if (capped) {
-        CK(t.start(s));
-        const uint64_t stride = std::min<uint64_t>(64, std::max<uint64_t>(1, tiles / 4096));
-        const uint64_t ns = (tiles + stride - 1) / stride;
-        sp.tile_stride = (uint32_t)stride;
-        LAUNCH_SCAN(SCAN_HIST, ns);
-        CK(exscan(c->part_count.p));
-        uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPL, &sample_records));
-        CK(t.stop(&c->st.ms_scan_hist));
-        const double mean = (double)sample_records * (double)tiles / (double)ns / (double)NPL;
-        part_cap = (uint32_t)(mean * 2.5 + 8.0 * std::sqrt(mean + 1.0) + 16.0);
-        part_cap = (part_cap + 7u) & ~7u;
-        if (const char* e = getenv("CDBG_PART_CAP")) part_cap = (uint32_t)std::max(1, atoi(e));   // test knob: force spills
-        const uint64_t spill_cap = std::max<uint64_t>((uint64_t)(mean * (double)NPL / 32.0), 65536);
-        if ((double)part_cap * (double)NPL * RW * 8.0 > 200e9) capped = false;     // would not fit: use the exact layout
+        bool fits = true;
+        if (c->ss_on) { part_cap = c->ss_part_cap; spill_cap = c->ss_spill_cap; }
         else {
-            CK(c->records.alloc((uint64_t)part_cap * NPL * RW, false));
-            CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
-            HIPCK(hipMemsetAsync(c->part_count.p, 0, NPL * sizeof(uint32_t), s));
-            HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+            CK(t.start(s));
+            const uint64_t stride = std::min<uint64_t>(64, std::max<uint64_t>(1, tiles / 4096));
+            const uint64_t ns = (tiles + stride - 1) / stride;
+            sp.tile_stride = (uint32_t)stride;
+            LAUNCH_SCAN(SCAN_HIST, ns);
+            CK(exscan(c->part_count.p));
+            uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPL, &sample_records));
+            CK(t.stop(&c->st.ms_scan_hist));
+            const double mean = (double)sample_records * (double)tiles / (double)ns / (double)NPL;
+            capped_capacities(mean, NPL, part_cap, spill_cap);
+            if ((double)part_cap * (double)NPL * RW * 8.0 > 200e9) fits = false;       // would not fit: use the exact layout
+            else {
+                CK(c->records.alloc((uint64_t)part_cap * NPL * RW, false));
+                CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
+                HIPCK(hipMemsetAsync(c->part_count.p, 0, NPL * sizeof(uint32_t), s));
+                HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+            }
+        }
+        if (!fits) capped = false;
+        else {
             sp.tile_stride = 1; sp.records = c->records.p; sp.part_cap = part_cap; sp.part_fill = c->part_count.p;
             sp.spill_recs = c->spill_recs.p; sp.spill_part = c->spill_part.p; sp.spill_cursor = c->cursors.p + 6; sp.spill_cap = spill_cap;
             CK(t.start(s));
-            LAUNCH_SCAN(SCAN_EMIT_CAPPED, tiles);
+            const uint64_t done = c->ss_on ? std::min<uint64_t>(c->ss_done, tiles) : 0;
+            sp.tile_offset = (uint32_t)done;
+            if (tiles > done) LAUNCH_SCAN(SCAN_EMIT_CAPPED, tiles - done);
+            sp.tile_offset = 0;
+            c->st.n_tiles_overlapped = done;
             CK(exscan(c->part_count.p));                     // only for the total number of records
             CK(t.stop(&c->st.ms_scan_emit));
             CK(read_u64(c->part_off.p + NPL, &n_records));
             CK(read_u64(c->dstats.p, hs, 2));
             CK(read_u64(c->cursors.p + 6, &n_spill));
             uint32_t derr = 0; CK(read_u32(c->derr.p, &derr));
+            c->ss_on = false;                                // (the streamed part is accounted for; a re-count scans everything)
             if (derr == 6 || n_spill > spill_cap) {          // estimate was off (very skewed input): exact layout instead
                 capped = false; HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t)));
             } else if (n_spill) {
@@ -1000,6 +1099,12 @@ int cdbg_push_text(cdbg_ctx* c, const char* text, uint64_t nbytes) {
     CK(ingest_append(c, "\n", 1));
     return CDBG_OK;
 }
+int cdbg_expect_input(cdbg_ctx* c, uint64_t text_bytes) {
+    if (!c) return fail(CDBG_E_PARAM, "null context");
+    if (c->stage != 0 || c->n_dev || c->pin_fill) return fail(CDBG_E_STATE, "cdbg_expect_input must precede the first push");
+    c->expect_bytes = text_bytes;
+    return CDBG_OK;
+}
 int cdbg_generate_reads(cdbg_ctx* c, uint64_t first_read, uint64_t n_reads, uint64_t total_reads, uint64_t read_len, int cfg) {
     if (!c) return fail(CDBG_E_PARAM, "null argument");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
@@ -1117,7 +1222,7 @@ int cdbg_reset(cdbg_ctx* c) {
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     c->stage = 0; c->st = cdbg_stats_t{};
     c->n_solid_entries = c->n_pieces = c->n_piece_bases = c->n_unitigs = c->unitig_total = 0; c->linked = false; c->n_links = 0; c->joined = false;
-    c->xchg_done = false; c->comm_bytes = 0; c->piece_lo = c->piece_hi = 0;
+    c->xchg_done = false; c->comm_bytes = 0; c->piece_lo = c->piece_hi = 0; c->ss_on = false; c->expect_bytes = 0;
     return CDBG_OK;                                  // reads and every device buffer stay resident
 }
 

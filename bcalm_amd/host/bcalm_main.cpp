@@ -11,8 +11,13 @@
 // this file is the replacement for bcalm_1::execute()/Functor (src/bcalm_1.cpp:49-97).
 #include <zlib.h>
 
+#include <sys/stat.h>
+
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -75,21 +80,22 @@ std::string base_name(const std::string& path) {          // strip directory and
     return b;
 }
 
-// FASTA / FASTQ, plain or gzip (zlib reads both), one call to cdbg_push_text per chunk
-void read_sequences(const std::string& path, const std::vector<cdbg_ctx*>& ctxs, size_t& next_ctx, uint64_t& n_seq, uint64_t& n_bases) {
+// Two-stage ingest: a parser thread turns FASTA / FASTQ (plain or gzip: zlib reads both) into chunks of sequences
+// separated by '\n'; the main thread pushes the chunks (cdbg_push_text copies into pinned staging buffers, the H2D
+// copies and -- with cdbg_expect_input -- the read scan itself overlap the parsing of the next chunk).
+struct ChunkQueue {
+    std::mutex m; std::condition_variable cv; std::deque<std::string> q; bool done = false; std::string error;
+    void put(std::string&& c) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return q.size() < 6; }); q.push_back(std::move(c)); cv.notify_all(); }
+    bool get(std::string& c) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || done; }); if (q.empty()) return false; c = std::move(q.front()); q.pop_front(); cv.notify_all(); return true; }
+    void finish(const std::string& err = "") { std::lock_guard<std::mutex> l(m); done = true; if (!err.empty()) error = err; cv.notify_all(); }
+};
+void parse_file(const std::string& path, ChunkQueue& out, size_t chunk_bytes, uint64_t& n_seq, uint64_t& n_bases) {
     gzFile f = gzopen(path.c_str(), "rb");
     if (!f) usage_error("cannot open input file " + path);
     gzbuffer(f, 1 << 20);
     std::vector<char> line(1 << 22);
-    std::string chunk; chunk.reserve(64 << 20);
+    std::string chunk; chunk.reserve(chunk_bytes + (1 << 20));
     int fmt = 0, fq_line = 0;                   // fmt: 0 unknown, 1 FASTA, 2 FASTQ
-    auto flush = [&]() {
-        if (chunk.empty()) return;
-        // (several GPUs: the reads are sharded -- whole chunks of complete sequences go to the contexts in turn)
-        if (cdbg_push_text(ctxs[next_ctx], chunk.data(), chunk.size()) != 0) usage_error(cdbg_last_error());
-        next_ctx = (next_ctx + 1) % ctxs.size();
-        chunk.clear();
-    };
     bool partial = false;                       // previous gzgets returned an unterminated piece
     while (gzgets(f, line.data(), (int)line.size())) {
         size_t n = strlen(line.data());
@@ -105,11 +111,23 @@ void read_sequences(const std::string& path, const std::vector<cdbg_ctx*>& ctxs,
             if (starts_line && n && line[0] == '>') { if (!chunk.empty() && chunk.back() != '\n') chunk.push_back('\n'); ++n_seq; }
             else if (!(starts_line && n && line[0] == ';')) { chunk.append(line.data(), n); n_bases += n; }
         }
-        if (chunk.size() > (ctxs.size() > 1 ? (4u << 20) : (48u << 20)) && (chunk.back() == '\n')) flush();
+        if (chunk.size() > chunk_bytes && chunk.back() == '\n') { out.put(std::move(chunk)); chunk.clear(); chunk.reserve(chunk_bytes + (1 << 20)); }
     }
     gzclose(f);
     if (!chunk.empty() && chunk.back() != '\n') chunk.push_back('\n');
-    flush();
+    if (!chunk.empty()) out.put(std::move(chunk));
+}
+// approximate number of sequence bytes a file will deliver (cdbg_expect_input): gzip ~4x, FASTQ carries as many quality bytes
+uint64_t estimate_text_bytes(const std::string& path) {
+    struct stat st; if (stat(path.c_str(), &st) != 0) return 0;
+    uint64_t n = (uint64_t)st.st_size;
+    gzFile f = gzopen(path.c_str(), "rb"); char c0 = 0;
+    if (f) { const int c = gzgetc(f); if (c >= 0) c0 = (char)c; gzclose(f); }
+    FILE* raw = fopen(path.c_str(), "rb"); unsigned char magic[2] = {0, 0};
+    if (raw) { if (fread(magic, 1, 2, raw) != 2) magic[0] = 0; fclose(raw); }
+    if (magic[0] == 0x1f && magic[1] == 0x8b) n *= 4;
+    if (c0 == '@') n /= 2;
+    return n + n / 50 + (1 << 20);
 }
 
 bool looks_like_file_list(const std::string& path) {       // README.md:47-50 "ls -1 *.fastq > list_reads"
@@ -160,11 +178,31 @@ int main(int argc, char** argv) {
             if (bad) for (auto& e : errs) if (!e.empty()) usage_error(e);
         }
         uint64_t n_seq = 0, n_bases = 0; size_t next_ctx = 0;
+        std::vector<std::string> files;
         if (looks_like_file_list(o.in)) {
             gzFile f = gzopen(o.in.c_str(), "rb"); char buf[4096];
-            while (gzgets(f, buf, sizeof buf)) { size_t n = strlen(buf); while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) buf[--n] = 0; if (n) read_sequences(buf, ctxs, next_ctx, n_seq, n_bases); }
+            while (gzgets(f, buf, sizeof buf)) { size_t n = strlen(buf); while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) buf[--n] = 0; if (n) files.push_back(buf); }
             gzclose(f);
-        } else read_sequences(o.in, ctxs, next_ctx, n_seq, n_bases);
+        } else files.push_back(o.in);
+        if (world == 1) {                                    // announce the volume: the scan starts while the input is still being parsed
+            uint64_t est = 0; for (const auto& f : files) est += estimate_text_bytes(f);
+            if (est) check(cdbg_expect_input(ctx, est));
+        }
+        {
+            ChunkQueue q;
+            std::thread parser([&]() {
+                try { for (const auto& f : files) parse_file(f, q, world > 1 ? (4u << 20) : (32u << 20), n_seq, n_bases); q.finish(); }
+                catch (const std::exception& e) { q.finish(e.what()); }
+            });
+            std::string chunk; std::string push_err;
+            while (q.get(chunk)) {                           // (several GPUs: whole chunks of complete sequences go to the contexts in turn)
+                if (push_err.empty() && cdbg_push_text(ctxs[next_ctx], chunk.data(), chunk.size()) != 0) push_err = cdbg_last_error();
+                next_ctx = (next_ctx + 1) % ctxs.size();
+            }
+            parser.join();
+            if (!q.error.empty()) usage_error(q.error);
+            if (!push_err.empty()) usage_error(push_err);
+        }
         auto t1 = std::chrono::steady_clock::now();
         // the stages are collective: one host thread per GPU
         auto all_ranks = [&](int (*stage)(cdbg_ctx*)) {
@@ -233,8 +271,8 @@ int main(int argc, char** argv) {
                (unsigned long long)st.n_distinct, (unsigned long long)st.n_solid, o.amin);
         printf("graph: %llu pieces -> %llu unitigs, %llu bases; minimizer size %d, 2^%d partitions\n", (unsigned long long)st.n_pieces,
                (unsigned long long)st.n_unitigs, (unsigned long long)st.unitig_bases, st.minimizer_size, st.log2_partitions);
-        printf("GPU: scan %.2f+%.2f ms, count %.2f ms, compact %.2f ms, glue %.2f ms; H2D+stages+D2H %.2f s; write %.2f s\n",
-               st.ms_scan_hist, st.ms_scan_emit, st.ms_count, st.ms_compact, st.ms_glue, sec(t1, t2), sec(t2, t3));
+        printf("GPU: scan %.2f+%.2f ms (%llu of %llu tiles scanned while the input was arriving), count %.2f ms, compact %.2f ms, glue %.2f ms; stages+links+D2H %.2f s; write %.2f s; end to end %.2f s\n",
+               st.ms_scan_hist, st.ms_scan_emit, (unsigned long long)st.n_tiles_overlapped, (unsigned long long)st.n_launch_scan, st.ms_count, st.ms_compact, st.ms_glue, sec(t1, t2), sec(t2, t3), sec(t0, t3));
         printf("unitigs written to %s\n", fa.c_str());
         for (cdbg_ctx* x : ctxs) cdbg_destroy(x);
     } catch (const std::exception& e) {

@@ -62,6 +62,7 @@ typedef struct cdbg_stats_t {
     float ms_exchange;            /* multi-GPU: time inside the record and glue exchanges (transport + merge kernels) */
     uint64_t n_launch_scan, n_launch_count, n_launch_compact;   /* workgroups launched */
     uint64_t n_multipass_partitions; /* partitions whose distinct k-mers did not fit one LDS pass (multi-pass kernel) */
+    uint64_t n_tiles_overlapped;     /* scan tiles processed while the input was still arriving (cdbg_expect_input) */
 } cdbg_stats_t;
 
 /* error codes */
@@ -82,6 +83,10 @@ const char* cdbg_last_error(void);
  * /root/reference/scripts/unitigEvaluator.cpp:130-131). */
 int cdbg_push_reads(cdbg_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_reads);
 int cdbg_push_text(cdbg_ctx* ctx, const char* text, uint64_t nbytes);
+/* Optional, before the first push: the (approximate) number of text bytes that will be pushed, e.g. from the file size.
+ * The device text is then allocated once, and the read scan starts on the part of the input that has already landed
+ * while the caller is still parsing and pushing the rest (single GPU; README.md:45-50 inputs through the CLI). */
+int cdbg_expect_input(cdbg_ctx* ctx, uint64_t text_bytes);
 /* Synthetic reads generated directly in HBM (BASELINE.md section 2 generator): reads
  * [first_read, first_read + n_reads) of a set of total_reads reads of read_len bases. */
 int cdbg_generate_reads(cdbg_ctx* ctx, uint64_t first_read, uint64_t n_reads, uint64_t total_reads,

@@ -180,3 +180,27 @@ def test_result_digest_on_gpu(oracle, oracle_1m, hip):
     assert d["set_digest"] == set_digest(exp["unitigs"]) == d2["set_digest"]
     assert d["kc_sum"] == d["solid_count_sum"] == sum(kc for _, kc in exp["unitigs"])
     assert d["kmers_in_unitigs"] == st["n_solid"] == exp["stats"]["solid"]
+
+
+def test_streaming_scan_while_ingesting_gpu(oracle, oracle_1m, hip, monkeypatch):
+    """cdbg_expect_input on the device: the single-pass scan runs on the tiles that have landed while later chunks are
+    still being pushed through the pinned staging buffers (copy stream -> event -> compute stream); 1 M reads vs the oracle"""
+    import bcalm_amd
+    monkeypatch.setenv("CDBG_STREAM_MIN_BYTES", str(16 << 20)); monkeypatch.setenv("CDBG_STREAM_BATCH_TILES", "2048")
+    text, exp = oracle_1m
+    g = bcalm_amd.Graph(31, 2, lib=hip)
+    g.expect_input(len(text))
+    step = 8 << 20
+    pos = 0
+    while pos < len(text):
+        end = text.find(b"\n", min(len(text) - 1, pos + step))
+        end = len(text) if end < 0 else end + 1
+        g.push_text(text[pos:end - 1] if text[end - 1:end] == b"\n" else text[pos:end])
+        pos = end
+    g.run()
+    st = g.stats()
+    canon = oracle_lib.canonical_set(oracle, g.unitigs(), 31)
+    g.close()
+    assert st["n_tiles_overlapped"] > 0.5 * st["n_launch_scan"]
+    assert st["n_distinct"] == exp["stats"]["distinct"] and st["n_solid"] == exp["stats"]["solid"]
+    assert canon == exp["unitigs"]

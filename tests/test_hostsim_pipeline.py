@@ -158,3 +158,26 @@ def test_result_digest_matches_formula(oracle, sim):
         assert d["set_digest"] == set_digest(exp["unitigs"])
         assert d["kc_sum"] == d["solid_count_sum"] == sum(c for _, c in exp["solid"])
         assert d["kmers_in_unitigs"] == st["n_solid"] == exp["stats"]["solid"]
+
+
+@pytest.mark.parametrize("k,amin,n_reads,cfg", [(31, 2, 3000, 3), (21, 1, 2500, 2), (55, 2, 1500, 4)])
+def test_streaming_scan_while_ingesting(oracle, sim, monkeypatch, k, amin, n_reads, cfg):
+    """cdbg_expect_input: the scan runs on the tiles that have landed while the rest is still being pushed (thresholds
+    shrunk to simulator sizes); same result as the oracle, and tiles really were scanned early"""
+    from bcalm_amd import api
+    monkeypatch.setenv("CDBG_STAGE_BYTES", "16384"); monkeypatch.setenv("CDBG_STREAM_MIN_BYTES", "40000"); monkeypatch.setenv("CDBG_STREAM_BATCH_TILES", "4")
+    text = oracle.synth_reads(n_reads, 150, cfg)
+    exp = oracle.run(text, k, amin)
+    reads = text.split(b"\n")
+    g = api.Graph(k, amin, lib=sim, log2_partitions=6)
+    g.expect_input(len(text))
+    for i in range(0, len(reads), 97):
+        chunk = b"\n".join(reads[i:i + 97])
+        if chunk:
+            g.push_text(chunk)
+    g.run()
+    st = g.stats()
+    canon = oracle_lib.canonical_set(oracle, g.unitigs(), k)
+    g.close()
+    assert st["n_tiles_overlapped"] > 0
+    assert st["n_distinct"] == exp["stats"]["distinct"] and canon == exp["unitigs"]
