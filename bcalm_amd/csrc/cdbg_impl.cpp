@@ -1002,7 +1002,8 @@ int link_impl(cdbg_ctx* c) {
     if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_link before cdbg_glue");
     hipStream_t s = c->stream;
     const uint64_t U = c->n_unitigs, NE = 2 * U;
-    if (NE >= 0x3FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many unitigs for 30-bit end slots");
+    // (k_links.h packs a slot index with a flag in bit 30: the table may have at most 2^30 slots)
+    if (pow2_at_least(4 * U + 64) > (1ull << 30)) return fail(CDBG_E_INTERNAL, "too many unitigs (%llu) for the 30-bit slots of the link table", (unsigned long long)U);
     const uint32_t cap = (uint32_t)pow2_at_least(4 * U + 64);
     DBuf<uint64_t> lk_keys; DBuf<uint32_t> lk_cnt, lk_ends, end_slot, deg;
     CK(lk_keys.alloc((uint64_t)cap * W, false)); CK(lk_cnt.alloc((uint64_t)cap * 2, true));
@@ -1161,7 +1162,7 @@ int cdbg_count(cdbg_ctx* c) {
         int extra = 1; while ((per_bucket >> extra) > 150 && c->log_np + extra < 26) ++extra;
         const float first_ms = c->st.ms_total;
         c->log_np_override = c->log_np + extra;
-        c->stage = 0;
+        c->stage = 0; c->st.n_big_partitions = 0; c->st.n_multipass_partitions = 0;       // (the first attempt's fallbacks are not part of the result)
         CK(count_dispatch(c));
         c->st.ms_total += first_ms;                          // the first attempt is part of the stage's time
     }

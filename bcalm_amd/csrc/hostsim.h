@@ -31,7 +31,7 @@
 #define CDBG_WAVE_SYNC() ::hostsim::wave_rendezvous(0)
 #define CDBG_PIN64(x) do { } while (0)
 #define CDBG_LAUNCH(kern, grid, block, stream, ...) \
-    ::hostsim::launch((unsigned)(grid), (unsigned)(block), [=]() { kern(__VA_ARGS__); })
+    (::hostsim::g_kernel_name = #kern, ::hostsim::launch((unsigned)(grid), (unsigned)(block), [=]() { kern(__VA_ARGS__); }))
 
 struct uint4 { unsigned x, y, z, w; };
 struct uint2 { unsigned x, y; };
@@ -46,6 +46,7 @@ struct Idx { unsigned x = 0, y = 0, z = 0; };
 inline Idx g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 
 enum { RUNNABLE = 0, AT_BLOCK = 1, AT_WAVE = 2, DONE = 3 };
+inline const char* g_kernel_name = "?";
 constexpr int kStack = 256 * 1024;
 constexpr int kMaxThreads = 1024;
 
@@ -128,7 +129,7 @@ inline void run_block(unsigned bx, unsigned nthreads, const std::function<void()
         bool any_runnable = false;
         for (int i = 0; i < B.n; ++i) if (B.state[i] == RUNNABLE) any_runnable = true;
         if (!any_runnable && !released) {
-            fprintf(stderr, "hostsim: DEADLOCK in block %u (divergent __syncthreads / wave intrinsic?) states:", bx);
+            fprintf(stderr, "hostsim: DEADLOCK in %s block %u (divergent __syncthreads / wave intrinsic?) states:", g_kernel_name, bx);
             for (int i = 0; i < B.n && i < 64; ++i) fprintf(stderr, " %d", B.state[i]);
             fprintf(stderr, "\n"); abort();
         }

@@ -384,19 +384,28 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                 // of the solid entries), solid entries are written compactly, the unused tail goes back to the
                 // workgroup's chunk.
                 if (npass == 1) {
+                    if (GLOBAL) {                                  // an HBM table's fill can exceed the solid capacity
+                        uint32_t my_solid = 0;                    // (sized for members / amin): count the solid entries first
+                        for (uint32_t s = tid; s < cap; s += NT)
+                            if (ktable_used<W>(T, s) && (cnt[s] & ~TRAV_FLAG) >= P.amin) ++my_solid;
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) my_solid += __shfl_xor(my_solid, d);
+                        if (lane == 0 && my_solid) atomic_add_u32(&s_nsolid, my_solid);
+                        block_sync<GLOBAL>();
+                    }
                     if (tid == 0) {
-                        const uint32_t need = s_fill;
+                        const uint32_t need = GLOBAL ? s_nsolid : s_fill;
                         uint64_t b;
                         if (need > COUNT_CHUNK) b = atomic_add_u64(P.solid_cursor, (uint64_t)need);
                         else {
                             if (need > chunk_left) { chunk_base = atomic_add_u64(P.solid_cursor, (uint64_t)COUNT_CHUNK); chunk_left = COUNT_CHUNK; }
                             b = chunk_base; chunk_base += need; chunk_left -= need;
                         }
-                        if (b + need > P.solid_cap) { *P.error = 1; b = 0; s_over = 2; }
+                        if (b + need > P.solid_cap) { *P.error = 1; b = ~0ull; }   // (not through s_over: slower waves may still be reading it)
                         s_base = b;
                     }
                     block_sync<GLOBAL>();
-                    const uint64_t obase = s_base; const bool wr_ok = s_over == 0;
+                    const bool wr_ok = s_base != ~0ull; const uint64_t obase = wr_ok ? s_base : 0;
                     uint32_t st_dist = 0, st_occ = 0, st_sh = 0, st_st = 0;
                     const uint32_t nfill = s_fill;
                     const bool by_list = !GLOBAL && nfill <= LIST_CAP;
@@ -430,7 +439,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     }
                     block_sync<GLOBAL>();
                     if (tid == 0) {
-                        const uint32_t used = s_wr, need = s_fill;
+                        const uint32_t used = s_wr, need = GLOBAL ? s_nsolid : s_fill;
                         P.seg_off[p] = obase; P.seg_n[p] = used;
                         if (need <= COUNT_CHUNK && wr_ok) { chunk_base -= (need - used); chunk_left += (need - used); }   // return the tail
                     }

@@ -294,6 +294,22 @@ def test_one_giant_partition_statistics(oracle, hip):
         assert got["stats"]["n_solid"] == exp["stats"]["solid"] == got["stats"]["n_distinct"]
 
 
+def test_one_giant_partition_many_weak_kmers(oracle, hip):
+    """ONE partition in the HBM count table whose fill (distinct k-mers) is far above the solid capacity
+    (members / abundance-min): 2 % errors, abundance-min 3, k = 97.  Found by bench_micro/fuzz_gpu.py (seed 21,
+    iteration 2124): the single-pass sweep reserved the table's fill and reported a solid overflow."""
+    rng = random.Random(97)
+    g = "".join(rng.choice("ACGT") for _ in range(200000))
+    reads = []
+    for _ in range(5000):
+        L = rng.randrange(150, 300); s = rng.randrange(0, len(g) - L)
+        reads.append("".join((rng.choice("ACGT") if rng.random() < 0.02 else c) for c in g[s:s + L]))
+    text = "\n".join(reads) + "\n"
+    exp = oracle.run(text, 97, 3)
+    got = assert_parity(oracle, hip, text, 97, 3, log2_partitions=0)
+    assert got["stats"]["n_distinct"] == exp["stats"]["distinct"] > 4 * exp["stats"]["solid"]
+
+
 def test_repartition_when_buckets_overflow(oracle, hip):
     """abundance-min 1 keeps every k-mer: with the partition count chosen for the count table the compaction buckets
     would hold ~900 entries and fall back to HBM tables (measured 716 ms instead of 40 ms for 3 M reads); cdbg_count
