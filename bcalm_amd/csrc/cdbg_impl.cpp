@@ -157,7 +157,7 @@ struct cdbg_ctx {
 
     DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
     DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;   // (fallback junction table)
-    DBuf<uint32_t> jfill, jtags; DBuf<uint64_t> jkeys;       // join buckets
+    DBuf<uint32_t> jfill; DBuf<uint64_t> jrecs;              // join buckets
     DBuf<uint64_t> glog_keys; DBuf<uint32_t> glog_tag; uint64_t glog_cap = 0, n_glog = 0;
     uint64_t n_pieces = 0, n_piece_bases = 0;
 
@@ -816,12 +816,12 @@ int glue_join_impl(cdbg_ctx* c, bool sharded) {
         // bucketed join (k_glue.h): scatter the log into buckets of ~JB_CAP / 2 records, one wave joins a bucket in LDS
         int log_jb = 0; while (((uint64_t)(JB_CAP / 2) << log_jb) < n_mine && log_jb < 26) ++log_jb;
         const uint64_t JB = 1ull << log_jb;
-        CK(c->jfill.alloc(JB, false)); CK(c->jkeys.alloc(JB * JB_CAP * W, false)); CK(c->jtags.alloc(JB * JB_CAP, false));
+        CK(c->jfill.alloc(JB, false)); CK(c->jrecs.alloc(JB * JB_CAP * (W + 1), false));
         HIPCK(hipMemsetAsync(c->jfill.p, 0, JB * sizeof(uint32_t), s));
-        JoinScatterParams sp{ c->glog_keys.p, c->glog_tag.p, c->n_glog, log_jb, c->jfill.p, c->jkeys.p, c->jtags.p, c->derr.p,
+        JoinScatterParams sp{ c->glog_keys.p, c->glog_tag.p, c->n_glog, log_jb, c->jfill.p, c->jrecs.p, c->derr.p,
                               world - 1, world > 1 ? (uint32_t)c->prm.rank : 0u };
         CDBG_LAUNCH((k_join_scatter<W>), std::min<uint64_t>((c->n_glog + GLUE_THREADS - 1) / GLUE_THREADS, 1u << 16), GLUE_THREADS, s, sp);
-        JoinBucketParams bp{ c->jfill.p, c->jkeys.p, c->jtags.p, (uint32_t)JB, c->link.p, c->dstats.p };
+        JoinBucketParams bp{ c->jfill.p, c->jrecs.p, (uint32_t)JB, c->link.p, c->dstats.p };
         CDBG_LAUNCH((k_join_bucket<W>), std::min<uint64_t>((JB + 3) / 4, 256 * 16), JB_THREADS, s, bp);
         HIPCK(hipStreamSynchronize(s));
         uint32_t e = 0; CK(read_u32(c->derr.p, &e));

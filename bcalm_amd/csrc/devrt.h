@@ -61,6 +61,11 @@ CDBG_DEV uint32_t atomic_cas_u32(uint32_t* p, uint32_t cmp, uint32_t v) { return
 CDBG_DEV uint32_t atomic_max_u32(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
 CDBG_DEV uint32_t atomic_min_u32(uint32_t* p, uint32_t v) { return atomicMin(p, v); }
 CDBG_DEV void atomic_or_u64(uint64_t* p, uint64_t v) { (void)atomicOr((unsigned long long*)p, (unsigned long long)v); }
+// unaligned global accesses (gfx950 global_load/store take any byte address; one request instead of 8 / 4 / 2)
+CDBG_DEV uint64_t ld_unaligned_u64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+CDBG_DEV void st_unaligned_u64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+CDBG_DEV void st_unaligned_u32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+CDBG_DEV void st_unaligned_u16(uint8_t* p, uint16_t v) { __builtin_memcpy(p, &v, 2); }
 
 // ---- wave64 primitives that do not go through the LDS crossbar ----
 // (measured on MI355X, bench_micro/micro_r02: one ds_bpermute costs ~19 SIMD cycles per wave, a DPP-modified
