@@ -78,7 +78,13 @@ struct DBuf {                                   // owned device array
 #ifndef CDBG_NTC1
 #define CDBG_NTC1 512
 #endif
-constexpr int TS_COUNT_1 = CDBG_TSC1, TS_COUNT_2 = 2048, TS_COUNT_4 = 1024;      // LDS table slots per W
+#ifndef CDBG_TSC2
+#define CDBG_TSC2 2048
+#endif
+#ifndef CDBG_TSC4
+#define CDBG_TSC4 2048
+#endif
+constexpr int TS_COUNT_1 = CDBG_TSC1, TS_COUNT_2 = CDBG_TSC2, TS_COUNT_4 = CDBG_TSC4;      // LDS table slots per W
 #ifndef CDBG_TSK1
 #define CDBG_TSK1 1024
 #endif
@@ -90,12 +96,18 @@ constexpr int TS_COMPACT_1 = CDBG_TSK1, TS_COMPACT_2 = 512, TS_COMPACT_4 = 512;
 template <int W> struct Cfg;
 // TSW: slots of the wave-per-bucket compaction tier (buckets of at most TSW / 2 entries; k_compact_wave.h)
 template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1, TSK2 = 2 * TS_COMPACT_1, NTC = CDBG_NTC1, TSW = 512; };
-template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, TSK2 = 2 * TS_COMPACT_2, NTC = 512, TSW = 256; };
-template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, TSK2 = 2 * TS_COMPACT_4, NTC = 256, TSW = 128; };
-
-#ifndef CDBG_TSW1
-#define CDBG_TSW1 512
+#ifndef CDBG_TSW2
+#define CDBG_TSW2 256
 #endif
+template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, TSK2 = 2 * TS_COMPACT_2, NTC = 512, TSW = CDBG_TSW2; };
+#ifndef CDBG_NTC4
+#define CDBG_NTC4 256
+#endif
+#ifndef CDBG_TSW4
+#define CDBG_TSW4 256
+#endif
+template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, TSK2 = 2 * TS_COMPACT_4, NTC = CDBG_NTC4, TSW = CDBG_TSW4; };
+
 #ifndef CDBG_PGRID
 #define CDBG_PGRID (256 * 12)
 #endif
@@ -294,7 +306,7 @@ void configure(cdbg_ctx* c, uint64_t total_bytes) {
 #endif
     // (four-word k-mers: at k = 127 three quarters of the k-mers of reads with 1 % errors are distinct, so a partition
     //  must hold fewer occurrences for its distinct k-mers to fit the one-pass table)
-    const uint64_t target_occ = W == 4 ? (uint64_t)ts * 3 / 5 : (uint64_t)ts * CDBG_OCC_NUM / CDBG_OCC_DEN;
+    const uint64_t target_occ = W == 4 ? (uint64_t)ts * 3 / 10 : (uint64_t)ts * CDBG_OCC_NUM / CDBG_OCC_DEN;
     int log_np = c->log_np_override >= 0 ? c->log_np_override : c->prm.log2_partitions;
     if (log_np < 0) {
         log_np = 0;
