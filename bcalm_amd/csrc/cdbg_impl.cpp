@@ -175,6 +175,9 @@ struct cdbg_ctx {
 
     // multi-GPU merge staging (cdbg_exchange_*)
     DBuf<uint32_t> mg_n, mg_gtag; DBuf<uint64_t> mg_kc, mg_boff, mg_gkeys; DBuf<uint8_t> mg_bases;
+    DBuf<uint32_t> mg_ab, xp_ab;                         // -all-abundance-counts: merged per-base abundances / this rank's gap-free stream
+    DBuf<uint64_t> xp_aoff, xr_aoff; uint64_t xp_nab = 0; bool xp_ab_ready = false;
+    uint64_t last_add_np = 0, last_add_nb = 0, last_add_pieces = 0;   // where the latest cdbg_exchange_add_packed put its pieces
     uint64_t mg_np = 0, mg_nb = 0, mg_nl = 0, mg_cap_p = 0, mg_cap_b = 0, mg_cap_l = 0; bool mg_open = false;
     // junction join result (cdbg_glue_join / first half of cdbg_glue): partner end of every piece end
     DBuf<uint32_t> link; bool joined = false; uint64_t n_join_local = 0;
@@ -897,10 +900,27 @@ int glue_exchange(cdbg_ctx* c) {
     }
     uint64_t tp = 0, tb = 0, tl = 0;
     for (int r = 0; r < world; ++r) { if (r == c->prm.rank) c->piece_lo = tp; tp += col(r, 0); if (r == c->prm.rank) c->piece_hi = tp; tb += col(r, 1); tl += col(r, 2); }
+    // -all-abundance-counts: a sixth array, one u32 per k-mer of the rank's pieces
+    std::vector<uint64_t> aoff(world), acnt(world);
+    if (c->prm.all_abundance_counts) {
+        uint64_t nv = 0; CK(cdbg_exchange_abundance_values(c, &nv));
+        std::vector<uint64_t> allv(world);
+        if (c->tr.all_gather_u64(c->tr.user, &nv, allv.data(), 1) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
+        uint64_t tot = 0;
+        for (int r = 0; r < world; ++r) { acnt[r] = allv[r] * 4; aoff[r] = tot; tot += (acnt[r] + 15) / 16 * 16; }
+        CK(c->xp_ab.alloc(tot / 4 + 4, false));
+        const uint64_t nb = acnt[c->prm.rank];
+        CK(sendbuf.alloc(nb + 16, false));
+        CK(cdbg_exchange_export_abundances(c, sendbuf.p, nb + 16));
+        if (c->tr.all_gather_v(c->tr.user, sendbuf.p, nb, c->xp_ab.p, aoff.data(), acnt.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_v failed");
+        for (int r = 0; r < world; ++r) if (r != c->prm.rank) c->comm_bytes += nb + acnt[r];
+    }
     CK(cdbg_exchange_begin(c, tp, tb, tl));
-    for (int r = 0; r < world; ++r)
+    for (int r = 0; r < world; ++r) {
         CK(cdbg_exchange_add_packed(c, col(r, 0), col(r, 1), col(r, 3), col(r, 2), c->xg[0].p + roff[0][r], c->xg[1].p + roff[1][r],
                                     c->xg[2].p + roff[2][r], c->xg[3].p + roff[3][r], c->xg[4].p + roff[4][r]));
+        if (c->prm.all_abundance_counts) CK(cdbg_exchange_add_abundances(c, (const uint8_t*)c->xp_ab.p + aoff[r], acnt[r] / 4));
+    }
     CK(cdbg_exchange_end(c));
     // sharded junction join
     uint64_t n_ends = 0; CK(cdbg_glue_join(c, &n_ends));
@@ -1235,7 +1255,7 @@ int cdbg_reset(cdbg_ctx* c) {
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     c->stage = 0; c->st = cdbg_stats_t{};
     c->n_solid_entries = c->n_pieces = c->n_piece_bases = c->n_unitigs = c->unitig_total = 0; c->linked = false; c->n_links = 0; c->joined = false;
-    c->xchg_done = false; c->comm_bytes = 0; c->piece_lo = c->piece_hi = 0; c->ss_on = false; c->expect_bytes = 0;
+    c->xchg_done = false; c->xp_ab_ready = false; c->comm_bytes = 0; c->piece_lo = c->piece_hi = 0; c->ss_on = false; c->expect_bytes = 0;
     return CDBG_OK;                                  // reads and every device buffer stay resident
 }
 
@@ -1301,7 +1321,7 @@ int cdbg_fetch_unitigs(cdbg_ctx* c, uint64_t first, uint64_t n, char* seq_buf, u
 int cdbg_exchange_sizes(cdbg_ctx* c, uint64_t out[3]) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    if (c->prm.all_abundance_counts) return fail(CDBG_E_PARAM, "-all-abundance-counts is single-GPU only in this version");
+    if (c->prm.all_abundance_counts) return fail(CDBG_E_PARAM, "-all-abundance-counts travels with the packed exchange only (cdbg_exchange_sizes_packed)");
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
     out[0] = c->n_pieces; out[1] = c->n_piece_bases; out[2] = c->n_glog;
     return CDBG_OK;
@@ -1336,6 +1356,7 @@ int cdbg_exchange_begin(cdbg_ctx* c, uint64_t total_pieces, uint64_t total_bases
     const uint64_t bases_slack = 64ull * 4096;               // the packed exchange starts every rank's bases on a 64-byte boundary
     CK(c->mg_bases.alloc(std::max<size_t>(total_bases + bases_slack, c->piece_bases.cap), false));
     CK(c->mg_gkeys.alloc(std::max<size_t>(total_glog * c->W, c->glog_keys.cap), false)); CK(c->mg_gtag.alloc(std::max<size_t>(total_glog, c->glog_tag.cap), false));
+    if (c->prm.all_abundance_counts) CK(c->mg_ab.alloc(std::max<size_t>(total_bases + bases_slack, c->piece_ab.cap), false));
     c->mg_np = c->mg_nb = c->mg_nl = 0; c->mg_cap_p = total_pieces; c->mg_cap_b = total_bases + bases_slack; c->mg_cap_l = total_glog; c->mg_open = true;
     return CDBG_OK;
 }
@@ -1361,7 +1382,6 @@ int cdbg_exchange_add(cdbg_ctx* c, uint64_t n_pieces, uint64_t n_bases, uint64_t
 int cdbg_exchange_sizes_packed(cdbg_ctx* c, uint64_t out[4]) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    if (c->prm.all_abundance_counts) return fail(CDBG_E_PARAM, "-all-abundance-counts is single-GPU only in this version");
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
     hipStream_t s = c->stream;
     const uint64_t NP = c->n_pieces;
@@ -1431,7 +1451,54 @@ int cdbg_exchange_add_packed(cdbg_ctx* c, uint64_t n_pieces, uint64_t n_bases, u
     const uint64_t work = std::max(n_pieces, n_glog);
     if (work) CDBG_LAUNCH(k_merge_append, std::min<uint64_t>((work + 255) / 256, MAX_GRID), 256, s, mp);
     HIPCK(hipStreamSynchronize(s));
+    c->last_add_np = c->mg_np; c->last_add_nb = c->mg_nb; c->last_add_pieces = n_pieces;
     c->mg_np += n_pieces; c->mg_nb += n_bases; c->mg_nl += n_glog;
+    return CDBG_OK;
+}
+// -all-abundance-counts: the abundances of this rank's pieces as a gap-free stream, one u32 per k-mer, in the piece
+// order of cdbg_exchange_sizes_packed
+int cdbg_exchange_abundance_values(cdbg_ctx* c, uint64_t* n_values) {
+    if (!c || !n_values) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);
+    if (!c->prm.all_abundance_counts) return fail(CDBG_E_STATE, "context was created without all_abundance_counts");
+    if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
+    CK(c->xp_aoff.alloc(c->n_pieces + 1, false));
+    CK(exscan_u32(c, c->piece_n.p, c->xp_aoff.p, c->n_pieces));
+    HIPCK(hipStreamSynchronize(c->stream));
+    CK(read_u64(c->xp_aoff.p + c->n_pieces, &c->xp_nab));
+    *n_values = c->xp_nab; c->xp_ab_ready = true;
+    return CDBG_OK;
+}
+int cdbg_exchange_export_abundances(cdbg_ctx* c, void* dst_dev, uint64_t nbytes) {
+    if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);
+    if (c->stage != 2 || !c->xp_ab_ready) return fail(CDBG_E_STATE, "cdbg_exchange_export_abundances before cdbg_exchange_abundance_values");
+    const uint64_t NP = c->n_pieces;
+    if (nbytes < c->xp_nab * sizeof(uint32_t)) return fail(CDBG_E_PARAM, "export buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)(c->xp_nab * sizeof(uint32_t)));
+    if (NP) {
+        AbStreamParams ap{ NP, c->k, 0, c->piece_n.p, c->xp_aoff.p, nullptr, c->piece_boff.p, 0, c->piece_ab.p, (uint32_t*)dst_dev };
+        CDBG_LAUNCH(k_ab_stream, (NP + 255) / 256, 256, c->stream, ap);
+    }
+    HIPCK(hipStreamSynchronize(c->stream));
+    return CDBG_OK;
+}
+// ... and the stream of the rank whose pieces the latest cdbg_exchange_add_packed appended
+int cdbg_exchange_add_abundances(cdbg_ctx* c, const void* ab_stream, uint64_t n_values) {
+    if (!c || !ab_stream) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);
+    if (!c->prm.all_abundance_counts) return fail(CDBG_E_STATE, "context was created without all_abundance_counts");
+    if (!c->mg_open) return fail(CDBG_E_STATE, "cdbg_exchange_add_abundances without cdbg_exchange_begin");
+    const uint64_t NP = c->last_add_pieces;
+    CK(c->xr_aoff.alloc(NP + 1, false));
+    CK(exscan_u32(c, c->mg_n.p + c->last_add_np, c->xr_aoff.p, NP));
+    HIPCK(hipStreamSynchronize(c->stream));
+    uint64_t tot = 0; CK(read_u64(c->xr_aoff.p + NP, &tot));
+    if (n_values != tot) return fail(CDBG_E_PARAM, "abundance stream of %llu values does not match the %llu k-mers of the pieces added last", (unsigned long long)n_values, (unsigned long long)tot);
+    if (NP) {
+        AbStreamParams ap{ NP, c->k, 1, c->mg_n.p + c->last_add_np, c->xr_aoff.p, c->xr_uoff.p, nullptr, c->last_add_nb, c->mg_ab.p, (uint32_t*)ab_stream };
+        CDBG_LAUNCH(k_ab_stream, (NP + 255) / 256, 256, c->stream, ap);
+    }
+    HIPCK(hipStreamSynchronize(c->stream));
     return CDBG_OK;
 }
 int cdbg_exchange_end(cdbg_ctx* c) {
@@ -1440,6 +1507,7 @@ int cdbg_exchange_end(cdbg_ctx* c) {
     if (!c->mg_open) return fail(CDBG_E_STATE, "cdbg_exchange_end without cdbg_exchange_begin");
     c->piece_n.swap(c->mg_n); c->piece_kc.swap(c->mg_kc); c->piece_boff.swap(c->mg_boff);
     c->piece_bases.swap(c->mg_bases); c->glog_keys.swap(c->mg_gkeys); c->glog_tag.swap(c->mg_gtag);
+    if (c->prm.all_abundance_counts) c->piece_ab.swap(c->mg_ab);
     c->n_pieces = c->mg_np; c->n_piece_bases = c->mg_nb; c->n_glog = c->mg_nl; c->glog_cap = c->mg_cap_l;
     c->mg_open = false;
     HIPCK(hipStreamSynchronize(c->stream));

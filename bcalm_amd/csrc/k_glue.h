@@ -415,6 +415,21 @@ __global__ void k_squeeze_bases(SqueezeParams P) {
     for (uint32_t j = 0; j < len; ++j) dst[j] = src[j];
 }
 // sender, step 2 / receiver: streaming 64 ASCII bases <-> 16 packed bytes per lane (dense is padded to 64 bytes)
+// -all-abundance-counts across ranks: the abundances of a rank's pieces as one gap-free u32 stream, n values per piece
+// (aoff = exclusive scan of piece_n).  dir 0: piece_ab (indexed like the bases) -> stream; dir 1: stream -> piece_ab
+// of the merged numbering (bases of the piece at boff_base + uoff[p])
+struct AbStreamParams { uint64_t n_pieces; int k; int dir; const uint32_t* piece_n; const uint64_t* aoff; const uint64_t* uoff; const uint64_t* boff; uint64_t boff_base;
+                        uint32_t* piece_ab; uint32_t* stream; };
+__global__ void k_ab_stream(AbStreamParams P) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P.n_pieces) return;
+    const uint32_t n = P.piece_n[p];
+    if (!n) return;                                        // reservation gap
+    uint32_t* const st = P.stream + P.aoff[p];
+    uint32_t* const ab = P.piece_ab + (P.boff ? P.boff[p] : P.boff_base + P.uoff[p]) + (P.k - 1);
+    if (P.dir == 0) { for (uint32_t t = 0; t < n; ++t) st[t] = ab[t]; }
+    else { for (uint32_t t = 0; t < n; ++t) ab[t] = st[t]; }
+}
 struct StreamPackParams { uint64_t n_chunks; const uint8_t* ascii; uint8_t* packed; uint64_t n_bases; };
 __global__ void k_pack_stream(StreamPackParams P) {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

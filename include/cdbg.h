@@ -164,6 +164,13 @@ int cdbg_exchange_export_packed(cdbg_ctx* ctx, void* dst_dev, uint64_t nbytes);
 int cdbg_exchange_add_packed(cdbg_ctx* ctx, uint64_t n_pieces, uint64_t n_bases, uint64_t n_packed, uint64_t n_glog,
                              const void* piece_n, const void* piece_kc, const void* packed_bases, const void* glog_keys,
                              const void* glog_tag);
+/* Contexts created with all_abundance_counts = 1 (-all-abundance-counts, README.md:74-80, across ranks): the abundances of
+ * a rank's pieces travel as one more gap-free stream, one u32 per k-mer, same piece order.  Sender:
+ * cdbg_exchange_abundance_values (how many), cdbg_exchange_export_abundances; receiver: cdbg_exchange_add_abundances
+ * right after the cdbg_exchange_add_packed of the same rank. */
+int cdbg_exchange_abundance_values(cdbg_ctx* ctx, uint64_t* n_values);
+int cdbg_exchange_export_abundances(cdbg_ctx* ctx, void* dst_dev, uint64_t nbytes);
+int cdbg_exchange_add_abundances(cdbg_ctx* ctx, const void* ab_stream, uint64_t n_values);
 /* Sharded junction join (optional, after cdbg_exchange_end): instead of every rank hash-joining ALL glue
  * records inside cdbg_glue, cdbg_glue_join joins only the junctions whose key hash selects this rank and
  * leaves link[end] = -1 for the others.  The caller exports the int32 link array (n_ends entries), combines

@@ -32,11 +32,12 @@ def _run_sharded(api, cdist, lib, orc, text, k, amin, world, rank, steps=1, **kw
             g.reset()
         g.run()
         mine = g.unitigs(); st = g.stats(); nbytes = g.comm_bytes()
+        ab = g.unitig_abundances() if kw.get("all_abundance_counts") else None
         gathered = [None] * world
         dist.all_gather_object(gathered, (mine, st["n_distinct"], st["n_solid"], st["n_occurrences"]))
         out = {"union": sorted((orc.canonical_unitig(s, k), int(kc)) for part in gathered for s, kc in part[0]),
                "mine": mine, "distinct": sum(p[1] for p in gathered), "solid": sum(p[2] for p in gathered),
-               "occ": sum(p[3] for p in gathered), "comm_bytes": nbytes, "per_rank": [len(p[0]) for p in gathered]}
+               "occ": sum(p[3] for p in gathered), "comm_bytes": nbytes, "per_rank": [len(p[0]) for p in gathered], "ab": ab}
     g.close()
     return out
 
@@ -63,6 +64,14 @@ def _worker(rank, world, port, q, cases):
             ok.append(got["union"] == exp["unitigs"])
         ok.append(got["distinct"] == exp["stats"]["distinct"] and got["solid"] == exp["stats"]["solid"] and got["occ"] == exp["stats"]["occurrences"])
         ok.append(got["comm_bytes"] > 0)
+        if kw.get("all_abundance_counts"):
+            # -all-abundance-counts across ranks: the vector of every unitig this rank emitted is the oracle's count of its k-mers
+            solid = dict(orc.run(text, k, amin, want_solid=True)["solid"]); comp = str.maketrans("ACGT", "TGCA")
+            good = len(got["ab"]) == len(got["mine"])
+            for (s_, kc), a in zip(got["mine"], got["ab"]):
+                want = [solid[min(s_[i:i + k], s_[i:i + k].translate(comp)[::-1])] for i in range(len(s_) - k + 1)]
+                good = good and a == want and sum(a) == kc
+            ok.append(good)
     # bench.py's reductions for N > 1
     t = torch.tensor([0.5 + rank], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ok.append(float(t.item()) == 0.5 + world - 1)
@@ -88,10 +97,12 @@ def _launch(world, cases, port_base, timeout):
 
 def test_two_rank_gloo():
     """world 2: one-, two- and four-word k-mers, automatic and forced partition counts, repeated steps (reset keeps the
-    buffers), emit_replicated (every rank ends with the whole graph: what the multi-GPU CLI's rank 0 writes)"""
+    buffers), emit_replicated (every rank ends with the whole graph: what the multi-GPU CLI's rank 0 writes),
+    -all-abundance-counts across the ranks"""
     _launch(2, [(31, 2, 300, 150, 3, {"steps": 2}), (31, 1, 150, 150, 3, {"log2_partitions": 6}),
                 (55, 2, 200, 150, 4, {"log2_partitions": 5}), (127, 1, 40, 600, 5, {"log2_partitions": 4}),
-                (31, 2, 200, 150, 3, {"emit_replicated": True})], 29500, 600)
+                (31, 2, 200, 150, 3, {"emit_replicated": True}),
+                (31, 2, 250, 150, 3, {"all_abundance_counts": True}), (55, 1, 100, 150, 4, {"all_abundance_counts": True, "emit_replicated": True})], 29500, 600)
 
 
 def test_four_rank_gloo():

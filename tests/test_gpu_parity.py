@@ -152,7 +152,8 @@ def test_multi_gpu_path_single_rank_rccl(oracle, hip, monkeypatch):
 
 @pytest.mark.parametrize("world,k,amin,n_reads,read_len,cfg,kw", [
     (2, 31, 2, 300000, 150, 3, {}), (4, 31, 1, 60000, 150, 3, {"log2_partitions": 12}),
-    (2, 55, 2, 100000, 150, 4, {}), (2, 127, 2, 8000, 1000, 5, {}), (2, 31, 2, 100000, 150, 3, {"emit_replicated": True})])
+    (2, 55, 2, 100000, 150, 4, {}), (2, 127, 2, 8000, 1000, 5, {}), (2, 31, 2, 100000, 150, 3, {"emit_replicated": True}),
+    (2, 31, 2, 60000, 150, 3, {"all_abundance_counts": True})])
 def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, read_len, cfg, kw):
     """the complete N-rank data path on the real device: N contexts on GPU 0 driven by N host threads, reads sharded,
     records / pieces / junction log / partner ids moved by an in-process loop-back transport (tests/loopback.py: RCCL
@@ -171,7 +172,7 @@ def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, rea
             ep = hub.endpoint(r); ep.attach(g)
             g.push_text(("\n".join(reads[r::world]) + "\n").encode())
             g.run()
-            out[r] = (g.unitigs(), g.stats(), g.comm_bytes(), ep.error)
+            out[r] = (g.unitigs(), g.stats(), g.comm_bytes(), ep.error, g.unitig_abundances() if kw.get("all_abundance_counts") else None)
             g.close()
         except Exception as e:                   # noqa: BLE001
             out[r] = e
@@ -194,6 +195,12 @@ def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, rea
     assert sum(out[r][1]["n_distinct"] for r in range(world)) == exp["stats"]["distinct"]
     assert sum(out[r][1]["n_solid"] for r in range(world)) == exp["stats"]["solid"]
     assert all(out[r][2] > 0 for r in range(world))
+    if kw.get("all_abundance_counts"):           # -all-abundance-counts across ranks: every k-mer of every unitig carries the oracle's count
+        solid = dict(oracle.run(text, k, amin, want_solid=True)["solid"]); comp = str.maketrans("ACGT", "TGCA")
+        for r in range(world):
+            assert len(out[r][4]) == len(out[r][0])
+            for (s, kc), a in zip(out[r][0], out[r][4]):
+                assert a == [solid[min(s[i:i + k], s[i:i + k].translate(comp)[::-1])] for i in range(len(s) - k + 1)] and sum(a) == kc
 
 
 @pytest.mark.parametrize("part_cap", [None, "64"])
