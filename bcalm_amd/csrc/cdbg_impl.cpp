@@ -951,23 +951,23 @@ int glue_impl(cdbg_ctx* c) {
     uint64_t n_cycles_cut = 0;
     const uint32_t gridS = (NS + GLUE_THREADS - 1) / GLUE_THREADS;
     RankParams rp{};
-    uint4* fa_st = nullptr;                                  // final state array
+    uint4* fa_st = nullptr;                                  // final state array of the 16-byte ranking
+    const uint2* st8 = nullptr; uint4* hinfo = nullptr;      // what heads / emit read: 8-byte states, and the array for the per-head records
     bool ranked = false;
     if (NS) {
-        // usual case (no closed chains): doubling on 8-byte states, expanded once at the end.  The two 8-byte
-        // ping-pong arrays live in st_b, which heads/emit later reuse for their per-head records.
+        // usual case (no closed chains): doubling on 8-byte states, expanded once at the end.  The 8-byte
+        // state array (updated in place) lives in st_b; st_a takes the per-head records of heads / emit.
         int max_rounds8 = 2; while ((1ull << (max_rounds8 - 1)) < NS) ++max_rounds8;
-        Rank8Params r8{ NS, link_p, c->piece_n.p, reinterpret_cast<uint2*>(st_b.p), reinterpret_cast<uint2*>(st_b.p) + NS, flag.p, st_a.p };
+        Rank8Params r8{ NS, link_p, c->piece_n.p, reinterpret_cast<uint2*>(st_b.p), flag.p };
         CDBG_LAUNCH(k_rank8_init, gridS, GLUE_THREADS, s, r8);
         for (int r = 0; r < max_rounds8 && !ranked; ++r) {
             HIPCK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), s));
             CDBG_LAUNCH(k_rank8_jump, gridS, GLUE_THREADS, s, r8);
-            std::swap(r8.a, r8.b);
             HIPCK(hipStreamSynchronize(s));
             uint32_t ch = 0; CK(read_u32(flag.p, &ch));
             if (!ch) ranked = true;
         }
-        if (ranked) { CDBG_LAUNCH(k_rank8_expand, gridS, GLUE_THREADS, s, r8); fa_st = st_a.p; }
+        if (ranked) { st8 = r8.a; hinfo = st_a.p; }
     }
     if (NS && !ranked) {                                     // closed chains: the 16-byte version elects cut points
         int max_rounds = 2; while ((1ull << (max_rounds - 1)) < NS) ++max_rounds;
@@ -995,6 +995,12 @@ int glue_impl(cdbg_ctx* c) {
             uint32_t nc = 0; CK(read_u32(flag.p, &nc)); n_cycles_cut += nc;
         }
     }
+    if (NS && !st8) {                                        // (16-byte ranking: narrow its final states into the other buffer)
+        uint4* const other = (fa_st == st_a.p) ? st_b.p : st_a.p;
+        RankNarrowParams np{ NS, fa_st, reinterpret_cast<uint2*>(other) };
+        CDBG_LAUNCH(k_rank_narrow, gridS, GLUE_THREADS, s, np);
+        st8 = reinterpret_cast<const uint2*>(other); hinfo = fa_st;
+    }
     // unitig heads + emission
     const uint64_t ucap = std::max<uint64_t>(NP, 1);
     const uint64_t ocap = std::max<uint64_t>(c->n_piece_bases, 1);
@@ -1004,14 +1010,14 @@ int glue_impl(cdbg_ctx* c) {
     HIPCK(hipMemsetAsync(c->cursors.p + 2, 0, 2 * sizeof(uint64_t), s));
     if (NS) {
         HeadParams hp{};
-        hp.n_states = NS; hp.k = c->k; hp.link = link_p; hp.st = fa_st; hp.hinfo = (fa_st == st_a.p) ? st_b.p : st_a.p;
+        hp.n_states = NS; hp.k = c->k; hp.link = link_p; hp.st = st8; hp.hinfo = hinfo;
         hp.unitig_off = c->unitig_off.p; hp.unitig_len = c->unitig_len.p; hp.unitig_kc = c->unitig_kc.p;
         hp.unitig_cap = ucap; hp.out_cap = ocap; hp.n_unitigs = c->cursors.p + 2; hp.out_cursor = c->cursors.p + 3; hp.error = c->derr.p;
         hp.own_lo = 0; hp.own_hi = NS;
         if (c->prm.world_size > 1 && !c->prm.emit_replicated && c->xchg_done) { hp.own_lo = (uint32_t)(2 * c->piece_lo); hp.own_hi = (uint32_t)(2 * c->piece_hi); }
         CDBG_LAUNCH(k_unitig_heads, (NS + HEADS_PER_WG - 1) / HEADS_PER_WG, GLUE_THREADS, s, hp);
         EmitParams ep{};
-        ep.n_pieces = (uint32_t)NP; ep.k = c->k; ep.st = fa_st; ep.hinfo = hp.hinfo;
+        ep.n_pieces = (uint32_t)NP; ep.k = c->k; ep.st = st8; ep.hinfo = hp.hinfo;
         ep.piece_n = c->piece_n.p; ep.piece_kc = c->piece_kc.p; ep.piece_boff = c->piece_boff.p; ep.piece_bases = c->piece_bases.p;
         ep.unitig_kc = c->unitig_kc.p; ep.out = c->unitig_bases.p;
         ep.piece_ab = c->prm.all_abundance_counts ? c->piece_ab.p : nullptr; ep.unitig_ab = c->unitig_ab.p;

@@ -192,7 +192,7 @@ __global__ void k_rank_jump(RankParams P) {
 // smallest-piece field that elects a cut point on closed chains is not carried: if this version does not
 // converge, the caller falls back to the 16-byte version, which can cut cycles.
 constexpr uint32_t RANK_TAIL = 0x80000000u;
-struct Rank8Params { uint32_t n_states; const uint32_t* link; const uint32_t* piece_n; uint2* a; uint2* b; uint32_t* changed; uint4* out; };
+struct Rank8Params { uint32_t n_states; const uint32_t* link; const uint32_t* piece_n; uint2* a; uint32_t* changed; };
 __global__ void k_rank8_init(Rank8Params P) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.n_states) return;
@@ -200,23 +200,35 @@ __global__ void k_rank8_init(Rank8Params P) {
     uint2 v; v.x = nxt == NONE32 ? (RANK_TAIL | e) : nxt; v.y = P.piece_n[e >> 1];
     P.a[e] = v;
 }
+// IN PLACE and asynchronous: a state is one aligned 8-byte word, so whatever a jump reads -- the successor's state of
+// before or after its own update in this launch -- is a consistent {x, y} pair ("y k-mers ahead lies state x"), and
+// jumping over either keeps the invariant.  Finished states cost one streaming read per launch and no write; a launch
+// makes up to RANK8_JUMPS jumps per state (9 ping-pong rounds of 2.5 GB each before: 13.8 ms at config 3).
+#ifndef CDBG_RANK8_JUMPS
+#define CDBG_RANK8_JUMPS 5
+#endif
+constexpr int RANK8_JUMPS = CDBG_RANK8_JUMPS;
 __global__ void k_rank8_jump(Rank8Params P) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.n_states) return;
     uint2 v = P.a[e];
-    if (!(v.x & RANK_TAIL)) {
+    if (v.x & RANK_TAIL) return;
+#pragma unroll 1
+    for (int j = 0; j < RANK8_JUMPS && !(v.x & RANK_TAIL); ++j) {
         const uint2 t = P.a[v.x];
         v.y += t.y; v.x = t.x;
-        *P.changed = 1u;
     }
-    P.b[e] = v;
+    P.a[e] = v;
+    if (!(v.x & RANK_TAIL)) *P.changed = 1u;
 }
-// converged 8-byte states -> the 16-byte layout k_unitig_heads / k_emit read (y = k-mers to the tail, z = tail)
-__global__ void k_rank8_expand(Rank8Params P) {
+// k_unitig_heads / k_emit read the converged 8-byte states {RANK_TAIL | tail state, k-mers to the tail}; the 16-byte
+// version (closed chains) is narrowed to that layout once it has converged
+struct RankNarrowParams { uint32_t n_states; const uint4* st; uint2* out; };
+__global__ void k_rank_narrow(RankNarrowParams P) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.n_states) return;
-    const uint2 v = P.a[e];
-    uint4 o; o.x = NONE32; o.y = v.y; o.z = v.x & ~RANK_TAIL; o.w = 0;
+    const uint4 v = P.st[e];
+    uint2 o; o.x = RANK_TAIL | v.z; o.y = v.y;
     P.out[e] = o;
 }
 
@@ -238,7 +250,7 @@ __global__ void k_cut_cycles(CutParams P) {
 // ---- (3) unitig heads: allocate id and output space ----
 struct HeadParams {
     uint32_t n_states; int k;
-    const uint32_t* link; const uint4* st;               // st[e].y = k-mers to the tail, st[e].z = tail state
+    const uint32_t* link; const uint2* st;               // st[e] = {RANK_TAIL | tail state, k-mers to the tail}
     uint4* hinfo;                  // per state, written for head states only: {unitig id, k-mers of the unitig, output offset lo, hi}
                                    // (the spare ping-pong buffer of the ranking: one 16-byte gather for k_emit)
     uint64_t* unitig_off; uint32_t* unitig_len; uint64_t* unitig_kc;
@@ -264,8 +276,8 @@ __global__ void k_unitig_heads(HeadParams P) {
         const uint64_t e = base + (uint64_t)i * GLUE_THREADS + tid;
         len[i] = 0;
         if (e < P.n_states && P.link[e] == NONE32) {
-            const uint4 v = P.st[e];
-            if (v.y != 0 && v.z > P.st[e ^ 1u].z) {
+            const uint2 v = P.st[e];
+            if (v.y != 0 && v.x > P.st[e ^ 1u].x) {
                 if (e >= P.own_lo && e < P.own_hi) { len[i] = v.y + (uint32_t)P.k - 1u; ++cnt; sum += len[i]; }
                 else { uint4 h; h.x = NONE32; h.y = 0; h.z = 0; h.w = 0; P.hinfo[e] = h; }   // another rank's unitig: its pieces are skipped by k_emit
             }
@@ -307,7 +319,7 @@ __global__ void k_unitig_heads(HeadParams P) {
 // ---- (4) emit: one lane per piece ----
 struct EmitParams {
     uint32_t n_pieces; int k;
-    const uint4* st; const uint4* hinfo;
+    const uint2* st; const uint4* hinfo;
     const uint32_t* piece_n; const uint64_t* piece_kc; const uint64_t* piece_boff; const uint8_t* piece_bases;
     uint64_t* unitig_kc; uint8_t* out;
     const uint32_t* piece_ab; uint32_t* unitig_ab;   // optional per-k-mer abundances, indexed like the bases (k-mer ending at that base)
@@ -323,15 +335,16 @@ __global__ void k_emit(EmitParams P) {
     if (p >= P.n_pieces) return;
     const uint32_t e0 = 2 * p, e1 = 2 * p + 1;
     // direction d visits this piece in state e; its reverse visits it in e^1; chosen: larger tail
-    const uint4 s0 = P.st[e0], s1 = P.st[e1];
-    const uint32_t e = (s0.z > s1.z) ? e0 : e1;
-    const uint32_t head = ((s0.z > s1.z) ? s1.z : s0.z) ^ 1u;             // head of d = mirror of the tail of the reverse direction
+    const uint4 s01 = reinterpret_cast<const uint4*>(P.st)[p];               // both states of the piece: one 16-byte load
+    const uint32_t z0 = s01.x & ~RANK_TAIL, y0 = s01.y, z1 = s01.z & ~RANK_TAIL, y1 = s01.w;
+    const uint32_t e = (z0 > z1) ? e0 : e1;
+    const uint32_t head = ((z0 > z1) ? z1 : z0) ^ 1u;                     // head of d = mirror of the tail of the reverse direction
     const uint32_t n = P.piece_n[p];
     if (n == 0) return;                                    // reservation gap
     const uint4 h = P.hinfo[head];                          // ONE gather: unitig id, its k-mer count, its output offset
     const uint32_t uid = h.x;
     if (uid == NONE32) return;
-    const uint32_t koff = h.y - ((s0.z > s1.z) ? s0.y : s1.y);             // k-mers before this piece
+    const uint32_t koff = h.y - ((z0 > z1) ? y0 : y1);                     // k-mers before this piece
     const uint32_t nb = n + (uint32_t)P.k - 1u;
     const uint8_t* src = P.piece_bases + P.piece_boff[p];
     const uint64_t uoff = (uint64_t)h.z | ((uint64_t)h.w << 32);
