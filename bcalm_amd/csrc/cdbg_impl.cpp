@@ -170,6 +170,7 @@ struct cdbg_ctx {
     DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
     DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;   // (fallback junction table)
     DBuf<uint32_t> jfill; DBuf<uint64_t> jrecs;              // join buckets
+    bool direct_join = false; int join_log_jb = 0;           // the compaction kernels filled the join buckets themselves (no junction log)
     DBuf<uint64_t> glog_keys; DBuf<uint32_t> glog_tag; uint64_t glog_cap = 0, n_glog = 0;
     uint64_t n_pieces = 0, n_piece_bases = 0;
 
@@ -711,13 +712,27 @@ int compact_impl(cdbg_ctx* c) {
     // (the junction join works from the glue LOG; its tables are built in cdbg_glue)
     CK(c->cursors.alloc(8, false));
 
+    // Single-rank contexts: the glue records go straight into the join buckets of the glue stage (k_glue.h) instead of a
+    // sequential log that a scatter pass re-reads; contexts that exchange the log with other ranks, and the global-table
+    // join (CDBG_GLUE_TABLE), keep the log.  Observed 1.8-2.0 records per solid traveller (bound: 3): buckets sized for
+    // a mean fill of at most 96 of JB_CAP = 256 at 2.2, 131 at the bound.
+    bool direct = !(c->prm.world_size > 1 || c->force_multi) && getenv("CDBG_GLUE_TABLE") == nullptr && getenv("CDBG_GLUE_LOG") == nullptr;
+    int log_jb = 0;
+    { const uint64_t est = c->st.n_solid_travellers * 22 / 10 + 1024; while ((96ull << log_jb) < est && log_jb < 26) ++log_jb; }
+    if (const char* ev = getenv("CDBG_JOIN_LOG_JB")) log_jb = std::max(0, std::min(26, atoi(ev)));   // (tests: force the overflow fallback)
     for (int attempt = 0; attempt < 2; ++attempt) {
         // glue log: <= 2 open ends + 1 confirm per junction, one junction per solid traveller at most; the tail of a
         // chunk that the next bucket does not fit into is abandoned, hence the generous second attempt
         // (every persistent wave of tier 0 may strand one partly used chunk of each output array as well)
         const uint64_t wave_slack = std::min<uint64_t>(NPL, 256ull * 32);
         c->glog_cap = (attempt == 0 ? 3 : 8) * c->st.n_solid_travellers + (attempt + 1) * (CHUNK_SLACK_WGS * (uint64_t)GLOG_CHUNK + wave_slack * CW_GLOG_CHUNK) + 64;
-        CK(c->glog_keys.alloc(c->glog_cap * W, false)); CK(c->glog_tag.alloc(c->glog_cap, false));
+        if (direct) {
+            c->glog_cap = ~0ull >> 2;                        // (the log cursor only counts)
+            CK(c->jfill.alloc(1ull << log_jb, false)); CK(c->jrecs.alloc((JB_CAP << log_jb) * (uint64_t)(W + 1), false));
+            HIPCK(hipMemsetAsync(c->jfill.p, 0, sizeof(uint32_t) << log_jb, s));
+        } else {
+            CK(c->glog_keys.alloc(c->glog_cap * W, false)); CK(c->glog_tag.alloc(c->glog_cap, false));
+        }
         const uint64_t pslack = CHUNK_SLACK_WGS * (uint64_t)PIECE_CHUNK + wave_slack * CW_PIECE_CHUNK, bslack = CHUNK_SLACK_WGS * (uint64_t)BASES_CHUNK + wave_slack * CW_BASES_CHUNK;
         const uint64_t pcap = (attempt == 0 ? std::min<uint64_t>(S, S / 3 + 4096) + 16 : S + 16) + pslack;
         const uint64_t bcap = (attempt == 0 ? S + (pcap - pslack) * (uint64_t)(c->k - 1) + 64 : S * (uint64_t)c->k + 64) + bslack;
@@ -726,7 +741,7 @@ int compact_impl(cdbg_ctx* c) {
         CK(c->piece_bases.alloc(bcap, false));
         if (c->prm.all_abundance_counts) CK(c->piece_ab.alloc(bcap, false));
         HIPCK(hipMemsetAsync(c->cursors.p, 0, 8 * sizeof(uint64_t), s));
-        HIPCK(hipMemsetAsync(c->glog_tag.p, 0xFF, c->glog_cap * sizeof(uint32_t), s));
+        if (!direct) HIPCK(hipMemsetAsync(c->glog_tag.p, 0xFF, c->glog_cap * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->big_count.p, 0, 4 * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
@@ -739,6 +754,7 @@ int compact_impl(cdbg_ctx* c) {
         kp.piece_cap = pcap; kp.bases_cap = bcap; kp.piece_cursor = c->cursors.p; kp.bases_cursor = c->cursors.p + 1;
         kp.glue_keys = nullptr; kp.glue_a = nullptr; kp.glue_b = nullptr; kp.glue_conf = nullptr; kp.glue_mask = 0;
         kp.glog_keys = c->glog_keys.p; kp.glog_tag = c->glog_tag.p; kp.glog_cap = c->glog_cap; kp.glog_cursor = c->cursors.p + 4;
+        kp.jfill = direct ? c->jfill.p : nullptr; kp.jrecs = direct ? c->jrecs.p : nullptr; kp.log_jb = log_jb;
         kp.big_list = c->big_list.p; kp.big_count = c->big_count.p; kp.error = c->derr.p; kp.stats = c->dstats.p;
         kp.n_items = (uint32_t)NPL;
         // tier 0: one wave per bucket (k_compact_wave.h); buckets beyond its table come back on big_list
@@ -789,6 +805,7 @@ int compact_impl(cdbg_ctx* c) {
             HIPCK(hipStreamSynchronize(s));
         }
         uint32_t e = 0; CK(read_u32(c->derr.p, &e));
+        if (e == 8 && direct) { direct = false; --attempt; continue; }   // a join bucket overflowed (cannot happen with a sound hash): through the log instead
         if ((e == 3 || e == 5) && attempt == 0) continue;    // piece arrays / glue log too small: retry with the safe bounds
         if (nbig) c->st.n_big_partitions += nbig;
         break;
@@ -797,6 +814,7 @@ int compact_impl(cdbg_ctx* c) {
     CK(check_device_error(c, "compact"));
     uint64_t cur[5]; CK(read_u64(c->cursors.p, cur, 5));
     c->n_pieces = cur[0]; c->n_piece_bases = cur[1]; c->n_glog = cur[4];
+    c->direct_join = direct; c->join_log_jb = log_jb;
     uint64_t ks[4]; CK(read_u64(c->dstats.p, ks, 4));
 #ifdef CDBG_PROFILE_PHASES
     { uint64_t ph[9]; CK(read_u64(c->dstats.p + 8, ph, 9)); fprintf(stderr, "k_compact_wave phase cycles (summed over waves): between buckets %llu | load+mins %llu | classify %llu | mutual+terminals %llu | walk1(+cycles) %llu | reserve+confirms %llu | walk2+prefix bases %llu | last bases+glog %llu | reset %llu\n",
@@ -826,8 +844,12 @@ int glue_join_impl(cdbg_ctx* c, bool sharded) {
     HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
     const uint32_t world = sharded ? (uint32_t)c->prm.world_size : 1u;
     const uint64_t n_mine = c->n_glog / world + (world > 1 ? (c->n_glog >> 6) + 1024 : 0);      // records this rank joins (estimate when sharded)
-    bool bucketed = getenv("CDBG_GLUE_TABLE") == nullptr && c->n_glog > 0;
-    if (bucketed) {
+    bool bucketed = (getenv("CDBG_GLUE_TABLE") == nullptr || c->direct_join) && c->n_glog > 0;
+    if (bucketed && c->direct_join) {                        // the buckets were filled by the compaction kernels
+        const uint64_t JB = 1ull << c->join_log_jb;
+        JoinBucketParams bp{ c->jfill.p, c->jrecs.p, (uint32_t)JB, c->link.p, c->dstats.p };
+        CDBG_LAUNCH((k_join_bucket<W>), std::min<uint64_t>((JB + 3) / 4, 256 * 16), JB_THREADS, s, bp);
+    } else if (bucketed) {
         // bucketed join (k_glue.h): scatter the log into buckets of ~JB_CAP / 2 records, one wave joins a bucket in LDS
         int log_jb = 0; while (((uint64_t)(JB_CAP / 2) << log_jb) < n_mine && log_jb < 26) ++log_jb;
         const uint64_t JB = 1ull << log_jb;
@@ -1329,6 +1351,7 @@ int cdbg_exchange_sizes(cdbg_ctx* c, uint64_t out[3]) {
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->prm.all_abundance_counts) return fail(CDBG_E_PARAM, "-all-abundance-counts travels with the packed exchange only (cdbg_exchange_sizes_packed)");
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
+    if (c->direct_join) return fail(CDBG_E_STATE, "this single-rank context joined its junction records in place and keeps no log to exchange (create it with world_size > 1, or set CDBG_GLUE_LOG=1)");
     out[0] = c->n_pieces; out[1] = c->n_piece_bases; out[2] = c->n_glog;
     return CDBG_OK;
 }
@@ -1336,6 +1359,7 @@ int cdbg_exchange_export(cdbg_ctx* c, int what, void* dst_dev, uint64_t nbytes) 
     if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_export before cdbg_compact");
+    if (c->direct_join && what >= 4) return fail(CDBG_E_STATE, "this single-rank context keeps no junction log (CDBG_GLUE_LOG=1 keeps it)");
     const void* src = nullptr; uint64_t have = 0;
     switch (what) {
         case 0: src = c->piece_n.p; have = c->n_pieces * sizeof(uint32_t); break;
@@ -1389,6 +1413,7 @@ int cdbg_exchange_sizes_packed(cdbg_ctx* c, uint64_t out[4]) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
+    if (c->direct_join) return fail(CDBG_E_STATE, "this single-rank context joined its junction records in place and keeps no log to exchange (create it with world_size > 1, or set CDBG_GLUE_LOG=1)");
     hipStream_t s = c->stream;
     const uint64_t NP = c->n_pieces;
     CK(c->xp_lens.alloc(NP, false)); CK(c->xp_uoff.alloc(NP + 1, false));

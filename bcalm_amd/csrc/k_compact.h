@@ -73,12 +73,36 @@ struct CompactParams {
     uint64_t* glue_keys; uint32_t* glue_a; uint32_t* glue_b; uint32_t* glue_conf; uint32_t glue_mask;
     // glue log: (junction key, tag) records; tag = piece-end id, GTAG_CONFIRM, or GTAG_EMPTY (pre-filled)
     uint64_t* glog_keys; uint32_t* glog_tag; uint64_t glog_cap; uint64_t* glog_cursor;
+    // ... or, single-rank contexts, straight into the join buckets of the glue stage (k_glue.h): jrecs != nullptr.
+    // The compaction kernels wait on LDS most of the time; their memory pipes take the one counter atomic + one
+    // 16-byte store per record that a separate scatter pass over the log paid 11 ms for (config 3).
+    uint32_t* jfill; uint64_t* jrecs; int log_jb;
     uint32_t* big_list; uint32_t* big_count; uint32_t* error;
     uint64_t* stats;               // [0] open ends posted [1] confirms posted [2] in-bucket cycles [3] pieces written
     // HBM scratch (GLOBAL variant)
     uint64_t* g_keys; uint32_t* g_cnt; uint32_t* g_lnk; uint32_t* g_aux; const uint64_t* big_off;
     uint32_t n_items;              // buckets (or part_list entries) to process
 };
+
+// join buckets of the glue stage: <= JB_CAP records each, chosen by a hash of the junction key; a record = W key words
+// + the tag word, ONE scattered store
+constexpr uint32_t JB_CAP = 256;
+template <int W>
+CDBG_DEV void join_bucket_put(uint32_t* jfill, uint64_t* jrecs, int log_jb, uint32_t* error, const Kmer<W>& jc, uint32_t tag) {
+    const uint32_t b = log_jb ? jc.hash_lds() >> (32 - log_jb) : 0u;
+    const uint32_t pos = atomic_add_u32(&jfill[b], 1u);
+    if (pos >= JB_CAP) { *error = 8; return; }           // (the host falls back: log + global table)
+    const uint64_t o = (uint64_t)b * JB_CAP + pos;
+    if (W == 1) { uint4 r; r.x = (uint32_t)jc.w[0]; r.y = (uint32_t)(jc.w[0] >> 32); r.z = tag; r.w = 0; reinterpret_cast<uint4*>(jrecs)[o] = r; }
+    else { for (int j = 0; j < W; ++j) jrecs[o * (W + 1) + j] = jc.w[j]; jrecs[o * (W + 1) + W] = tag; }
+}
+// one glue record: into its join bucket, or at position o of the sequential log
+template <int W>
+CDBG_DEV void glue_record_put(const CompactParams& P, uint64_t o, const Kmer<W>& jc, uint32_t tag) {
+    if (P.jrecs) { join_bucket_put<W>(P.jfill, P.jrecs, P.log_jb, P.error, jc, tag); return; }
+    for (int i = 0; i < W; ++i) P.glog_keys[o * W + i] = jc.w[i];
+    P.glog_tag[o] = tag;
+}
 
 // orient stored label x so that `end` is on the right (we leave x through `end`)
 template <int W>
@@ -287,8 +311,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
             if (!(l & LNK_CONF) || (l & 3u) == LNK_OPEN) continue;   // open home ends carry their confirmation themselves
             const uint64_t o = s_lbase + atomic_add_u32(&s_lw, 1u);
             const Kmer<W> jc = canon_junction<W>(orient_out<W>(ktable_key<W>(T, s), end, k), k);
-            for (int i = 0; i < W; ++i) P.glog_keys[o * W + i] = jc.w[i];
-            P.glog_tag[o] = GTAG_CONFIRM;
+            glue_record_put<W>(P, o, jc, GTAG_CONFIRM);
         }
     }
     block_sync<GLOBAL>();
@@ -354,8 +377,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
             if (!(l & LNK_POSTED)) continue;
             const uint64_t o = s_lbase + atomic_add_u32(&s_lw, 1u);
             const Kmer<W> jc = canon_junction<W>(orient_out<W>(ktable_key<W>(T, s), end, k), k);
-            for (int i = 0; i < W; ++i) P.glog_keys[o * W + i] = jc.w[i];
-            P.glog_tag[o] = (uint32_t)(s_pbase * 2 + (l & 0x3FFFFFFFu)) | ((l & LNK_CONF) ? GTAG_CONFBIT : 0u);
+            glue_record_put<W>(P, o, jc, (uint32_t)(s_pbase * 2 + (l & 0x3FFFFFFFu)) | ((l & LNK_CONF) ? GTAG_CONFBIT : 0u));
             ++my_open;
         }
         if (my_open) atomic_add_u32(&s_stat[0], my_open);

@@ -346,8 +346,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
             if (!(l & CWL_CONF) || (l & 3u) == LNK_OPEN) continue;   // open home ends carry their confirmation themselves
             const uint64_t o = lbase + atomic_add_u32(&L.lw, 1u);
             const Kmer<W> jc = canon_junction<W>(orient_out<W>(cw_key<W, TSW>(L, it >> 1), it & 1u, k), k);
-            for (int i = 0; i < W; ++i) P.glog_keys[o * W + i] = jc.w[i];
-            P.glog_tag[o] = GTAG_CONFIRM;
+            glue_record_put<W>(P, o, jc, GTAG_CONFIRM);
         }
     }
     CDBG_WAVE_SYNC();                                    // walk 2 rewrites the link words this pass reads
@@ -402,8 +401,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
             if (!(l & CWL_POSTED)) continue;
             const uint64_t o = lbase + atomic_add_u32(&L.lw, 1u);
             const Kmer<W> jc = canon_junction<W>(orient_out<W>(cw_key<W, TSW>(L, it >> 1), it & 1u, k), k);
-            for (int i = 0; i < W; ++i) P.glog_keys[o * W + i] = jc.w[i];
-            P.glog_tag[o] = (uint32_t)(pbase * 2 + (l & 0x3FFu)) | ((l & CWL_CONF) ? GTAG_CONFBIT : 0u);
+            glue_record_put<W>(P, o, jc, (uint32_t)(pbase * 2 + (l & 0x3FFu)) | ((l & CWL_CONF) ? GTAG_CONFBIT : 0u));
         }
     }
     CDBG_WAVE_SYNC();

@@ -58,7 +58,6 @@ __global__ void k_glue_resolve(GlueResolveParams P) {
 // JOIN BUCKETS of <= JB_CAP records by a hash of the junction key (one device atomic on a bucket counter -- an
 // L2-resident array -- and one plain store per record), then ONE WAVE joins each bucket in an LDS table of 2 JB_CAP slots
 // and writes the mutual links.  The global-table kernels above remain the fallback (a bucket that overflows).
-constexpr uint32_t JB_CAP = 256;                        // records per join bucket
 constexpr int JB_THREADS = 256;                         // 4 independent waves per workgroup
 struct JoinScatterParams {
     const uint64_t* glog_keys; const uint32_t* glog_tag; uint64_t n_records; int log_jb;
@@ -74,12 +73,7 @@ __global__ void k_join_scatter(JoinScatterParams P) {
         Kmer<W> jc;
         for (int j = 0; j < W; ++j) jc.w[j] = P.glog_keys[i * W + j];
         if (P.shard_mask && (mix32(jc.hash()) & P.shard_mask) != P.shard_rank) continue;
-        const uint32_t b = P.log_jb ? jc.hash_lds() >> (32 - P.log_jb) : 0u;
-        const uint32_t pos = atomic_add_u32(&P.jfill[b], 1u);
-        if (pos >= JB_CAP) { *P.error = 8; continue; }   // (the host falls back to the global table)
-        const uint64_t o = (uint64_t)b * JB_CAP + pos;
-        if (W == 1) { uint4 r; r.x = (uint32_t)jc.w[0]; r.y = (uint32_t)(jc.w[0] >> 32); r.z = tag; r.w = 0; reinterpret_cast<uint4*>(P.jrecs)[o] = r; }
-        else { for (int j = 0; j < W; ++j) P.jrecs[o * (W + 1) + j] = jc.w[j]; P.jrecs[o * (W + 1) + W] = tag; }
+        join_bucket_put<W>(P.jfill, P.jrecs, P.log_jb, P.error, jc, tag);
     }
 }
 template <int W>

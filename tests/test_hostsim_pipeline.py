@@ -97,6 +97,25 @@ def test_capped_single_pass_scan(oracle, sim, key, part_cap, monkeypatch):
     assert_parity(oracle, sim, oracle_lib.read_input(name), k, amin, log2_partitions=4)
 
 
+@pytest.mark.parametrize("key", ["rand_a/15/2", "rand_w2/55/2", "rand_w4/127/1", "circ_test3/7/1"])
+@pytest.mark.parametrize("mode", ["log", "table", "overflow"])
+def test_glue_record_paths(oracle, sim, key, mode, monkeypatch):
+    """single-rank contexts put the glue records straight into the join buckets (the default, every other test);
+    here the other paths: the sequential log + scatter pass (what multi-rank contexts exchange), the global-table join,
+    and a join bucket that overflows during compaction (forced: ONE bucket of 256 records) -> compaction again through the log"""
+    if mode == "log":
+        monkeypatch.setenv("CDBG_GLUE_LOG", "1")
+    elif mode == "table":
+        monkeypatch.setenv("CDBG_GLUE_TABLE", "1")
+    else:
+        monkeypatch.setenv("CDBG_JOIN_LOG_JB", "0")
+    name, k, amin = _case(key)
+    text = oracle_lib.read_input(name)
+    if mode == "overflow":
+        text = text + oracle.synth_reads(400, 150, 3).decode() if isinstance(text, str) else text + oracle.synth_reads(400, 150, 3)
+    assert_parity(oracle, sim, text, k, amin, log2_partitions=5)
+
+
 @pytest.mark.parametrize("k,m", [(31, 16), (21, 6), (25, 10), (31, 10), (17, 16), (55, 16), (63, 16), (33, 15), (45, 12), (63, 8), (71, 16), (127, 16)])
 def test_scan_window_variants(oracle, sim, k, m):
     """every (k, m) shape of the register-window scan: the 15-key specialisation (k-m == 15, with and without a
