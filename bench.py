@@ -32,19 +32,27 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 PMC_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_per_kernel.csv")
 
 
+GLUE_LABEL = "glue(k_join_bucket+k_rank8_*+k_unitig_heads+k_emit)"
+
+
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (bench_micro/pmc_bench.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench;
     bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 FETCH_SIZE halving corrected as
     MI355X_MICROARCH.md section HBM prescribes).  None when the profile is absent."""
+    keys = kernel_key if isinstance(kernel_key, (list, tuple)) else [kernel_key]
+    tot, found = 0.0, False
     try:
         for line in open(PMC_TRAFFIC_CSV):
             row = line.rstrip("\n").rsplit(",", 4)          # kernel names contain commas
-            if len(row) == 5 and kernel_key in row[0]:
-                return float(row[4]) * 1e9
+            if len(row) == 5 and any(x in row[0] for x in keys):
+                tot += float(row[4]) * float(row[1]) / 2 * 1e9 if len(keys) > 1 else float(row[4]) * 1e9   # (a stage: all launches of its kernels in one of the 2 profiled steps)
+                found = True
+                if len(keys) == 1:
+                    break
     except Exception:
-        pass
-    return None
+        return None
+    return tot if found else None
 
 
 def alg_bytes(k, st, n_reads, read_len):
@@ -63,7 +71,7 @@ def alg_bytes(k, st, n_reads, read_len):
         "k_scan<emit>": A1 + A2 / 2,           # reads bases again, writes the super-k-mer records
         "k_count_fast": A2 / 2 + A3 / 2,       # reads records, writes solid (k-mer, count)   (+ k_count for multi-pass partitions)
         "k_compact_wave": A3 / 2 + A4 / 2,     # reads solid k-mers, writes pieces + glue records   (+ k_compact for big buckets)
-        "glue(k_glue_build+k_glue_resolve+k_rank_*+k_emit)": A4 / 2 + A5,
+        GLUE_LABEL: A4 / 2 + A5,
     }
     return per_kernel, A1 + A2 + A3 + A4 + A5
 
@@ -308,7 +316,7 @@ def main():
     if rank == 0:
         per_kernel, alg_total = alg_bytes(a.k, st, a.reads, a.read_len)
         ms = {"k_scan<hist>": acc["ms_scan_hist"], "k_scan<emit>": acc["ms_scan_emit"], "k_count_fast": acc["ms_count"],
-              "k_compact_wave": acc["ms_compact"], "glue(k_glue_build+k_glue_resolve+k_rank_*+k_emit)": acc["ms_glue"]}
+              "k_compact_wave": acc["ms_compact"], GLUE_LABEL: acc["ms_glue"]}
         dom = max(ms, key=lambda x: ms[x])
         dom_ms = ms[dom] / a.steps
         achieved = per_kernel[dom] / (dom_ms * 1e-3) / 1e9
@@ -336,7 +344,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic({"k_count_fast": "k_count_fast<", "k_compact_wave": "k_compact_wave<", "k_scan<emit>": "k_scan_fast<1, 2",
-                                                 "k_scan<hist>": "k_scan_fast<1, 0"}.get(dom, "k_glue_build")) if a.cfg == 3 else None,
+                                                 "k_scan<hist>": "k_scan_fast<1, 0"}.get(dom, ["k_join_bucket", "k_rank8", "k_unitig_heads", "k_emit"])) if a.cfg == 3 else None,
                          "traffic_source": "profiles/r02_pmc_hbm_traffic_per_kernel.csv (separate rocprofv3 --pmc passes of this bench at config 3)",
                          "alg_bytes_per_launch": per_kernel[dom], "avg_launch_ms": dom_ms,
                          "pipeline": {"alg_bytes": alg_total, "gpu_ms": gpu_ms,
