@@ -662,6 +662,7 @@ int count_impl(cdbg_ctx* c) {
         CountParams rp2 = cp;
         rp2.records = repair_recs.p; rp2.item_off = repair_off.p; rp2.part_list = repair_part.p; rp2.part_stride = 0;
         rp2.n_items = (uint32_t)spill_parts.size(); rp2.max_passes = 4096;
+        if (const char* ev = getenv("CDBG_REPAIR_MAX_PASSES")) rp2.max_passes = (uint32_t)std::max(1, atoi(ev));   // (tests: a spilled partition that is deferred as well)
         CDBG_LAUNCH((k_count<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(rp2.n_items, PERSISTENT_GRID), Cfg<W>::NTC, s, rp2);
     }
     uint32_t nbig = 0;

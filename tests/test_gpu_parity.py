@@ -212,6 +212,17 @@ def test_glue_record_paths_gpu(oracle, hip, mode, k, n_reads, read_len, cfg, mon
     assert_parity(oracle, hip, oracle.synth_reads(n_reads, read_len, cfg), k, 2)
 
 
+@pytest.mark.parametrize("k", [55, 127])
+def test_identical_multiword_keys_in_one_wave_gpu(oracle, hip, k):
+    """the same multi-word k-mers from every lane of a wave (2000 copies of one read, both strands) on the device: a wave has
+    no independent thread scheduling, so the W = 2 / 4 find-or-insert must publish inside the claiming iteration"""
+    rng = random.Random(k)
+    r = "".join(rng.choice("ACGT") for _ in range(2 * k + 40))
+    rc = r[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    for log_np in (0, 3):
+        assert_parity(oracle, hip, "\n".join([r, rc] * 1000) + "\n", k, 2, log2_partitions=log_np)
+
+
 @pytest.mark.parametrize("part_cap", [None, "64"])
 def test_capped_single_pass_scan_gpu(oracle, hip, part_cap, monkeypatch):
     """the large-input scan path (single pass, fixed-capacity partition regions, spill repair)"""

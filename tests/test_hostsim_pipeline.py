@@ -116,6 +116,33 @@ def test_glue_record_paths(oracle, sim, key, mode, monkeypatch):
     assert_parity(oracle, sim, text, k, amin, log2_partitions=5)
 
 
+def test_spilled_and_deferred_partition_is_reported(sim, monkeypatch):
+    """a partition that spilled out of its capped region AND is deferred out of the repair launch (more LDS passes than
+    allowed) has no region the HBM pass could read: the library must report it, not drop its k-mers"""
+    import random
+    from bcalm_amd import api
+    monkeypatch.setenv("CDBG_SCAN_MODE", "capped"); monkeypatch.setenv("CDBG_PART_CAP", "1"); monkeypatch.setenv("CDBG_REPAIR_MAX_PASSES", "1")
+    rng = random.Random(7)
+    text = "".join(rng.choice("ACGT") for _ in range(9000)) + "\n"
+    g = api.Graph(15, 1, lib=sim, log2_partitions=0)
+    g.push_text(text)
+    with pytest.raises(api.CdbgError) as e:
+        g.run()
+    assert "error 7" in str(e.value)
+    g.close()
+
+
+@pytest.mark.parametrize("k", [55, 127])
+def test_identical_multiword_keys_in_one_wave(oracle, sim, k):
+    """the same multi-word k-mers from every lane of a wave (200 copies of one read, both strands): the find-or-insert of
+    W = 2 / 4 keys must publish inside the iteration that claimed the slot"""
+    import random
+    rng = random.Random(k)
+    r = "".join(rng.choice("ACGT") for _ in range(2 * k + 40))
+    rc = r[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    assert_parity(oracle, sim, "\n".join([r, rc] * 100) + "\n", k, 2, log2_partitions=2)
+
+
 @pytest.mark.parametrize("k,m", [(31, 16), (21, 6), (25, 10), (31, 10), (17, 16), (55, 16), (63, 16), (33, 15), (45, 12), (63, 8), (71, 16), (127, 16)])
 def test_scan_window_variants(oracle, sim, k, m):
     """every (k, m) shape of the register-window scan: the 15-key specialisation (k-m == 15, with and without a
