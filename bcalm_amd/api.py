@@ -300,16 +300,18 @@ class Graph:
         k1 = self.k + 1
         return sorted((raw[i * k1:i * k1 + self.k].decode(), cnt[i]) for i in range(nw.value))
 
-    def unitigs(self):
-        """-> [(sequence, KC)] in the library's arbitrary order/orientation"""
+    def unitigs(self, first=0, count=None):
+        """-> [(sequence, KC)] of unitigs [first, first + count) (default: all) in the library's arbitrary order/orientation"""
         n, tb = C.c_uint64(), C.c_uint64()
         self._ck(self.lib.cdbg_num_unitigs(self._h, C.byref(n), C.byref(tb)))
         n, tb = n.value, tb.value
+        if count is not None or first:
+            n = max(0, min(n - first, n if count is None else count))
         if n == 0:
             return []
         seq = C.create_string_buffer(max(tb, 1))
         off = (C.c_uint64 * (n + 1))()
         kc = (C.c_uint64 * n)()
-        self._ck(self.lib.cdbg_fetch_unitigs(self._h, 0, n, seq, off, kc))
+        self._ck(self.lib.cdbg_fetch_unitigs(self._h, first, n, seq, off, kc))
         raw = seq.raw
         return [(raw[off[i]:off[i + 1]].decode(), kc[i]) for i in range(n)]

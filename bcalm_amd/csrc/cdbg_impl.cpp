@@ -1344,8 +1344,15 @@ int cdbg_fetch_unitigs(cdbg_ctx* c, uint64_t first, uint64_t n, char* seq_buf, u
         std::vector<char> arena(c->unitig_total);
         HIPCK(hipMemcpy(arena.data(), c->unitig_bases.p, c->unitig_total, hipMemcpyDeviceToHost));
         for (uint64_t i = 0; i < n; ++i) { seq_off[i] = w; memcpy(seq_buf + w, arena.data() + off[i], len[i]); w += len[i]; }
-    } else {
-        for (uint64_t i = 0; i < n; ++i) { seq_off[i] = w; HIPCK(hipMemcpy(seq_buf + w, c->unitig_bases.p + off[i], len[i], hipMemcpyDeviceToHost)); w += len[i]; }
+    } else {                                                 // a sub-range: gathered gap-free on the device, one copy back
+        for (uint64_t i = 0; i < n; ++i) { seq_off[i] = w; w += len[i]; }
+        DBuf<uint64_t> doff; DBuf<uint8_t> dense;
+        CK(doff.alloc(n, false)); CK(dense.alloc(w, false));
+        HIPCK(hipMemcpy(doff.p, seq_off, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+        GatherUnitigParams gp{ n, c->unitig_off.p + first, c->unitig_len.p + first, doff.p, c->unitig_bases.p, dense.p };
+        CDBG_LAUNCH(k_gather_unitigs, (uint32_t)((n * 64 + 255) / 256), 256, c->stream, gp);
+        HIPCK(hipStreamSynchronize(c->stream));
+        HIPCK(hipMemcpy(seq_buf, dense.p, w, hipMemcpyDeviceToHost));
     }
     seq_off[n] = w;
     return CDBG_OK;

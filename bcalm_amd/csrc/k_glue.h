@@ -374,6 +374,17 @@ __global__ void k_emit(EmitParams P) {
 #endif
 }
 
+// ---- fetch helper: unitigs [first, first + n) gathered gap-free into one buffer (one wave per unitig), so that a partial
+// cdbg_fetch_unitigs is ONE device-to-host copy instead of one per unitig ----
+struct GatherUnitigParams { uint64_t n; const uint64_t* src_off; const uint32_t* len; const uint64_t* dst_off; const uint8_t* src; uint8_t* dst; };
+__global__ void k_gather_unitigs(GatherUnitigParams P) {
+    const uint64_t u = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (u >= P.n) return;
+    const uint32_t lane = threadIdx.x & 63u, len = P.len[u];
+    const uint8_t* s = P.src + P.src_off[u]; uint8_t* d = P.dst + P.dst_off[u];
+    for (uint32_t i = lane; i < len; i += 64) d[i] = s[i];
+}
+
 // ---- fetch helpers: solid k-mers as ASCII (stage-1 parity surface); one lane per partition segment ----
 struct DecodeParams { const uint64_t* keys; const uint32_t* cnt; const uint64_t* seg_off; const uint32_t* seg_n; uint64_t n_parts;
                       int k, W; uint8_t* out_kmers; uint32_t* out_cnt; uint64_t* n_out; uint64_t cap; };

@@ -143,6 +143,18 @@ def test_identical_multiword_keys_in_one_wave(oracle, sim, k):
     assert_parity(oracle, sim, "\n".join([r, rc] * 100) + "\n", k, 2, log2_partitions=2)
 
 
+def test_partial_unitig_fetch(oracle, sim):
+    """cdbg_fetch_unitigs over sub-ranges (gathered on the device, one copy) returns the same records as the full fetch"""
+    from bcalm_amd import api
+    g = api.Graph(21, 2, lib=sim)
+    g.push_text(oracle.synth_reads(300, 150, 3)); g.run()
+    full = g.unitigs()
+    assert len(full) > 10
+    for first, count in [(0, 1), (3, 5), (len(full) - 2, 2), (1, len(full) - 1), (len(full), 0)]:
+        assert g.unitigs(first, count) == full[first:first + count]
+    g.close()
+
+
 @pytest.mark.parametrize("k,m", [(31, 16), (21, 6), (25, 10), (31, 10), (17, 16), (55, 16), (63, 16), (33, 15), (45, 12), (63, 8), (71, 16), (127, 16)])
 def test_scan_window_variants(oracle, sim, k, m):
     """every (k, m) shape of the register-window scan: the 15-key specialisation (k-m == 15, with and without a
