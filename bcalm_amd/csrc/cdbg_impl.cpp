@@ -175,6 +175,7 @@ struct cdbg_ctx {
 
     DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
     DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;   // (fallback junction table)
+    DBuf<uint32_t> retry_list2;                              // partitions that did not fit the second count tier either
     DBuf<uint32_t> jfill; DBuf<uint64_t> jrecs;              // join buckets
     bool direct_join = false; int join_log_jb = 0;           // the compaction kernels filled the join buckets themselves (no junction log)
     DBuf<uint64_t> glog_keys; DBuf<uint32_t> glog_tag; uint64_t glog_cap = 0, n_glog = 0;
@@ -652,10 +653,24 @@ int count_impl(cdbg_ctx* c) {
     uint32_t nretry = 0;
     HIPCK(hipStreamSynchronize(s));
     CK(read_u32(c->big_count.p + 1, &nretry));
+    const uint32_t* retry_ptr = c->retry_list.p;
+    if (nretry && getenv("CDBG_NO_COUNT_TIER2") == nullptr) {
+        // second tier: the same one-pass kernel with a table twice the size (one workgroup per CU) over the retry list; at the
+        // config-5 share 6 % of the partitions -- a minimizer locus of long reads -- cost 250 of 590 ms in the multi-pass kernel
+        CK(c->retry_list2.alloc(nretry, false));
+        HIPCK(hipMemsetAsync(c->big_count.p + 2, 0, sizeof(uint32_t), s));
+        CountParams c2 = cp; c2.part_list = c->retry_list.p; c2.n_items = nretry;
+        CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2 };
+        if (capped) CDBG_LAUNCH((k_count_fast<W, 2 * TS, Cfg<W>::NTC, 3>), std::min<uint64_t>(nretry, 256), Cfg<W>::NTC, s, fp2);
+        else CDBG_LAUNCH((k_count_fast<W, 2 * TS, Cfg<W>::NTC, 2>), std::min<uint64_t>(nretry, 256), Cfg<W>::NTC, s, fp2);
+        HIPCK(hipStreamSynchronize(s));
+        CK(read_u32(c->big_count.p + 2, &nretry));
+        retry_ptr = c->retry_list2.p;
+    }
     c->st.n_multipass_partitions = nretry;
     if (nretry) {
         CountParams rp1 = cp;
-        rp1.part_list = c->retry_list.p; rp1.n_items = nretry;
+        rp1.part_list = retry_ptr; rp1.n_items = nretry;
         CDBG_LAUNCH((k_count<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(nretry, PERSISTENT_GRID), Cfg<W>::NTC, s, rp1);
     }
     if (!spill_parts.empty()) {                              // spilled partitions: count their gathered copies

@@ -565,8 +565,13 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
 
 // persistent workgroups, grid-stride over partitions (HIP limits grid*block to < 2^32 work-items);
 // statistics are accumulated in registers and published with one atomic per workgroup
+// waves per SIMD to promise the register allocator: the target, or what the workgroup's LDS leaves room for (160 KB per CU)
+constexpr int lds_waves_per_simd(size_t lds_bytes, int nt, int target) {
+    const int wgs = (int)(163840 / (lds_bytes ? lds_bytes : 1)), w = wgs * (nt / 64) / 4;
+    return w < 1 ? 1 : (w < target ? w : target);
+}
 template <int W, int TS, int NT, bool GLOBAL>
-__global__ void __launch_bounds__(NT, (W == 1 && !GLOBAL) ? 6 : 4) k_count(CountParams P) {   // waves per SIMD that the LDS tables allow: 3 workgroups x 2 waves (W = 1), 4 otherwise
+__global__ void __launch_bounds__(NT, lds_waves_per_simd(GLOBAL ? 1024 : (size_t)TS * (8 * W + 4 + 1) + 1024, NT, (W == 1 && !GLOBAL) ? 6 : 4)) k_count(CountParams P) {   // waves per SIMD that the LDS tables allow: 3 workgroups x 2 waves (W = 1), 4 otherwise
     uint64_t acc[4] = {0, 0, 0, 0};
     uint32_t start_np = 1, strikes = 0; bool clean = false;
     uint64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_prev = 0;

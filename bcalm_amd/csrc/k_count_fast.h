@@ -53,30 +53,37 @@ struct CountFastLds {
 };
 
 struct CountFastParams {
-    CountParams c;                                       // part_list / item_off / g_* unused here
+    CountParams c;                                       // item_off / g_* unused here; part_list only by the LISTED tier
     uint32_t* retry_list; uint32_t* retry_count;         // partitions that need the multi-pass kernel
 };
 
 // raw words of a partition's record range as loaded: resolved one partition later, so that no load is waited for
 // in the partition that issues it (unconditional loads from a clamped index: a select on a loaded value would
 // put an s_waitcnt right behind the load).  CAPPED: fixed-capacity regions + fill counts; else exact offsets.
-template <bool CAPPED> struct CountRaw;
-template <> struct CountRaw<true> { uint32_t f; };
-template <> struct CountRaw<false> { uint64_t a, b; };
-template <bool CAPPED>
+// (CAPPED is a small bit set: bit 0 = capped layout, bit 1 = LISTED: the items are entries of P.part_list -- the second
+//  tier that takes the first tier's retry list with a table twice the size; the list entry is one more dependent load)
+template <int CAPPED> struct CountRaw;
+template <> struct CountRaw<1> { uint32_t f; };
+template <> struct CountRaw<0> { uint64_t a, b; };
+template <> struct CountRaw<3> { uint32_t f, p; };
+template <> struct CountRaw<2> { uint64_t a, b; uint32_t p; };
+template <int CAPPED>
 CDBG_DEV CountRaw<CAPPED> count_raw_load(const CountParams& P, uint32_t item) {
     const uint32_t i = item < P.n_items ? item : P.n_items - 1u;
     CountRaw<CAPPED> r;
-    if constexpr (CAPPED) r.f = P.part_fill[i];
-    else { r.a = P.part_off[i]; r.b = P.part_off[i + 1]; }
+    uint32_t p = i;
+    if constexpr (CAPPED & 2) { p = P.part_list[i]; r.p = p; }
+    if constexpr (CAPPED & 1) r.f = P.part_fill[p];
+    else { r.a = P.part_off[p]; r.b = P.part_off[p + 1]; }
     return r;
 }
 struct CountRange { uint64_t rec0; uint32_t n; uint32_t p; };      // records [rec0, rec0 + n) of partition p (n == 0: nothing to do here); wave-uniform
-template <bool CAPPED>
+template <int CAPPED>
 CDBG_DEV CountRange count_raw_resolve(const CountParams& P, uint32_t item, const CountRaw<CAPPED>& w) {
     CountRange r; r.p = item; r.rec0 = 0; r.n = 0;
     if (item >= P.n_items) return r;
-    if constexpr (CAPPED) { const uint32_t f = uni_u32(w.f); r.rec0 = (uint64_t)item * P.part_stride; r.n = f > P.part_stride ? 0u : f; }   // spilled: counted by the repair launch
+    if constexpr (CAPPED & 2) r.p = uni_u32(w.p);
+    if constexpr (CAPPED & 1) { const uint32_t f = uni_u32(w.f); r.rec0 = (uint64_t)r.p * P.part_stride; r.n = f > P.part_stride ? 0u : f; }   // spilled: counted by the repair launch
     else { const uint64_t a = uni_u64(w.a), b = uni_u64(w.b); r.rec0 = a; r.n = (uint32_t)(b - a); }
     return r;
 }
@@ -112,13 +119,13 @@ struct CountAcc { uint32_t dist, sh, st; uint64_t occ;
 // what the kernel's loop carries one partition ahead
 // The loop is unrolled twice over two register sets (ping-pong): a register COPY of a requested value would be its
 // first use and put the wait for it at the end of the partition that issued the request.
-template <int W, bool CAPPED>
+template <int W, int CAPPED>
 struct CountSet { RecView<W> R; CountRaw<CAPPED> raw; };    // R: this wave's records of a partition; raw: range words of the partition after it
-template <int W, bool CAPPED>
+template <int W, int CAPPED>
 struct CountAhead { CountSet<W, CAPPED>* cur; CountSet<W, CAPPED>* nxt; CountRange rg_nxt; uint32_t item_nxt, item_nn; bool issued; };
 // resolve the next partition's range from the words requested one partition ago, request this wave's share of its
 // records and the range words of the partition after it
-template <int W, int NW, bool CAPPED>
+template <int W, int NW, int CAPPED>
 CDBG_DEV void count_issue_ahead(const CountParams& P, CountAhead<W, CAPPED>& A, int wave, int lane) {
     A.rg_nxt = count_raw_resolve<CAPPED>(P, A.item_nxt, A.cur->raw);
     uint64_t w0, w1; count_wave_share<NW>(A.rg_nxt, wave, w0, w1);
@@ -128,7 +135,7 @@ CDBG_DEV void count_issue_ahead(const CountParams& P, CountAhead<W, CAPPED>& A, 
 }
 
 // returns false when the partition did not fit one pass (table left dirty)
-template <int W, int TS, int NT, bool CAPPED>
+template <int W, int TS, int NT, int CAPPED>
 CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>& L, const CountRange& rg, CountAhead<W, CAPPED>& A,
                                    const uint32_t par, uint64_t& chunk_base, uint32_t& chunk_left, CountAcc& acc) {
     constexpr int RW = RecFmt<W>::RW;
@@ -322,8 +329,8 @@ CDBG_NOINLINE CDBG_DEV_NOINL void count_fast_clear(CountFastLds<W, TS, NT>& L) {
 
 // persistent workgroups, grid-stride over partitions; statistics are accumulated in registers and published once
 // per wave when the kernel ends
-template <int W, int TS, int NT, bool CAPPED>
-__global__ void __launch_bounds__(NT, W == 1 ? 6 : W == 2 ? 4 : 3) k_count_fast(CountFastParams FP) {   // waves per SIMD that the LDS tables allow: 3 workgroups x 2 waves (W = 1)
+template <int W, int TS, int NT, int CAPPED>
+__global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, TS, NT>), NT, W == 1 ? 6 : W == 2 ? 4 : 3)) k_count_fast(CountFastParams FP) {   // waves per SIMD that the LDS tables allow: 3 workgroups x 2 waves (W = 1)
     CDBG_SHARED CountFastLds<W, TS, NT> L;
     const CountParams& P = FP.c;
     constexpr int NW = NT / 64;

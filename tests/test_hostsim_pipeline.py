@@ -155,6 +155,23 @@ def test_partial_unitig_fetch(oracle, sim):
     g.close()
 
 
+@pytest.mark.parametrize("k,glen", [(31, 3800), (31, 11000), (55, 1900), (55, 6000), (127, 1900), (127, 6000)])
+@pytest.mark.parametrize("mode", ["exact", "capped"])
+def test_count_tiers(oracle, sim, k, glen, mode, monkeypatch):
+    """ONE partition whose distinct k-mers overflow the one-pass LDS table: the second tier (same kernel, table twice the
+    size, over the retry list) takes the smaller case, the multi-pass kernel the larger one"""
+    import random
+    from bcalm_amd import api
+    if mode == "capped":
+        monkeypatch.setenv("CDBG_SCAN_MODE", "capped")
+    rng = random.Random(glen + k)
+    g = "".join(rng.choice("ACGT") for _ in range(glen))
+    text = g + "\n" + g[100:100 + 2 * k] + "\n"
+    got = assert_parity(oracle, sim, text, k, 1, log2_partitions=0)
+    small = glen in (3800, 1900)
+    assert got["stats"]["n_multipass_partitions"] == (0 if small else 1)
+
+
 @pytest.mark.parametrize("k,m", [(31, 16), (21, 6), (25, 10), (31, 10), (17, 16), (55, 16), (63, 16), (33, 15), (45, 12), (63, 8), (71, 16), (127, 16)])
 def test_scan_window_variants(oracle, sim, k, m):
     """every (k, m) shape of the register-window scan: the 15-key specialisation (k-m == 15, with and without a
