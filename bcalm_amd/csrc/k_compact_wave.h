@@ -424,7 +424,19 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
 // wave: queue ticket -> segment descriptor -> entries -> compaction, one bucket apart each; the entries live in two
 // register sets (ping-pong, as in k_count_fast).
 template <int W, int TSW>
-__global__ void __launch_bounds__(CW_THREADS) k_compact_wave(CompactWaveParams WP) {
+// waves per SIMD promised to the register allocator: left alone it takes 131 / 126 / 179 VGPRs (W = 1 / 2 / 4), which caps
+// the kernel at 12 / 16 / 8 waves per CU below what the LDS allows.  Measured: W = 4 with <= 168 VGPRs 163 -> 131 ms
+// (config-5 share), W = 2 with <= 96 126 -> 122 ms, W = 1 with <= 128 48.5 -> 49.2 ms (left alone)
+#ifndef CDBG_CW_WAVES1
+#define CDBG_CW_WAVES1 1
+#endif
+#ifndef CDBG_CW_WAVES2
+#define CDBG_CW_WAVES2 5
+#endif
+#ifndef CDBG_CW_WAVES4
+#define CDBG_CW_WAVES4 3
+#endif
+__global__ void __launch_bounds__(CW_THREADS, W == 1 ? CDBG_CW_WAVES1 : W == 2 ? CDBG_CW_WAVES2 : CDBG_CW_WAVES4) k_compact_wave(CompactWaveParams WP) {
     CDBG_SHARED CompactWaveLds<W, TSW> Ls[CW_THREADS / 64];
     const CompactParams& P = WP.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)uni_u32((uint32_t)tid >> 6);
