@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r02b_pmc_hbm_traffic_per_kernel.csv")
+PMC_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r02c_pmc_hbm_traffic_per_kernel.csv")
 
 
 GLUE_LABEL = "glue(k_join_bucket+k_rank8_*+k_unitig_heads+k_emit)"
@@ -345,7 +345,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic({"k_count_fast": "k_count_fast<", "k_compact_wave": "k_compact_wave<", "k_scan<emit>": "k_scan_fast<1, 2",
                                                  "k_scan<hist>": "k_scan_fast<1, 0"}.get(dom, ["k_join_bucket", "k_rank8", "k_unitig_heads", "k_emit"])) if a.cfg == 3 else None,
-                         "traffic_source": "profiles/r02b_pmc_hbm_traffic_per_kernel.csv (separate rocprofv3 --pmc passes of this bench at config 3)",
+                         "traffic_source": "profiles/r02c_pmc_hbm_traffic_per_kernel.csv (separate rocprofv3 --pmc passes of this bench at config 3)",
                          "alg_bytes_per_launch": per_kernel[dom], "avg_launch_ms": dom_ms,
                          "pipeline": {"alg_bytes": alg_total, "gpu_ms": gpu_ms,
                                       "achieved": alg_total / (gpu_ms * 1e-3) / 1e9,
