@@ -329,8 +329,13 @@ CDBG_NOINLINE CDBG_DEV_NOINL void count_fast_clear(CountFastLds<W, TS, NT>& L) {
 
 // persistent workgroups, grid-stride over partitions; statistics are accumulated in registers and published once
 // per wave when the kernel ends
+// (two-word k-mers: promised 4 waves per SIMD the kernel took 90 VGPRs and only two of the three workgroups the LDS has
+//  room for were resident; promised 6 it takes 80 and no scratch: count 218 -> 180 ms at the config-4 share)
+#ifndef CDBG_CF_WAVES2
+#define CDBG_CF_WAVES2 6
+#endif
 template <int W, int TS, int NT, int CAPPED>
-__global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, TS, NT>), NT, W == 1 ? 6 : W == 2 ? 4 : 3)) k_count_fast(CountFastParams FP) {   // waves per SIMD that the LDS tables allow: 3 workgroups x 2 waves (W = 1)
+__global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, TS, NT>), NT, W == 1 ? 6 : W == 2 ? CDBG_CF_WAVES2 : 3)) k_count_fast(CountFastParams FP) {   // waves per SIMD that the LDS tables allow: 3 workgroups x 2 waves (W = 1)
     CDBG_SHARED CountFastLds<W, TS, NT> L;
     const CountParams& P = FP.c;
     constexpr int NW = NT / 64;

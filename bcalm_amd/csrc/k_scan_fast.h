@@ -35,8 +35,13 @@ CDBG_DEV uint32_t scanf_enc4(uint32_t x, uint32_t& vbits) {
     return (t * 0x40100401u) >> 24;                                        // b0<<6 | b1<<4 | b2<<2 | b3
 }
 
+// (the generic-window variant took 222 VGPRs when left alone: two workgroups per CU where the LDS has room for five;
+//  promised 3 waves per SIMD it takes 168 and no scratch: scan 118 -> 93 ms at the config-4 share; 4 spills: 113 ms)
+#ifndef CDBG_SCAN_WAVES0
+#define CDBG_SCAN_WAVES0 3
+#endif
 template <int W, int MODE, int WNT>
-__global__ void __launch_bounds__(SCAN_THREADS) k_scan_fast(ScanParams P) {
+__global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : 1) k_scan_fast(ScanParams P) {
     constexpr int RW = RecFmt<W>::RW;
     constexpr int CAPB = RecFmt<W>::CAPB;
     CDBG_SHARED uint32_t pk[SCANF_PKW];
