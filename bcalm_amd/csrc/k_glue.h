@@ -369,9 +369,7 @@ __global__ void k_emit(EmitParams P) {
         if ((e & 1u) == END_LEFT) { for (uint32_t t = 0; t < n; ++t) da[t] = sa[t]; }
         else { for (uint32_t t = 0; t < n; ++t) da[t] = sa[n - 1 - t]; }
     }
-#ifndef CDBG_EXP_EMIT_NOKC
-    atomic_add_u64(&P.unitig_kc[uid], P.piece_kc[p]);
-#endif
+    atomic_add_u64(&P.unitig_kc[uid], P.piece_kc[p]);     // (77 M device atomics at config 3: 0.5 ms of the kernel, measured by leaving them out)
 }
 
 // ---- fetch helper: unitigs [first, first + n) gathered gap-free into one buffer (one wave per unitig), so that a partial

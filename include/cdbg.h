@@ -211,6 +211,14 @@ int cdbg_link(cdbg_ctx* ctx);
 int cdbg_num_links(cdbg_ctx* ctx, uint64_t* n);
 int cdbg_fetch_links(cdbg_ctx* ctx, uint64_t* end_off, uint32_t* link_to);
 
+/* Environment variables read by the library -- test hooks that force paths an ordinary input does not reach (tests/), not
+ * tuning knobs; results are identical with and without them:
+ *   CDBG_SCAN_MODE=capped|exact   record layout (default: by input size)     CDBG_PART_CAP=<n>         capped region size (forces spills)
+ *   CDBG_REPAIR_MAX_PASSES=<n>    LDS pass limit of the spill-repair launch   CDBG_NO_COUNT_TIER2=1     skip the second one-pass count tier
+ *   CDBG_GLUE_LOG=1               junction records through the sequential log CDBG_GLUE_TABLE=1         global-table junction join
+ *   CDBG_JOIN_LOG_JB=<n>          log2 of the join buckets (0 forces the overflow fallback)
+ *   CDBG_FORCE_MULTI=1            run the multi-GPU data path with one rank   CDBG_STAGE_BYTES, CDBG_STREAM_MIN_BYTES, CDBG_STREAM_BATCH_TILES: ingest staging sizes */
+
 #ifdef __cplusplus
 }
 #endif
