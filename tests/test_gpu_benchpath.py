@@ -182,6 +182,23 @@ def test_result_digest_on_gpu(oracle, oracle_1m, hip):
     assert d["kmers_in_unitigs"] == st["n_solid"] == exp["stats"]["solid"]
 
 
+def test_four_million_reads_against_the_multithreaded_restatement(oracle, hip):
+    """the largest oracle-checked run of the suite: 4 M x 150 bp reads (600 Mbp; the capped single-pass scan, 2^17+ partitions,
+    the bench's kernels) against oracle/cpu_mt.cpp -- the multithreaded CPU restatement that bench.py times as its baseline,
+    itself pinned to the scalar oracle in tests/test_oracle.py: distinct / solid / unitig counts, KC sum and the
+    order-independent set digest must be equal"""
+    import bcalm_amd
+    text = oracle.synth_reads(4_000_000, 150, 3)
+    cpu = oracle_lib.cpu_mt_run(text, 31, 2, os.cpu_count() or 8)
+    g = bcalm_amd.Graph(31, 2, lib=hip)
+    g.push_text(text); g.run()
+    st = g.stats(); d = g.digest(); g.close()
+    assert st["n_occurrences"] == cpu["occurrences"] == 4_000_000 * 120
+    assert (st["n_distinct"], st["n_solid"], st["n_unitigs"]) == (cpu["distinct"], cpu["solid"], cpu["unitigs"])
+    assert d["kc_sum"] == cpu["kc_sum"] and d["set_digest"] == cpu["set_digest"]
+    assert st["unitig_bases"] == cpu["unitig_bases"]
+
+
 def test_streaming_scan_while_ingesting_gpu(oracle, oracle_1m, hip, monkeypatch):
     """cdbg_expect_input on the device: the single-pass scan runs on the tiles that have landed while later chunks are
     still being pushed through the pinned staging buffers (copy stream -> event -> compute stream); 1 M reads vs the oracle"""
