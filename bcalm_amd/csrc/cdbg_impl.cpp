@@ -352,6 +352,7 @@ void launch_scan_mode(cdbg_ctx* c, ScanParams& sp, uint64_t grid) {
     const bool fast_scan = c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX;
     sp.n_tiles = grid;
     if (fast_scan && W == 1 && c->k - c->m == 15) CDBG_LAUNCH((k_scan_fast<W, MODE, W == 1 ? 15 : 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, W == 1 ? 15 : 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);
+    else if (fast_scan && W == 2 && c->k - c->m == 39) CDBG_LAUNCH((k_scan_fast<W, MODE, W == 2 ? 39 : 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, W == 2 ? 39 : 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);   // k = 55, m = 16 (config 4)
     else if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE, 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);
     else CDBG_LAUNCH((k_scan<W, MODE>), std::min<uint64_t>(grid, resident_grid(k_scan<W, MODE>, SCAN_THREADS, SCAN_GRID)), SCAN_THREADS, s, sp);
 }

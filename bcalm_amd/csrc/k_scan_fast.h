@@ -41,7 +41,7 @@ CDBG_DEV uint32_t scanf_enc4(uint32_t x, uint32_t& vbits) {
 #define CDBG_SCAN_WAVES0 3
 #endif
 template <int W, int MODE, int WNT>
-__global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : 1) k_scan_fast(ScanParams P) {
+__global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : WNT == 15 ? 1 : 4) k_scan_fast(ScanParams P) {
     constexpr int RW = RecFmt<W>::RW;
     constexpr int CAPB = RecFmt<W>::CAPB;
     CDBG_SHARED uint32_t pk[SCANF_PKW];
@@ -125,6 +125,21 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : 1)
             gq[0] = a[0]; gq[15] = a[29];
 #pragma unroll
             for (int j = 1; j < 15; ++j) gq[j] = a[j] < a[j + 14] ? a[j] : a[j + 14];
+        } else if (WNT > 0) {
+            // any other compile-time window (k = 55, m = 16: 39 keys): minima over 2, 4, ... 2^p <= WNT keys by doubling in
+            // place, then g[j] = min of the two 2^p-blocks that cover [j, j + WNT): ~ (16 + WNT) log2(WNT) min instead of 16 WNT
+            constexpr int N = 16 + WNT - 1;
+            uint32_t a[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) a[i] = kg[scanf_pad(16 * c + i)];
+            constexpr int L = WNT >= 32 ? 32 : WNT >= 16 ? 16 : WNT >= 8 ? 8 : WNT >= 4 ? 4 : WNT >= 2 ? 2 : 1;
+#pragma unroll
+            for (int len = 1; len < L; len *= 2) {
+#pragma unroll
+                for (int i = 0; i + len < N; ++i) a[i] = a[i] < a[i + len] ? a[i] : a[i + len];   // ascending i: a[i + len] is still the previous level
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) gq[j] = a[j] < a[j + WNT - L] ? a[j] : a[j + WNT - L];
         } else {
             uint32_t a[16 + SCANF_WNMAX - 1];
 #pragma unroll
