@@ -218,9 +218,37 @@ template <int W>
 CDBG_HD void kmer_junction_mins(const Kmer<W>& x, int k, int m, uint32_t& g_left, uint32_t& g_right) {
     // every m-mer and its reverse complement are bit fields of x and of rc(x): the reverse complement of the
     // m-mer at base j is the m-mer of rc(x) at base k-m-j (no per-base rolling, one rc() for the whole k-mer)
-    const Kmer<W> r = x.rc(k);
     uint32_t gl = 0xFFFFFFFFu, gr = 0xFFFFFFFFu;
     const int last = k - m;                                // m-mer starts 0 .. k-m; left junction owns 0 .. k-m-1, right 1 .. k-m
+    if (W > 1) {
+        // multi-word k-mers: two bit-field extractions per m-mer cost a select chain over the words each (a runtime word
+        // index); instead stream the bases from the top word down and roll the m-mer and its reverse complement
+        // (k steps of ~22 instructions instead of k-m+1 of ~44: half of k_compact_wave<4>'s time went here at k = 127)
+        const uint32_t mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+        const int rsh = 2 * (m - 1);
+        uint32_t fw = 0, rc = 0; int i = 0;
+#pragma unroll
+        for (int wi = W - 1; wi >= 0; --wi) {
+            int nb = (2 * k - 64 * wi) / 2; nb = nb > 32 ? 32 : nb;   // bases of the k-mer held in word wi
+            if (nb <= 0) continue;
+            uint64_t v = x.w[wi] << (64 - 2 * nb);
+            for (int t = 0; t < nb; ++t) {
+                const uint32_t b = (uint32_t)(v >> 62); v <<= 2;
+                fw = ((fw << 2) | b) & mmask;
+                rc = (rc >> 2) | ((3u - b) << rsh);
+                ++i;
+                if (i >= m) {
+                    const int j = i - m;
+                    const uint32_t key = mix32(rc < fw ? rc : fw);
+                    if (j < last) gl = key < gl ? key : gl;
+                    if (j >= 1) gr = key < gr ? key : gr;
+                }
+            }
+        }
+        g_left = gl; g_right = gr;
+        return;
+    }
+    const Kmer<W> r = x.rc(k);
     for (int j = 0; j <= last; ++j) {
         const uint32_t fw = mmer_at<W>(x, k, j, m), rc = mmer_at<W>(r, k, last - j, m);
         const uint32_t key = mix32(rc < fw ? rc : fw);
