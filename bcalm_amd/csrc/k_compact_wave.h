@@ -381,7 +381,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
         // the first k-1 bases of the piece: the start k-mer, read leaving through the far end of the start terminal
         const Kmer<W> x0 = cw_key<W, TSW>(L, s0);
         const Kmer<W> xo = ((e0 ^ 1u) == END_RIGHT) ? x0 : x0.rc(k);
-        for (int i = 0; i < k - 1; ++i) out[rel + (uint32_t)i] = (uint8_t)("ACGT"[xo.base(k, i)]);
+        kmer_prefix_ascii<W>(out + rel, xo, k, k - 1);   // (8 bases per unaligned store: 30 byte stores per piece were 2 G transactions at config 3)
     }
     CDBG_WAVE_SYNC();
     CDBG_WPH(6);
