@@ -351,9 +351,15 @@ void launch_scan_mode(cdbg_ctx* c, ScanParams& sp, uint64_t grid) {
     hipStream_t s = c->stream;
     const bool fast_scan = c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX;
     sp.n_tiles = grid;
-    if (fast_scan && W == 1 && c->k - c->m == 15) CDBG_LAUNCH((k_scan_fast<W, MODE, W == 1 ? 15 : 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, W == 1 ? 15 : 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);
-    else if (fast_scan && W == 2 && c->k - c->m == 39) CDBG_LAUNCH((k_scan_fast<W, MODE, W == 2 ? 39 : 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, W == 2 ? 39 : 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);   // k = 55, m = 16 (config 4)
-    else if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE, 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);
+    // compile-time minimizer windows (k - m): the k = 31 family m = 16 .. 12 and k = 55, m = 16 (config 4)
+#define CDBG_SCAN_WNT(WW, WNT_)                                                                                                  \
+    if (fast_scan && W == WW && c->k - c->m == WNT_) {                                                                           \
+        CDBG_LAUNCH((k_scan_fast<W, MODE, W == WW ? WNT_ : 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, W == WW ? WNT_ : 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp); \
+        return;                                                                                                                  \
+    }
+    CDBG_SCAN_WNT(1, 15) CDBG_SCAN_WNT(1, 16) CDBG_SCAN_WNT(1, 17) CDBG_SCAN_WNT(1, 18) CDBG_SCAN_WNT(1, 19) CDBG_SCAN_WNT(2, 39)
+#undef CDBG_SCAN_WNT
+    if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE, 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);
     else CDBG_LAUNCH((k_scan<W, MODE>), std::min<uint64_t>(grid, resident_grid(k_scan<W, MODE>, SCAN_THREADS, SCAN_GRID)), SCAN_THREADS, s, sp);
 }
 inline uint64_t scan_tile_bytes(const cdbg_ctx* c) { return (c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX) ? (uint64_t)SCANF_TILE : (uint64_t)SCAN_TILE; }

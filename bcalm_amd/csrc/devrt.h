@@ -6,7 +6,7 @@
 //
 // CDBG_HOSTSIM build: compiled by tests/hostsim/build.sh with g++.  Every kernel
 // body is the same source; threads of a workgroup run as cooperative fibers
-// (hostsim.h).  It exists so that `pytest -m "not gpu"` can exercise the real
+// (tests/hostsim/hostsim.h, found through the include path of tests/hostsim/build.sh).  It exists so that `pytest -m "not gpu"` can exercise the real
 // kernel logic (record packing, junction rules, chain walks, glue, ranking) in a
 // container without a GPU.  It is test infrastructure and is never loaded by
 // bcalm_amd/.

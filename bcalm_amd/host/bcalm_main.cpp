@@ -95,7 +95,10 @@ void parse_file(const std::string& path, ChunkQueue& out, size_t chunk_bytes, ui
     gzbuffer(f, 1 << 20);
     std::vector<char> line(1 << 22);
     std::string chunk; chunk.reserve(chunk_bytes + (1 << 20));
-    int fmt = 0, fq_line = 0;                   // fmt: 0 unknown, 1 FASTA, 2 FASTQ
+    int fmt = 0;                                // 0 unknown, 1 FASTA, 2 FASTQ
+    // FASTQ records may wrap their sequence and quality over several lines (README.md:45-50 accepts any FASTQ): after the
+    // '@' header the sequence runs until the '+' line, the quality until it is as long as the sequence
+    int fq_state = 0; char fq_kind = 0; uint64_t fq_seq = 0, fq_qual = 0;   // state: 0 header expected, 1 sequence, 2 quality
     bool partial = false;                       // previous gzgets returned an unterminated piece
     while (gzgets(f, line.data(), (int)line.size())) {
         size_t n = strlen(line.data());
@@ -105,8 +108,21 @@ void parse_file(const std::string& path, ChunkQueue& out, size_t chunk_bytes, ui
         partial = !complete;
         if (fmt == 0 && starts_line && n) fmt = line[0] == '@' ? 2 : 1;
         if (fmt == 2) {
-            if (starts_line) fq_line = (fq_line % 4) + 1;
-            if (fq_line == 2) { chunk.append(line.data(), n); n_bases += n; if (complete) { chunk.push_back('\n'); ++n_seq; } }
+            if (starts_line) {
+                if (fq_state == 0) {
+                    if (!n) fq_kind = 0;
+                    else if (line[0] == '@') fq_kind = 'H';
+                    else { gzclose(f); usage_error("malformed FASTQ record in " + path + " (sequence " + std::to_string(n_seq + 1) + "): '@' expected"); }
+                } else if (fq_state == 1) fq_kind = (n && line[0] == '+') ? 'P' : 'S';
+                else fq_kind = 'Q';
+            }
+            if (fq_kind == 'S') { chunk.append(line.data(), n); n_bases += n; fq_seq += n; }
+            else if (fq_kind == 'Q') fq_qual += n;
+            if (complete) {
+                if (fq_kind == 'H') { fq_state = 1; fq_seq = 0; }
+                else if (fq_kind == 'P') { chunk.push_back('\n'); ++n_seq; fq_state = 2; fq_qual = 0; }
+                else if (fq_kind == 'Q' && fq_qual >= fq_seq) fq_state = 0;
+            }
         } else {
             if (starts_line && n && line[0] == '>') { if (!chunk.empty() && chunk.back() != '\n') chunk.push_back('\n'); ++n_seq; }
             else if (!(starts_line && n && line[0] == ';')) { chunk.append(line.data(), n); n_bases += n; }

@@ -11,7 +11,8 @@ SRC = os.path.join(os.path.dirname(HERE), "bcalm_amd", "csrc")
 
 
 def load():
-    newest = max(os.path.getmtime(os.path.join(SRC, f)) for f in os.listdir(SRC))
+    newest = max([os.path.getmtime(os.path.join(SRC, f)) for f in os.listdir(SRC)] +
+                 [os.path.getmtime(os.path.join(HERE, "hostsim", f)) for f in ("hostsim.h", "build.sh")])
     if not os.path.exists(SO) or os.path.getmtime(SO) < newest:
         subprocess.check_call([os.path.join(HERE, "hostsim", "build.sh")], stdout=subprocess.DEVNULL)
     return api.load(SO)

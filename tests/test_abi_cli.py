@@ -109,6 +109,29 @@ def test_cli_contract(cli, oracle, tmp_path):
     assert sorted(fa_links) == sorted(gfa_links)
 
 
+def test_cli_wrapped_fastq(cli, oracle, tmp_path):
+    """FASTQ whose sequence and quality wrap over several lines, with quality lines that start with '@' and '+'
+    (README.md:45-50 takes any FASTQ): the result equals that of the unwrapped reads"""
+    reads = ["ACTGATGCAGATGACACTGATGCAGATGACAGTAGTGGGG", "ATGACACTGATGCAGATGACAGTAGTGGGGTTTACG", "GATTACAGATTACAGATTACACCCGT"]
+    with open(tmp_path / "w.fastq", "w") as f:
+        for i, r in enumerate(reads):
+            f.write("@read%d some text\n" % i)
+            for j in range(0, len(r), 11):
+                f.write(r[j:j + 11] + "\n")
+            f.write("+read%d\n" % i)
+            q = ("@+I" * len(r))[:len(r)]
+            for j in range(0, len(r), 7):
+                f.write(q[j:j + 7] + "\n")
+    r = subprocess.run([cli, "-in", "w.fastq", "-kmer-size", "21", "-abundance-min", "1"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    recs = _parse_fa(tmp_path / "w.unitigs.fa")
+    exp = oracle.run("\n".join(reads) + "\n", 21, 1)
+    assert oracle_lib.canonical_set(oracle, [(s, kc) for s, _, kc, _ in recs], 21) == exp["unitigs"]
+    (tmp_path / "bad.fastq").write_text("@a\nACGT\n+\nIIII\nACGT\n")
+    r = subprocess.run([cli, "-in", "bad.fastq", "-kmer-size", "3", "-abundance-min", "1"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "malformed FASTQ" in r.stdout
+
+
 def test_cli_solid_kmers_out(cli, oracle, tmp_path):
     """-solid-kmers-out (hidden option of the reference, bcalm_1.cpp:37): canonical k-mer + abundance per line"""
     inp = os.path.join(ROOT, "tests", "golden", "inputs", "minitip.fa")
