@@ -3,7 +3,7 @@
 // This is the MI355X replacement for what GraphUnitigsTemplate<span>::create() does
 // behind /root/reference/src/bcalm_1.cpp:57 (configure -> count -> bcalm -> bglue):
 // pick the k-mer width (the Integer::apply dispatch of bcalm_1.cpp:95 becomes a
-// template switch on W = 1, 2, 4), pick minimizer size / partition count from the input
+// template switch on W = 1, 2, 3, 4), pick minimizer size / partition count from the input
 // volume (the job of DSK's configuration step), then drive
 // the hand-written HIP kernels on one stream with everything resident in HBM.
 //
@@ -113,6 +113,9 @@ template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMP
 #define CDBG_TSW4 256
 #endif
 template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, TSK2 = 2 * TS_COMPACT_4, NTC = CDBG_NTC4, TSW = CDBG_TSW4; };
+// three-word k-mers (64 <= k <= 95, the span-96 entry of the reference's KSIZE_LIST, README.md:93-99): the four-word geometry
+// with 3/4 of the key bytes (count table 56 KB instead of 72)
+template <> struct Cfg<3> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, TSK2 = 2 * TS_COMPACT_4, NTC = CDBG_NTC4, TSW = CDBG_TSW4; };
 
 #ifndef CDBG_PGRID
 #define CDBG_PGRID (256 * 12)
@@ -308,7 +311,7 @@ struct Timer {
 // ---------------------------------------------------------------------------------------
 void configure(cdbg_ctx* c, uint64_t total_bytes) {
     const int W = c->W;
-    const int ts = W == 1 ? TS_COUNT_1 : W == 2 ? TS_COUNT_2 : TS_COUNT_4;
+    const int ts = W == 1 ? TS_COUNT_1 : W == 2 ? TS_COUNT_2 : TS_COUNT_4;   // (W = 3 shares the four-word geometry)
     // mean k-mer occurrences per partition: ~0.3 distinct per occurrence at sequencing depth fills the
     // LDS table to ~45 %; inputs with more distinct k-mers per occurrence take several LDS passes
 #ifndef CDBG_OCC_NUM
@@ -317,7 +320,7 @@ void configure(cdbg_ctx* c, uint64_t total_bytes) {
 #endif
     // (four-word k-mers: at k = 127 three quarters of the k-mers of reads with 1 % errors are distinct, so a partition
     //  must hold fewer occurrences for its distinct k-mers to fit the one-pass table)
-    const uint64_t target_occ = W == 4 ? (uint64_t)ts * 3 / 10 : (uint64_t)ts * CDBG_OCC_NUM / CDBG_OCC_DEN;
+    const uint64_t target_occ = W >= 3 ? (uint64_t)ts * 3 / 10 : (uint64_t)ts * CDBG_OCC_NUM / CDBG_OCC_DEN;
     int log_np = c->log_np_override >= 0 ? c->log_np_override : c->prm.log2_partitions;
     if (log_np < 0) {
         log_np = 0;
@@ -434,7 +437,7 @@ int stream_scan_advance(cdbg_ctx* c) {
     return CDBG_OK;
 }
 int stream_scan_dispatch(cdbg_ctx* c) {
-    switch (c->W) { case 1: return stream_scan_advance<1>(c); case 2: return stream_scan_advance<2>(c); default: return stream_scan_advance<4>(c); }
+    switch (c->W) { case 1: return stream_scan_advance<1>(c); case 2: return stream_scan_advance<2>(c); case 3: return stream_scan_advance<3>(c); default: return stream_scan_advance<4>(c); }
 }
 
 template <int W>
@@ -1096,7 +1099,7 @@ int link_impl(cdbg_ctx* c) {
     const uint32_t cap = (uint32_t)pow2_at_least(4 * U + 64);
     DBuf<uint64_t> lk_keys; DBuf<uint32_t> lk_cnt, lk_ends, end_slot, deg;
     CK(lk_keys.alloc((uint64_t)cap * W, false)); CK(lk_cnt.alloc((uint64_t)cap * 2, true));
-    CK(lk_ends.alloc((uint64_t)cap * 8, false)); CK(end_slot.alloc(NE, false)); CK(deg.alloc(NE, false));
+    CK(lk_ends.alloc((uint64_t)cap * 2 * LINK_PER_FLAG, false)); CK(end_slot.alloc(NE, false)); CK(deg.alloc(NE, false));
     HIPCK(hipMemsetAsync(lk_keys.p, 0xFF, (uint64_t)cap * W * sizeof(uint64_t), s));
     CK(c->link_off.alloc(NE + 1, true));
     LinkParams lp{};
@@ -1137,7 +1140,6 @@ int cdbg_create(const cdbg_params* p, cdbg_ctx** out) {
     if (!p || !out) return fail(CDBG_E_PARAM, "null argument");
     *out = nullptr;
     if (p->k < 3 || p->k > 127) return fail(CDBG_E_PARAM, "kmer-size %d out of range (3..127)", p->k);
-    if ((p->k & 1) == 0) return fail(CDBG_E_PARAM, "kmer-size %d is even: only odd k is supported (a k-mer must differ from its reverse complement)", p->k);
     if (p->abundance_min < 1) return fail(CDBG_E_PARAM, "abundance-min must be >= 1");
     const int ws = p->world_size <= 0 ? 1 : p->world_size;
     if (ws & (ws - 1)) return fail(CDBG_E_PARAM, "world_size must be a power of two");
@@ -1151,7 +1153,9 @@ int cdbg_create(const cdbg_params* p, cdbg_ctx** out) {
     HIPCK(hipSetDevice(p->device_id));
     cdbg_ctx* c = new cdbg_ctx();
     c->prm = *p; c->prm.world_size = ws;
-    c->k = p->k; c->W = p->k <= 31 ? 1 : p->k <= 63 ? 2 : 4;
+    // words per k-mer: the reference's span rule k < 32 W (README.md:91-99, Integer::apply at src/bcalm_1.cpp:95); the top word of a
+    // multi-word key therefore always keeps its two top bits free for the slot-claim protocol (k_count.h), for even k as well
+    c->k = p->k; c->W = p->k <= 31 ? 1 : p->k <= 63 ? 2 : p->k <= 95 ? 3 : 4;
     c->rank_bits = 0; while ((1 << c->rank_bits) < ws) ++c->rank_bits;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(CDBG_E_NODEVICE, "hipStreamCreate failed"); }
     *out = c;
@@ -1224,6 +1228,7 @@ int cdbg_read_text(cdbg_ctx* c, uint64_t first_byte, uint64_t nbytes, char* out)
     switch (c->W) {                                                  \
         case 1: return fn<1>(c);                                     \
         case 2: return fn<2>(c);                                     \
+        case 3: return fn<3>(c);                                     \
         default: return fn<4>(c);                                    \
     }
 static int count_dispatch(cdbg_ctx* c) { DISPATCH_W(count_impl) }
@@ -1267,7 +1272,7 @@ int cdbg_glue_join(cdbg_ctx* c, uint64_t* n_ends) {
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_glue_join needs a compacted, not yet glued context");
     int rc;
-    switch (c->W) { case 1: rc = glue_join_impl<1>(c, true); break; case 2: rc = glue_join_impl<2>(c, true); break; default: rc = glue_join_impl<4>(c, true); }
+    switch (c->W) { case 1: rc = glue_join_impl<1>(c, true); break; case 2: rc = glue_join_impl<2>(c, true); break; case 3: rc = glue_join_impl<3>(c, true); break; default: rc = glue_join_impl<4>(c, true); }
     if (rc == CDBG_OK) *n_ends = 2 * c->n_pieces;
     return rc;
 }

@@ -158,7 +158,8 @@ CDBG_DEV int probe_succ(const KTable<W>& T, const Kmer<W>& u, int k, uint32_t& s
         Kmer<W> r = rb; r.or_word(pos >> 6, (uint64_t)(3u - c) << (pos & 63));
         const bool fwd = !(r < v);                       // v is the canonical label
         const uint32_t f = ktable_find<W>(T, fwd ? v : r);
-        if (f != NONE32) { ++n; slot = f; enter_end = fwd ? END_LEFT : END_RIGHT; }
+        // (even k: a successor that is its own reverse complement is reached by two edges, .md:41-46: never a unique successor)
+        if (f != NONE32) { n += (r == v) ? 2 : 1; slot = f; enter_end = fwd ? END_LEFT : END_RIGHT; }
     }
     return n;
 }

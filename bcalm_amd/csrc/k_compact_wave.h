@@ -98,7 +98,7 @@ CDBG_DEV int cw_probe_succ(const CompactWaveLds<W, TSW>& L, const Kmer<W>& u, in
         Kmer<W> r = rb; r.or_word(pos >> 6, (uint64_t)(3u - c) << (pos & 63));
         const bool fwd = !(r < v);
         const uint32_t f = cw_find<W, TSW>(L.keys, fwd ? v : r);
-        if (f != NONE32) { ++n; ent = L.ent[f]; enter_end = fwd ? END_LEFT : END_RIGHT; }
+        if (f != NONE32) { n += (r == v) ? 2 : 1; ent = L.ent[f]; enter_end = fwd ? END_LEFT : END_RIGHT; }   // (even k: see compact_bucket_wave)
     }
     return n;
 }
@@ -211,6 +211,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
     CDBG_WPH(1);
 
     // ---- classify: every end whose junction this bucket owns notes its unique successor end (or none) ----
+    const bool even_k = (k & 1) == 0;
     for (uint32_t it = lane; it < 2 * E; it += 64) {
         const uint32_t e = it >> 1, end = it & 1u;
         uint32_t note = CWN_FOREIGN;                     // junction owned elsewhere: glue decides
@@ -221,12 +222,14 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
             Kmer<W> vb = u; vb.push_right(k, 0);
             const Kmer<W> rb = u.rc(k).shr(2);
             const int pos = 2 * (k - 1);
-            Kmer<W> lab[4]; uint32_t hs[4]; uint64_t first[4]; bool fwd[4];
+            // (even k: a successor that is its own reverse complement is reached by TWO edges -- the rows (s,+) and (s,-) of
+            //  the overlap table, .md:41-46 -- so it counts twice and the junction is never 1-in/1-out)
+            Kmer<W> lab[4]; uint32_t hs[4]; uint64_t first[4]; bool fwd[4], pal[4];
 #pragma unroll
             for (uint32_t c = 0; c < 4; ++c) {
                 Kmer<W> v = vb; v.w[0] |= (uint64_t)c;
                 Kmer<W> r = rb; r.or_word(pos >> 6, (uint64_t)(3u - c) << (pos & 63));
-                fwd[c] = !(r < v);
+                fwd[c] = !(r < v); pal[c] = even_k && r == v;
                 lab[c] = fwd[c] ? v : r;
                 hs[c] = cw_home<W, TSW>(lab[c]);
                 first[c] = L.keys[(uint64_t)hs[c] * W + (W - 1)];
@@ -235,7 +238,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
 #pragma unroll
             for (uint32_t c = 0; c < 4; ++c) {
                 const uint32_t f = cw_find_after_first<W, TSW>(L.keys, lab[c], hs[c], first[c]);
-                if (f != NONE32) { ++nsucc; y = L.ent[f]; ye = fwd[c] ? END_LEFT : END_RIGHT; }
+                if (f != NONE32) { nsucc += pal[c] ? 2u : 1u; y = L.ent[f]; ye = fwd[c] ? END_LEFT : END_RIGHT; }
             }
             note = (nsucc == 1 && y != e) ? (y * 2 + ye) : CWN_NONE;
         }

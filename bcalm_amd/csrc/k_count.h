@@ -27,7 +27,7 @@ namespace cdbg {
 // measured 13 % faster than 64-record batches at 2 workgroups per CU.
 constexpr uint32_t COUNT_CHUNK = 32768;                // solid entries a workgroup reserves per device atomic
 constexpr uint32_t TRAV_FLAG = 0x80000000u;          // in a count word: this entry is a traveller copy
-// Multi-word keys (W > 1) are claimed through their TOP word: a k-mer or (k-1)-mer of an odd k <= 127 leaves
+// Multi-word keys (W > 1) are claimed through their TOP word: a k-mer or (k-1)-mer of k < 32 W (the span rule) leaves
 // the two top bits of that word clear, so all-ones can mean "empty" and bit 63 "claimed, lower words not written
 // yet".  One 64-bit compare-and-swap per probe, no separate state array.
 constexpr uint64_t KEY_EMPTY = ~0ULL, KEY_PENDING = 1ULL << 63;

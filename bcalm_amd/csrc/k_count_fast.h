@@ -28,8 +28,8 @@ namespace cdbg {
 
 constexpr int COUNT_CB = 16;                            // records per wave batch
 template <int W> struct CountGeom {
-    // member positions of one batch: COUNT_CB records of at most CAPB - k + 1 members, k >= 3 (W = 1), 33, 65
-    static constexpr int KMIN = W == 1 ? 3 : W == 2 ? 33 : 65;
+    // member positions of one batch: COUNT_CB records of at most CAPB - k + 1 members, k >= 3 (W = 1), 32, 64, 96
+    static constexpr int KMIN = W == 1 ? 3 : 32 * (W - 1);
     static constexpr int NMAX = RecFmt<W>::CAPB - KMIN + 1;
     static constexpr int MASKW = (COUNT_CB * NMAX + 63) / 64;
 };
@@ -96,6 +96,23 @@ CDBG_DEV void count_wave_share(const CountRange& rg, int wave, uint64_t& w0, uin
     if (w0 > end) w0 = end;
     w1 = (w0 + per_wave < end) ? w0 + per_wave : end;
 }
+// Multi-word k-mers (W > 1): a partition holds few records (tens) of very unequal size (1 .. CAPB - k + 1 members), so equal
+// RECORD shares left the last wave of a workgroup 40 % of its time at the barrier (k = 127) and every wave 31 % (k = 55).
+// There wave w takes members [M w / NW, M (w + 1) / NW) of the partition's M member k-mers in record order: it walks the
+// 64-record chunks that overlap its range and a record may be split between two waves (a wave stages it with the index of
+// its first member).  M needs the member counts of all records before the first insert: the first chunk arrives whole with
+// the prefetch, the meta words of the next COUNT_NPRE chunks ride along with it (one dword per lane each), later chunks
+// (rare) are summed in a loop.  Balancing every chunk by itself instead was measured: a partition of 68 records then costs
+// every wave a fourth, nearly empty step for the 4 records of its second chunk (k = 55: count 180 -> 205 ms).
+// One-word k-mers keep the record shares: ~48 records per wave even out by themselves, and eight waves reading all ~380
+// records would cost more than the barrier wait it removes.
+template <int W> struct CountBal { static constexpr bool ON = W > 1; };
+constexpr int COUNT_NPRE = 2;
+template <int W, int NW>
+CDBG_DEV void count_share(const CountRange& rg, int wave, uint64_t& w0, uint64_t& w1) {
+    if (CountBal<W>::ON) { w0 = rg.rec0; w1 = rg.rec0 + rg.n; }
+    else count_wave_share<NW>(rg, wave, w0, w1);
+}
 template <int W>
 CDBG_DEV void count_load_chunk(const CountParams& P, uint64_t first, uint64_t end, int lane, RecView<W>& R) {
     constexpr int RW = RecFmt<W>::RW;
@@ -106,6 +123,18 @@ CDBG_DEV void count_load_chunk(const CountParams& P, uint64_t first, uint64_t en
         for (int i = 0; i < RW; ++i) R.r[i] = P.records[(first + lane) * RW + i];
     }
 }
+// meta words (member count in the low byte) of the records of chunks 1 .. COUNT_NPRE of [first, end); 0 beyond the end
+template <int W>
+CDBG_DEV void count_load_metas(const CountParams& P, uint64_t first, uint64_t end, int lane, uint32_t (&mx)[COUNT_NPRE]) {
+    constexpr int RW = RecFmt<W>::RW;
+#pragma unroll
+    for (int j = 0; j < COUNT_NPRE; ++j) {
+        const uint64_t i = first + 64u * (uint64_t)(j + 1) + (uint64_t)lane;
+        mx[j] = 0;
+        if (i < end) mx[j] = (uint32_t)P.records[i * RW];
+    }
+}
+CDBG_DEV uint32_t wave_total_u32(uint32_t v) { return wave_readlane_u32(wave_incl_sum_u32(v), 63); }
 struct CountAcc { uint32_t dist, sh, st; uint64_t occ;
 #ifdef CDBG_PROFILE_PHASES
     uint64_t ph[8], t_prev;
@@ -120,7 +149,7 @@ struct CountAcc { uint32_t dist, sh, st; uint64_t occ;
 // The loop is unrolled twice over two register sets (ping-pong): a register COPY of a requested value would be its
 // first use and put the wait for it at the end of the partition that issued the request.
 template <int W, int CAPPED>
-struct CountSet { RecView<W> R; CountRaw<CAPPED> raw; };    // R: this wave's records of a partition; raw: range words of the partition after it
+struct CountSet { RecView<W> R; CountRaw<CAPPED> raw; uint32_t mx[COUNT_NPRE]; };   // mx: (balanced shares) meta words of the chunks after the first    // R: this wave's records of a partition; raw: range words of the partition after it
 template <int W, int CAPPED>
 struct CountAhead { CountSet<W, CAPPED>* cur; CountSet<W, CAPPED>* nxt; CountRange rg_nxt; uint32_t item_nxt, item_nn; bool issued; };
 // resolve the next partition's range from the words requested one partition ago, request this wave's share of its
@@ -128,8 +157,9 @@ struct CountAhead { CountSet<W, CAPPED>* cur; CountSet<W, CAPPED>* nxt; CountRan
 template <int W, int NW, int CAPPED>
 CDBG_DEV void count_issue_ahead(const CountParams& P, CountAhead<W, CAPPED>& A, int wave, int lane) {
     A.rg_nxt = count_raw_resolve<CAPPED>(P, A.item_nxt, A.cur->raw);
-    uint64_t w0, w1; count_wave_share<NW>(A.rg_nxt, wave, w0, w1);
+    uint64_t w0, w1; count_share<W, NW>(A.rg_nxt, wave, w0, w1);
     count_load_chunk<W>(P, w0, w1, lane, A.nxt->R);
+    if (CountBal<W>::ON) count_load_metas<W>(P, w0, w1, lane, A.nxt->mx);
     A.nxt->raw = count_raw_load<CAPPED>(P, A.item_nn);
     A.issued = true;
 }
@@ -154,27 +184,59 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
     const uint32_t RBITS = 64u * RW;                                            // bits of a record
     const uint64_t kmask1 = ~0ULL >> (64 - 2 * (k < 32 ? k : 31));             // (W == 1 only)
 
-    uint64_t w0, w1; count_wave_share<NW>(rg, wave, w0, w1);
+    uint64_t w0, w1; count_share<W, NW>(rg, wave, w0, w1);
     CDBG_FPH(0);
     uint32_t n_new = 0;                                                       // wave-uniform: keys this wave added
     RecView<W> R = A.cur->R;
-    for (uint64_t c0 = w0; c0 < w1; c0 += 64) {                               // wave-uniform
+    // balanced shares: this wave's member range [m_lo, m_hi) of the partition, and the member totals of the first chunks
+    uint64_t m_lo = 0, m_hi = 0, g0c = 0;                                     // g0c: members in the chunks before the current one
+    uint32_t tpre[COUNT_NPRE + 1] = {};
+    if (CountBal<W>::ON) {
+        tpre[0] = wave_total_u32((uint64_t)lane < w1 - w0 ? (uint32_t)R.n() : 0u);
+        uint64_t mtot = tpre[0];
+#pragma unroll
+        for (int j = 0; j < COUNT_NPRE; ++j) { tpre[j + 1] = wave_total_u32(A.cur->mx[j] & 0xFFu); mtot += tpre[j + 1]; }
+        for (uint64_t c0 = w0 + 64u * (COUNT_NPRE + 1); c0 < w1; c0 += 64) {  // (partitions of more than 192 records: rare)
+            const uint64_t i = c0 + (uint64_t)lane;
+            mtot += wave_total_u32(i < w1 ? (uint32_t)P.records[i * RW] & 0xFFu : 0u);
+        }
+        m_lo = mtot * (uint64_t)wave / (uint64_t)NW; m_hi = mtot * ((uint64_t)wave + 1u) / (uint64_t)NW;
+    }
+    uint32_t ci = 0;                                                          // chunk index
+    for (uint64_t c0 = w0; c0 < w1; c0 += 64, ++ci) {                         // wave-uniform
+        if (CountBal<W>::ON && ci <= (uint32_t)COUNT_NPRE) {                  // a chunk outside this wave's range is not even loaded
+            const uint32_t tc = ci == 0 ? tpre[0] : ci == 1 ? tpre[1] : tpre[COUNT_NPRE];
+            static_assert(COUNT_NPRE == 2, "select chain over tpre");
+            if (g0c + tc <= m_lo || g0c >= m_hi) { g0c += tc; continue; }
+        }
         if (c0 != w0) count_load_chunk<W>(P, c0, w1, lane, R);                 // (the first 64 records came prefetched)
         const int nrec = (int)((w1 - c0) < 64 ? (w1 - c0) : 64);
-        const uint32_t n = lane < nrec ? (uint32_t)R.n() : 0u;
+        const uint32_t nfull = lane < nrec ? (uint32_t)R.n() : 0u;             // members of the lane's record
+        uint32_t n = nfull, first = 0;                                        // ... of which this wave takes [first, first + n)
+        if (CountBal<W>::ON) {
+            const uint32_t gi = wave_incl_sum_u32(nfull), mc = wave_readlane_u32(gi, 63);
+            const uint64_t ge = g0c + (gi - nfull), gn = g0c + gi;            // the record's members in partition coordinates
+            const uint64_t sb = ge > m_lo ? ge : m_lo, se = gn < m_hi ? gn : m_hi;
+            n = se > sb ? (uint32_t)(se - sb) : 0u; first = (uint32_t)(sb - ge);
+            g0c += mc;
+        }
         const uint32_t incl = wave_incl_sum_u32(n);
+        // (the wave's records with members are consecutive lanes; the stage index of a record is its rank among them)
+        const int fa = CountBal<W>::ON ? (int)uni_u32((uint32_t)__builtin_ctzll(__ballot(n != 0u) | (1ULL << 63))) : 0;
         for (int lo = 0; lo < nrec; lo += COUNT_CB) {                         // batches of COUNT_CB records
             const uint32_t before = lo ? wave_readlane_u32(incl, lo - 1) : 0u;
             const uint32_t total = wave_readlane_u32(incl, lo + COUNT_CB - 1) - before;
             const uint32_t excl = incl - n - before;
+            if (CountBal<W>::ON && total == 0u && A.issued) continue;        // (uniform) none of these 16 records has members for this wave
             if (lane >= lo && lane < lo + COUNT_CB && n) {
+                const int si = lane - (fa > lo ? fa : lo);
 #pragma unroll
-                for (int i = 0; i < RW; ++i) stage[(lane - lo) * RW + i] = R.r[i];
-                rbase[lane - lo] = (uint16_t)(RBITS - 2u * (uint32_t)k + 2u * excl);
+                for (int i = 0; i < RW; ++i) stage[si * RW + i] = R.r[i];
+                rbase[si] = (uint16_t)(RBITS - 2u * (uint32_t)k - 2u * first + 2u * excl);
                 atomic_or_u64(&smask[excl >> 6], 1ULL << (excl & 63u));
                 const uint32_t meta = (uint32_t)R.r[0], last = excl + n - 1u;
-                if (meta & 0x100u) atomic_or_u64(&tmask[excl >> 6], 1ULL << (excl & 63u));
-                if (meta & 0x200u) atomic_or_u64(&tmask[last >> 6], 1ULL << (last & 63u));
+                if ((meta & 0x100u) && first == 0u) atomic_or_u64(&tmask[excl >> 6], 1ULL << (excl & 63u));
+                if ((meta & 0x200u) && first + n == nfull) atomic_or_u64(&tmask[last >> 6], 1ULL << (last & 63u));
             }
             CDBG_WAVE_SYNC();
             if (!A.issued) { CDBG_FPH(1); count_issue_ahead<W, NW, CAPPED>(P, A, wave, lane); }        // behind the wait for this partition's own records
@@ -353,7 +415,7 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, 
     CountRange rg_cur = count_raw_resolve<CAPPED>(P, blockIdx.x, count_raw_load<CAPPED>(P, blockIdx.x));
     CountSet<W, CAPPED> S0, S1;
     S0.raw = count_raw_load<CAPPED>(P, blockIdx.x + stride);
-    { uint64_t w0, w1; count_wave_share<NW>(rg_cur, wave, w0, w1); count_load_chunk<W>(P, w0, w1, lane, S0.R); }
+    { uint64_t w0, w1; count_share<W, NW>(rg_cur, wave, w0, w1); count_load_chunk<W>(P, w0, w1, lane, S0.R); if (CountBal<W>::ON) count_load_metas<W>(P, w0, w1, lane, S0.mx); }
     uint32_t par = 0, misses = 0;                        // misses: consecutive partitions that did not fit one pass
     auto one_partition = [&](CountSet<W, CAPPED>& cur, CountSet<W, CAPPED>& nxt, const uint32_t item) {
         CountAhead<W, CAPPED> A;

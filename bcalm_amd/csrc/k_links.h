@@ -20,12 +20,15 @@
 namespace cdbg {
 
 constexpr int LINK_THREADS = 256;
+// unitig ends that can share one junction key and strand flag: the four k-mers c + J, plus one more at even k, where a
+// k-mer that is its own reverse complement is a unitig of its own whose two ends both leave through J (.md:30)
+constexpr uint32_t LINK_PER_FLAG = 6;
 
 template <int W>
 struct LinkTable {
     KTable<W> t;
     uint32_t* cnt;        // [cap * 2]  ends seen per flag
-    uint32_t* ends;       // [cap * 8]  up to 4 end ids per flag
+    uint32_t* ends;       // [cap * 2 * LINK_PER_FLAG]  end ids per flag
 };
 struct LinkParams {
     uint64_t n_unitigs; int k;
@@ -59,7 +62,7 @@ __global__ void k_link_insert(LinkParams P) {
     const KTable<W> T{ P.lk_keys, P.lk_mask };
     bool nw; const uint32_t s = ktable_insert<W, true>(T, jc, nw);
     const uint32_t idx = atomic_add_u32(&P.lk_cnt[s * 2 + flag], 1u);
-    if (idx < 4) P.lk_ends[s * 8 + flag * 4 + idx] = (uint32_t)e;
+    if (idx < LINK_PER_FLAG) P.lk_ends[((uint64_t)s * 2 + flag) * LINK_PER_FLAG + idx] = (uint32_t)e;
     P.end_slot[e] = s | (flag << 31) | (pal ? (1u << 30) : 0u);
 }
 __global__ void k_link_count(LinkParams P) {
@@ -68,7 +71,7 @@ __global__ void k_link_count(LinkParams P) {
     const uint32_t v = P.end_slot[e], s = v & 0x3FFFFFFFu, flag = v >> 31, pal = (v >> 30) & 1u;
     const uint32_t other = pal ? flag : flag ^ 1u;
     const uint32_t c = P.lk_cnt[s * 2 + other];
-    P.deg[e] = c < 4 ? c : 4;
+    P.deg[e] = c < LINK_PER_FLAG ? c : LINK_PER_FLAG;
 }
 __global__ void k_link_fill(LinkParams P) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,7 +80,7 @@ __global__ void k_link_fill(LinkParams P) {
     const uint32_t other = pal ? flag : flag ^ 1u;
     const uint32_t c = P.deg[e];
     const uint64_t o = P.link_off[e];
-    for (uint32_t i = 0; i < c; ++i) P.link_to[o + i] = P.lk_ends[s * 8 + other * 4 + i];
+    for (uint32_t i = 0; i < c; ++i) P.link_to[o + i] = P.lk_ends[((uint64_t)s * 2 + other) * LINK_PER_FLAG + i];
 }
 
 

@@ -2,8 +2,8 @@
 //
 // Plays the role of gatb-core's Integer / LargeInt<N> selected by Integer::apply
 // (/root/reference/src/bcalm_1.cpp:95, KSIZE_LIST in /root/reference/README.md:91-99):
-// W 64-bit words hold a k-mer of up to 32*W-1 bases; W = 1, 2, 4 cover the
-// BASELINE configs k = 31, 55, 127.  New code, MI355X-first: plain structs of
+// W 64-bit words hold a k-mer of up to 32*W-1 bases (the reference's span rule); W = 1, 2, 3, 4 cover
+// k <= 31, 63, 95, 127 (BASELINE configs: k = 31, 55, 127).  New code, MI355X-first: plain structs of
 // uint64_t that live in VGPRs, no virtual dispatch, everything __forceinline__.
 //
 // Encoding: A=0 C=1 G=2 T=3 (numeric order == lexicographic order, the canonical

@@ -57,7 +57,7 @@ def pmc_traffic(kernel_key):
 
 def alg_bytes(k, st, n_reads, read_len):
     """SURVEY.md section 8(d) stage-interface bytes, with measured counts."""
-    W = 1 if k <= 31 else 2 if k <= 63 else 4
+    W = 1 if k <= 31 else 2 if k <= 63 else 3 if k <= 95 else 4
     Kb = 8 * W
     sbar = (k - 10 + 2) / 2.0
     n_occ, S, P, U = st["n_occurrences"], st["n_solid"], st["n_pieces"], st["n_unitigs"]

@@ -30,7 +30,7 @@ extern "C" {
 typedef struct cdbg_ctx cdbg_ctx;
 
 typedef struct cdbg_params {
-    int k;                    /* -kmer-size (README.md:17-19); odd, 3..127 */
+    int k;                    /* -kmer-size (README.md:17-19,99): any k in 3..127, even or odd */
     int abundance_min;        /* -abundance-min (README.md:21-25): keep k-mers seen >= this many times */
     int minimizer_size;       /* -minimizer-size (example/circular_unitigs_unittests/CMD:4); 0 = auto */
     int log2_partitions;      /* minimizer partitions = 1 << this; -1 = auto from the input volume */
@@ -67,7 +67,7 @@ typedef struct cdbg_stats_t {
 
 /* error codes */
 #define CDBG_OK 0
-#define CDBG_E_PARAM (-1)     /* bad parameter (even k, k out of range, ...) */
+#define CDBG_E_PARAM (-1)     /* bad parameter (k out of range, ...) */
 #define CDBG_E_NODEVICE (-2)  /* no HIP device / HIP call failed: there is NO CPU fallback */
 #define CDBG_E_NOMEM (-3)
 #define CDBG_E_STATE (-4)     /* stages called out of order */

@@ -110,14 +110,20 @@ struct orc_result {
 #define ORC_W 2
 #include "oracle_impl.h"
 #undef ORC_W
+#define ORC_W 3
+#include "oracle_impl.h"
+#undef ORC_W
 #define ORC_W 4
 #include "oracle_impl.h"
 #undef ORC_W
 
 orc_result* orc_build(const char* seq, uint64_t n, int k, int abundance_min) {
-    if (k < 3 || k > 127 || (k & 1) == 0 || abundance_min < 1) return NULL;
+    /* any k in 3..127, even or odd (README.md:99 "any k value up to the largest one"); the word count follows the
+     * reference's span rule k < 32 W (README.md:91-99) */
+    if (k < 3 || k > 127 || abundance_min < 1) return NULL;
     if (k <= 31) return build_w1(seq, n, k, abundance_min);
     if (k <= 63) return build_w2(seq, n, k, abundance_min);
+    if (k <= 95) return build_w3(seq, n, k, abundance_min);
     return build_w4(seq, n, k, abundance_min);
 }
 void orc_free(orc_result* r) {

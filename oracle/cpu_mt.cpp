@@ -74,19 +74,22 @@ struct Ref { int64_t node; int sign; };
 struct Graph {
     const Table* S; int k; km_t kmask;
     km_t oriented(int64_t x, int sign) const { const km_t u = S->keys[x]; return sign ? rc_of(u, k) : u; }
-    int out_edges(int64_t x, int sign, Ref out[4]) const {
+    int out_edges(int64_t x, int sign, Ref out[5]) const {
         const km_t u = oriented(x, sign);
         int n = 0;
         for (unsigned c = 0; c < 4; ++c) {
             const km_t v = ((u << 2) | c) & kmask, r = rc_of(v, k);
             const int vs = v <= r ? 0 : 1;
             const int64_t y = S->find(vs ? r : v);
-            if (y >= 0) { out[n].node = y; out[n].sign = vs; ++n; }
+            if (y >= 0) {
+                out[n].node = y; out[n].sign = vs; ++n;
+                if (v == r) { out[n].node = y; out[n].sign = 1; ++n; }   /* even k, palindromic neighbour: two edges (.md:7,41-46) */
+            }
         }
         return n;
     }
     Ref succ(int64_t x, int sign) const {
-        Ref none = { -1, 0 }, o[4], b[4];
+        Ref none = { -1, 0 }, o[5], b[5];
         if (out_edges(x, sign, o) != 1) return none;
         if (o[0].node == x) return none;
         if (out_edges(o[0].node, !o[0].sign, b) != 1) return none;
@@ -112,7 +115,7 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
 /* out: [0] occurrences [1] distinct [2] solid [3] unitigs [4] sum KC [5] set digest [6] total unitig bases
  * secs: [0] count [1] solid table [2] unitigs [3] total.  Returns 0, or -1 for unsupported k. */
 extern "C" int cpu_mt_run(const char* text, uint64_t n, int k, int amin, int n_threads, uint64_t out[8], double secs[4]) {
-    if (k < 3 || k > 31 || !(k & 1)) return -1;
+    if (k < 3 || k > 31) return -1;
     if (n_threads < 1) n_threads = 1;
     const km_t kmask = (~0ULL) >> (64 - 2 * k);
     const double t0 = now();

@@ -1,7 +1,7 @@
 /* oracle_impl.h -- body of the CPU oracle, instantiated once per k-mer width.
  *
  * TEST INFRASTRUCTURE ONLY (see cdbg_oracle.c header).  Included three times by
- * cdbg_oracle.c with ORC_W = 1, 2, 4 (k <= 31, 63, 127), the analogue of the
+ * cdbg_oracle.c with ORC_W = 1, 2, 3, 4 (k <= 31, 63, 95, 127), the analogue of the
  * reference's KSIZE_LIST spans (/root/reference/README.md:91-99,
  * /root/reference/src/bcalm_1.cpp:95 Integer::apply).
  *
@@ -145,17 +145,26 @@ static void FN(count_kmers)(TAB* t, const char* seq, uint64_t n, int k) {
 typedef struct { int64_t node; int sign; } FN(ref_t);   /* sign: 0 = '+', 1 = '-' ; node<0 = none */
 #define REF FN(ref_t)
 
-/* out-neighbours of (x, sign): bidirected-graphs-in-bcalm2.md:39-46 overlap table */
-static int FN(out_edges)(const TAB* s, int k, int64_t x, int sign, REF out[4]) {
+/* out-neighbours of (x, sign): bidirected-graphs-in-bcalm2.md:39-46 overlap table.
+ * Even k: a k-mer can be its own reverse complement.  Such a node y has label == rc(label), so the overlap
+ * "suffix of x = prefix of y.label" and the overlap "suffix of x = prefix of rc(y.label)" both hold: the rows
+ * (s,+) and (s,-) of the table are two distinct edges (x,y,s,+) and (x,y,s,-) (edges are 5-tuples, .md:7).  Both
+ * are listed (at most one of the four extensions can be a palindrome, hence out[5]); a node with a palindromic
+ * neighbour therefore never has a unique out-edge towards it and a palindromic k-mer is always a unitig of its own. */
+static int FN(out_edges)(const TAB* s, int k, int64_t x, int sign, REF out[5]) {
     KM u = s->keys[x];
     if (sign) u = FN(km_rc)(&u, k);
     int n = 0;
     for (unsigned c = 0; c < 4; ++c) {
         KM v = u; FN(km_push_right)(&v, k, c);
         KM r = FN(km_rc)(&v, k);
-        int vs = FN(km_cmp)(&v, &r) <= 0 ? 0 : 1;      /* label is the canonical strand */
+        int cmp = FN(km_cmp)(&v, &r);
+        int vs = cmp <= 0 ? 0 : 1;                       /* label is the canonical strand */
         int64_t y = FN(tab_find)(s, vs ? &r : &v);
-        if (y >= 0) { out[n].node = y; out[n].sign = vs; ++n; }
+        if (y >= 0) {
+            out[n].node = y; out[n].sign = vs; ++n;
+            if (cmp == 0) { out[n].node = y; out[n].sign = 1; ++n; }
+        }
     }
     return n;
 }
@@ -165,7 +174,7 @@ static int FN(out_edges)(const TAB* s, int k, int64_t x, int sign, REF out[4]) {
  * x != y (a unitig is a path: ".md:83 does not repeat vertices" -- this rules out
  * self-loops and self-mirror hairpins, .md:30). */
 static REF FN(succ)(const TAB* s, int k, int64_t x, int sign) {
-    REF none = { -1, 0 }, o[4], b[4];
+    REF none = { -1, 0 }, o[5], b[5];
     if (FN(out_edges)(s, k, x, sign, o) != 1) return none;
     if (o[0].node == x) return none;
     if (FN(out_edges)(s, k, o[0].node, !o[0].sign, b) != 1) return none;

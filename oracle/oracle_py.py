@@ -56,6 +56,8 @@ def _out_edges(solid, node: str, sign: str):
         cv = canonical(v)
         if cv in solid:
             out.append((cv, "+" if v == cv else "-"))
+            if v == revcomp(v):        # even k, palindromic neighbour: label == rc(label), so the rows (s,+) and
+                out.append((cv, "-"))  # (s,-) of the overlap table (.md:41-46) are two distinct edges (.md:7)
     return out
 
 
@@ -94,7 +96,6 @@ def canonical_unitig(s: str, k: int) -> str:
 
 def unitigs(text: str, k: int, abundance_min: int):
     """returns (sorted list of (canonical_seq, KC), stats dict)"""
-    assert k % 2 == 1, "odd k only"
     counts = count_kmers(text, k)
     solid = {x: c for x, c in counts.items() if c >= abundance_min}
     seen = set()

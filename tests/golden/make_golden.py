@@ -35,6 +35,9 @@ CASES = [
     ("minitip", 21, 1), ("minitip", 21, 2),
     ("circ_test1", 7, 1), ("circ_test2", 7, 1), ("circ_test3", 7, 1),
     ("pufferize_refs", 9, 1),
+    # even k (README.md:99 "any k value"): a k-mer may equal its reverse complement (.md:30,57)
+    ("tiny_read", 12, 1), ("minitip", 20, 1), ("minitip", 20, 2), ("circ_test1", 6, 1), ("circ_test2", 8, 1),
+    ("circ_test3", 6, 1), ("pufferize_refs", 8, 1), ("pufferize_refs", 10, 1), ("palin4", 4, 1),
 ]
 
 # SURVEY.md section 4 anchor table, transcribed by hand (seq, LN, KC); circular
@@ -49,6 +52,10 @@ ANCHORS = {
     "circ_test1/7/1": {"distinct": 9, "solid": 9, "circular": [[9, 15, 10]]},
     "circ_test3/7/1": {"distinct": 9, "solid": 9, "circular": [[9, 15, 10]]},
     "circ_test2/7/1": {"distinct": 13, "solid": 13, "unitigs": [["ACCATGATTCAGAAAAAA", 18, 12], ["AAAAAAA", 7, 3]]},
+    # even k, by hand from .md:7,41-46: CAATTG has the 4-mers CAAT, AATT, ATTG = rc(CAAT): nodes ATTG (seen twice) and AATT, which
+    # is its own reverse complement.  ATTG reaches AATT by the two distinct edges (ATTG,AATT,-,+) and (ATTG,AATT,-,-), so it has no
+    # unique out-edge and neither node extends: two unitigs.  ACGTAC: ACGT (palindrome), CGTA, GTAC (palindrome): three unitigs
+    "palin4/4/1": {"distinct": 5, "solid": 5, "unitigs": [["AATT", 4, 1], ["ATTG", 4, 2], ["ACGT", 4, 1], ["CGTA", 4, 1], ["GTAC", 4, 1]]},
     "pufferize_refs/9/1": {"distinct": 70, "solid": 70, "unitigs_partial": [["AATTGGTCT", 9, 2], ["ATTGGTCTGGTTGGATTGTACTCATGATG", 29, 21]],
                            "n_unitigs": 3, "other": [[56, 49]]},
 }
@@ -72,6 +79,37 @@ def random_genome_case(seed, glen, nreads, rlen, err, k, amin):
         if rng.random() < 0.02:
             p = rng.randrange(rlen); r = r[:p] + "N" + r[p + 1:]
         reads.append(r)
+    return "\n".join(reads) + "\n"
+
+def palindrome_case(seed, glen, nreads, rlen, err, k, amin):
+    """even k: random genome with planted k-mers that equal their reverse complement (w + rc(w)), alone, back to back,
+    inside a repeat and at read ends; optional substitutions"""
+    rng = random.Random(seed)
+    g = [rng.choice("ACGT") for _ in range(glen)]
+    pals = []
+    for i in range(8):
+        w = "".join(rng.choice("ACGT") for _ in range(k // 2))
+        pals.append(w + op.revcomp(w))
+    pos = sorted(rng.sample(range(k, glen - 3 * k), 10))
+    for i, p in enumerate(pos):
+        q = pals[i % len(pals)] + (pals[(i + 1) % len(pals)] if i % 4 == 3 else "")
+        g[p:p + len(q)] = list(q)
+    g = "".join(g)
+    reads = []
+    for i in range(nreads):
+        if i < len(pos):                                   # a read that ends exactly on a planted palindrome
+            s = max(0, pos[i] + k - rlen)
+        else:
+            s = rng.randrange(0, len(g) - rlen + 1)
+        r = list(g[s:s + rlen])
+        for j in range(len(r)):
+            if rng.random() < err:
+                r[j] = rng.choice([c for c in "ACGT" if c != r[j]])
+        r = "".join(r)
+        if rng.random() < 0.5:
+            r = op.revcomp(r)
+        reads.append(r)
+    reads.append(pals[0])                                  # a palindromic k-mer as a read of its own
     return "\n".join(reads) + "\n"
 
 def solid_entry(text, k, amin):
@@ -107,6 +145,25 @@ def main():
         k, amin = args[5], args[6]
         u, st = op.unitigs(text, k, amin)
         golden[f"{tag}/{k}/{amin}"] = {"stats": st, "unitigs": u, "solid": solid_entry(text, k, amin)}
+    # even k with planted palindromic k-mers (W = 1, 2, 3, 4), and one odd three-word case
+    for tag, args in {"even_k4": (21, 300, 60, 30, 0.0, 4, 1),
+                      "even_k8": (22, 900, 150, 50, 0.01, 8, 1),
+                      "even_k16": (23, 1500, 300, 60, 0.01, 16, 2),
+                      "even_k32": (24, 2500, 300, 100, 0.004, 32, 2),
+                      "even_k64": (25, 3000, 200, 160, 0.003, 64, 1),
+                      "even_k96": (26, 3000, 150, 250, 0.002, 96, 1),
+                      "even_k126": (27, 3000, 120, 300, 0.002, 126, 1)}.items():
+        text = palindrome_case(*args)
+        with open(os.path.join(HERE, "inputs", tag + ".txt"), "w") as f:
+            f.write(text)
+        k, amin = args[5], args[6]
+        u, st = op.unitigs(text, k, amin)
+        golden[f"{tag}/{k}/{amin}"] = {"stats": st, "unitigs": u, "solid": solid_entry(text, k, amin)}
+    text = random_genome_case(16, 3000, 150, 250, 0.003, 77, 1)
+    with open(os.path.join(HERE, "inputs", "rand_w3.txt"), "w") as f:
+        f.write(text)
+    u, st = op.unitigs(text, 77, 1)
+    golden["rand_w3/77/1"] = {"stats": st, "unitigs": u, "solid": solid_entry(text, 77, 1)}
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(golden, f, indent=0, sort_keys=True)
     with open(os.path.join(HERE, "anchors.json"), "w") as f:

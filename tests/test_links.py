@@ -12,7 +12,9 @@ sys.path.insert(0, os.path.join(oracle_lib.ROOT, "oracle"))
 import oracle_py as op  # noqa: E402
 from bcalm_amd import api  # noqa: E402
 
-CASES = [("pufferize_refs", 9, 1), ("minitip", 21, 1), ("circ_test2", 7, 1), ("rand_a", 15, 2), ("rand_b", 31, 2), ("rand_w2", 55, 2)]
+CASES = [("pufferize_refs", 9, 1), ("minitip", 21, 1), ("circ_test2", 7, 1), ("rand_a", 15, 2), ("rand_b", 31, 2), ("rand_w2", 55, 2),
+         # even k: a k-mer that is its own reverse complement is a unitig whose two ends leave through the same junction (.md:30)
+         ("palin4", 4, 1), ("even_k8", 8, 1), ("even_k16", 16, 2), ("even_k32", 32, 2), ("even_k64", 64, 1), ("rand_w3", 77, 1)]
 
 
 def _check(lib, text, k, amin, **kw):
@@ -48,11 +50,11 @@ def test_links_sim(name, k, amin, log_np):
 def test_links_low_complexity_sim():
     import hostsim_lib
     lib = hostsim_lib.load()
-    for seed in range(4):
+    for seed in range(8):
         rng = random.Random(77 + seed)
         g = "".join(rng.choice("AT" if seed % 2 else "ACG") for _ in range(300))
         text = "\n".join(g[i:i + 60] for i in range(0, 240, 17)) + "\n"
-        _check(lib, text, rng.choice([5, 7, 9]), 1, log2_partitions=3, minimizer_size=3)
+        _check(lib, text, rng.choice([5, 7, 9] if seed < 4 else [4, 6, 8]), 1, log2_partitions=3, minimizer_size=3)
 
 
 @pytest.mark.gpu

@@ -66,10 +66,10 @@ def test_survey_anchors(oracle, key):
         assert rest == [tuple(x) for x in a["other"]]
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(12))
 def test_c_vs_python_random(oracle, seed):
     rng = random.Random(1000 + seed)
-    k = rng.choice([5, 7, 9, 11, 15, 21, 31, 33, 45, 63, 65, 99, 127])
+    k = rng.choice([5, 7, 9, 11, 15, 21, 31, 33, 45, 63, 65, 99, 127] if seed < 6 else [4, 6, 8, 12, 16, 20, 30, 32, 48, 62, 64, 66, 80, 94, 96, 126])
     glen = rng.randrange(200, 900)
     alphabet = "ACGT" if seed % 3 else "AC"          # low complexity -> cycles, palindromes, self-loops
     g = "".join(rng.choice(alphabet) for _ in range(glen))
@@ -109,9 +109,19 @@ def test_unitig_kmer_partition(oracle):
         assert sum(kc for _, kc in got["unitigs"]) == sum(c for _, c in got["solid"])
 
 
-def test_rejects_even_k(oracle):
+def test_even_k_palindromic_kmer_is_its_own_unitig(oracle):
+    """even k (README.md:99): a k-mer equal to its reverse complement is reached by two distinct edges (.md:7,41-46), so it
+    never merges: w + rc(w) in the middle of an otherwise linear read splits it into three unitigs"""
+    left, w, right = "GGATCTTAGC", "ACCTGA", "CCATTGAGTC"
+    pal = w + op.revcomp(w)                                   # 12 bases
+    read = left + pal + right
+    got = oracle.run(read + "\n", 12, 1)
+    seqs = sorted(s for s, _ in got["unitigs"])
+    assert oracle.canonical_unitig(pal, 12) in seqs
+    assert got["stats"]["unitigs"] == 3 and sorted(len(s) for s in seqs) == [12, 12 + len(left) - 1, 12 + len(right) - 1]
+    assert op.unitigs(read + "\n", 12, 1)[0] == got["unitigs"]
     with pytest.raises(ValueError):
-        oracle.run("ACGTACGTACGT\n", 8, 1)
+        oracle.run("ACGTACGTACGT\n", 128, 1)
 
 
 EVAL = os.path.join(ROOT, "oracle", "_ref", "unitigEvaluator")
@@ -146,7 +156,7 @@ def test_reference_checker_accepts_oracle_unitigs(oracle, tmp_path, key):
     assert "REPEATED" not in final
 
 
-@pytest.mark.parametrize("k,amin,n_reads,cfg,threads", [(31, 2, 4000, 3, 4), (21, 1, 2000, 2, 3), (27, 3, 3000, 3, 8)])
+@pytest.mark.parametrize("k,amin,n_reads,cfg,threads", [(31, 2, 4000, 3, 4), (21, 1, 2000, 2, 3), (27, 3, 3000, 3, 8), (30, 2, 3000, 3, 4), (8, 1, 300, 3, 3)])
 def test_cpu_mt_baseline_matches_oracle(oracle, k, amin, n_reads, cfg, threads):
     """oracle/cpu_mt.cpp (bench.py's multithreaded CPU baseline) against the oracle: counts, KC sum and the set digest"""
     from parity import set_digest
