@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -179,6 +180,7 @@ struct cdbg_ctx {
     DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
     DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;   // (fallback junction table)
     DBuf<uint32_t> retry_list2;                              // partitions that did not fit the second count tier either
+    DBuf<uint64_t> repair_recs, repair_off, rp_idx; DBuf<uint32_t> repair_part, rp_flag, rp_size, rp_fill;   // capped-scan spill repair (kept: no allocation per step)
     DBuf<uint32_t> jfill; DBuf<uint64_t> jrecs;              // join buckets
     bool direct_join = false; int join_log_jb = 0;           // the compaction kernels filled the join buckets themselves (no junction log)
     DBuf<uint64_t> glog_keys; DBuf<uint32_t> glog_tag; uint64_t glog_cap = 0, n_glog = 0;
@@ -300,6 +302,13 @@ int check_device_error(cdbg_ctx* c, const char* where) {
     HIPCK(hipGetLastError());
     return CDBG_OK;
 }
+// dev aid (CDBG_HOST_MARKS=1): wall-clock marks on stderr between the host-side phases of a stage, to find time that no
+// stage timer covers (allocations, host sorts, synchronous copies)
+struct HostMarks {
+    bool on = getenv("CDBG_HOST_MARKS") != nullptr; double t0 = now();
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+    void mark(const char* what) { if (!on) return; (void)hipDeviceSynchronize(); const double t = now(); fprintf(stderr, "[host] %-28s %8.2f ms\n", what, t - t0); t0 = t; }
+};
 struct Timer {
     hipEvent_t a{}, b{}; hipStream_t s{};
     int start(hipStream_t st) { s = st; HIPCK(hipEventCreate(&a)); HIPCK(hipEventCreate(&b)); HIPCK(hipEventRecord(a, s)); return CDBG_OK; }
@@ -461,6 +470,7 @@ int count_impl(cdbg_ctx* c) {
     const uint64_t NPL = c->n_local_parts;
     const uint64_t NPS = multi ? (NPL << c->rank_bits) : NPL;    // partition slots the scan fills: all of them when the reads are sharded
     hipStream_t s = c->stream;
+    HostMarks hm;
     Timer t_total; CK(t_total.start(s));
 
     if (!c->ss_on) {
@@ -472,6 +482,7 @@ int count_impl(cdbg_ctx* c) {
         CK(c->cursors.alloc(8, true));
     }
 
+    hm.mark("count: allocations");
     ScanParams sp{};
     scan_params_base(c, sp);
     sp.emit_all = multi ? 1u : 0u; sp.npl = (uint32_t)NPL;
@@ -492,8 +503,7 @@ int count_impl(cdbg_ctx* c) {
     if (const char* e = getenv("CDBG_SCAN_MODE"); e && !multi) { if (!strcmp(e, "exact")) capped = false; else if (!strcmp(e, "capped")) capped = true; }
     uint64_t n_records = 0, hs[2] = {0, 0};
     uint32_t part_cap = 0; uint64_t n_spill = 0;
-    std::vector<uint32_t> spill_parts;                       // spilled partitions (sorted), capped mode
-    DBuf<uint64_t> repair_recs, repair_off; DBuf<uint32_t> repair_part;
+    uint64_t n_spilled_parts = 0;                            // partitions whose region overflowed (capped mode): counted from gathered copies
     Timer t;
     uint64_t spill_cap = 0;
     if (c->ss_on) capped = true;                             // tiles [0, ss_done) were scanned while the input was arriving
@@ -531,6 +541,7 @@ int count_impl(cdbg_ctx* c) {
             c->st.n_tiles_overlapped = done;
             CK(exscan(c->part_count.p));                     // only for the total number of records
             CK(t.stop(&c->st.ms_scan_emit));
+            hm.mark("count: sample + capped scan");
             CK(read_u64(c->part_off.p + NPL, &n_records));
             CK(read_u64(c->dstats.p, hs, 2));
             CK(read_u64(c->cursors.p + 6, &n_spill));
@@ -539,29 +550,25 @@ int count_impl(cdbg_ctx* c) {
             if (derr == 6 || n_spill > spill_cap) {          // estimate was off (very skewed input): exact layout instead
                 capped = false; HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t)));
             } else if (n_spill) {
-                // repair: gather region + spilled records of each spilled partition into one contiguous run
-                std::vector<uint32_t> sp_part(n_spill); CK(read_u32(c->spill_part.p, sp_part.data(), n_spill));
-                std::vector<uint32_t> order(n_spill);
-                for (uint64_t i = 0; i < n_spill; ++i) order[i] = (uint32_t)i;
-                std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sp_part[a] < sp_part[b] || (sp_part[a] == sp_part[b] && a < b); });
-                std::vector<uint64_t> ioff(1, 0), soff(1, 0);
-                for (uint64_t i = 0; i < n_spill;) {
-                    uint64_t j = i; while (j < n_spill && sp_part[order[j]] == sp_part[order[i]]) ++j;
-                    spill_parts.push_back(sp_part[order[i]]);
-                    ioff.push_back(ioff.back() + part_cap + (j - i)); soff.push_back(j);
-                    i = j;
-                }
-                const uint64_t nsp = spill_parts.size();
-                DBuf<uint32_t> d_order; DBuf<uint64_t> d_soff;
-                CK(repair_recs.alloc(ioff.back() * RW, false)); CK(repair_off.alloc(nsp + 1, false)); CK(repair_part.alloc(nsp, false));
-                CK(d_order.alloc(n_spill, false)); CK(d_soff.alloc(nsp + 1, false));
-                HIPCK(hipMemcpy(repair_off.p, ioff.data(), (nsp + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-                HIPCK(hipMemcpy(repair_part.p, spill_parts.data(), nsp * sizeof(uint32_t), hipMemcpyHostToDevice));
-                HIPCK(hipMemcpy(d_order.p, order.data(), n_spill * sizeof(uint32_t), hipMemcpyHostToDevice));
-                HIPCK(hipMemcpy(d_soff.p, soff.data(), (nsp + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-                RepairParams rp{ c->records.p, c->spill_recs.p, d_order.p, d_soff.p, repair_off.p, repair_part.p, part_cap, RW, repair_recs.p };
+                // repair: gather region + spilled records of each spilled partition into one contiguous run (k_count.h)
+                RepairParams rp{};
+                rp.records = c->records.p; rp.spill_recs = c->spill_recs.p; rp.spill_part = c->spill_part.p; rp.n_spill = n_spill;
+                rp.part_fill = c->part_count.p; rp.npl = NPL; rp.part_cap = part_cap; rp.RW = RW;
+                CK(c->rp_flag.alloc(NPL, false)); CK(c->rp_idx.alloc(NPL + 1, false));
+                rp.flag = c->rp_flag.p; rp.ridx = c->rp_idx.p;
+                CDBG_LAUNCH(k_repair_flag, (NPL + 255) / 256, 256, s, rp);
+                CK(exscan_u32(c, c->rp_flag.p, c->rp_idx.p, NPL));
+                CK(read_u64(c->rp_idx.p + NPL, &n_spilled_parts));
+                const uint64_t nsp = n_spilled_parts;
+                CK(c->repair_part.alloc(nsp, false)); CK(c->rp_size.alloc(nsp, false)); CK(c->repair_off.alloc(nsp + 1, false)); CK(c->rp_fill.alloc(nsp, true));
+                rp.item_part = c->repair_part.p; rp.item_size = c->rp_size.p; rp.item_off = c->repair_off.p; rp.item_fill = c->rp_fill.p;
+                CDBG_LAUNCH(k_repair_list, (NPL + 255) / 256, 256, s, rp);
+                CK(exscan_u32(c, c->rp_size.p, c->repair_off.p, nsp));
+                uint64_t total = 0; CK(read_u64(c->repair_off.p + nsp, &total));
+                CK(c->repair_recs.alloc(total * RW, false));
+                rp.out = c->repair_recs.p;
                 CDBG_LAUNCH(k_repair_gather, nsp, 256, s, rp);
-                HIPCK(hipStreamSynchronize(s));
+                CDBG_LAUNCH(k_repair_scatter, std::min<uint64_t>((n_spill + 255) / 256, 1u << 16), 256, s, rp);
             }
         }
     }
@@ -629,6 +636,7 @@ int count_impl(cdbg_ctx* c) {
     { uint64_t ph[6]; CK(read_u64(c->dstats.p + 16, ph, 6)); fprintf(stderr, "k_scan phase ticks: load %llu keys %llu winmin %llu flags %llu collect %llu emit %llu\n", (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3], (unsigned long long)ph[4], (unsigned long long)ph[5]); }
 #endif
     c->st.n_records = n_records; c->st.n_member_kmers = hs[0];
+    hm.mark("count: spill repair/exchange");
 
     // count
     // (slack: every persistent workgroup of every launch of the stage may strand one partly used chunk)
@@ -650,6 +658,7 @@ int count_impl(cdbg_ctx* c) {
     cp.solid_keys = c->solid_keys.p; cp.solid_cnt = c->solid_cnt.p; cp.solid_cap = solid_cap; cp.solid_cursor = c->solid_cursor.p;
     cp.seg_off = c->seg_off.p; cp.seg_n = c->seg_n.p; cp.stats = c->dstats.p;
     cp.big_list = c->big_list.p; cp.big_count = c->big_count.p; cp.error = c->derr.p;
+    hm.mark("count: solid buffers");
     CK(t.start(s));
     cp.n_items = (uint32_t)NPL; cp.max_passes = 64;
     // one-pass kernel over all partitions; the ones whose distinct k-mers do not fit the LDS table at once come back on
@@ -662,6 +671,7 @@ int count_impl(cdbg_ctx* c) {
     c->st.n_launch_count = NPL;
     uint32_t nretry = 0;
     HIPCK(hipStreamSynchronize(s));
+    hm.mark("count: tier 1");
     CK(read_u32(c->big_count.p + 1, &nretry));
     const uint32_t* retry_ptr = c->retry_list.p;
     if (nretry && getenv("CDBG_NO_COUNT_TIER2") == nullptr) {
@@ -683,15 +693,16 @@ int count_impl(cdbg_ctx* c) {
         rp1.part_list = retry_ptr; rp1.n_items = nretry;
         CDBG_LAUNCH((k_count<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(nretry, PERSISTENT_GRID), Cfg<W>::NTC, s, rp1);
     }
-    if (!spill_parts.empty()) {                              // spilled partitions: count their gathered copies
+    if (n_spilled_parts) {                                   // spilled partitions: count their gathered copies
         CountParams rp2 = cp;
-        rp2.records = repair_recs.p; rp2.item_off = repair_off.p; rp2.part_list = repair_part.p; rp2.part_stride = 0;
-        rp2.n_items = (uint32_t)spill_parts.size(); rp2.max_passes = 4096;
+        rp2.records = c->repair_recs.p; rp2.item_off = c->repair_off.p; rp2.part_list = c->repair_part.p; rp2.part_stride = 0;
+        rp2.n_items = (uint32_t)n_spilled_parts; rp2.max_passes = 4096;
         if (const char* ev = getenv("CDBG_REPAIR_MAX_PASSES")) rp2.max_passes = (uint32_t)std::max(1, atoi(ev));   // (tests: a spilled partition that is deferred as well)
         CDBG_LAUNCH((k_count<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(rp2.n_items, PERSISTENT_GRID), Cfg<W>::NTC, s, rp2);
     }
     uint32_t nbig = 0;
     HIPCK(hipStreamSynchronize(s));
+    hm.mark("count: tier 2 + multi-pass");
     CK(read_u32(c->big_count.p, &nbig));
     DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_cnt;
     if (nbig) {                                              // partitions whose distinct k-mers overflow LDS
@@ -718,6 +729,7 @@ int count_impl(cdbg_ctx* c) {
         c->st.n_big_partitions += nbig;
     }
     CK(t.stop(&c->st.ms_count));
+    hm.mark("count: HBM-table partitions");
     CK(check_device_error(c, "count"));
     uint64_t cs[4]; CK(read_u64(c->dstats.p, cs, 4));
 #ifdef CDBG_PROFILE_PHASES
@@ -740,6 +752,7 @@ int compact_impl(cdbg_ctx* c) {
     hipStream_t s = c->stream;
     const uint64_t NPL = c->n_local_parts;
     const uint64_t S = c->st.n_solid;
+    HostMarks hm;
     Timer t; CK(t.start(s));
     // (the junction join works from the glue LOG; its tables are built in cdbg_glue)
     CK(c->cursors.alloc(8, false));
@@ -797,6 +810,7 @@ int compact_impl(cdbg_ctx* c) {
             CDBG_LAUNCH((k_compact_wave<W, Cfg<W>::TSW>), std::min<uint64_t>((NPL + CW_THREADS / 64 - 1) / (CW_THREADS / 64), wgrid), CW_THREADS, s, wp);
             c->st.n_launch_compact = NPL;
             HIPCK(hipStreamSynchronize(s));
+            hm.mark("compact: buffers + wave tier");
             CK(read_u32(c->big_count.p, &nbig));
         }
         if (nbig) {                                          // tier 1: a workgroup per bucket, LDS table of TS slots
@@ -843,6 +857,7 @@ int compact_impl(cdbg_ctx* c) {
         break;
     }
     CK(t.stop(&c->st.ms_compact));
+    hm.mark("compact: workgroup tiers");
     CK(check_device_error(c, "compact"));
     uint64_t cur[5]; CK(read_u64(c->cursors.p, cur, 5));
     c->n_pieces = cur[0]; c->n_piece_bases = cur[1]; c->n_glog = cur[4];
@@ -994,6 +1009,7 @@ int glue_impl(cdbg_ctx* c) {
     const uint64_t NP = c->n_pieces;
     const uint32_t NS = (uint32_t)(2 * NP);
     const float ms_join = c->st.ms_glue;
+    HostMarks hm;
     Timer t; CK(t.start(s));
     DBuf<uint32_t>& flag = c->rank_flag; DBuf<uint4>& st_a = c->rank_a; DBuf<uint4>& st_b = c->rank_b;
     CK(st_a.alloc(NS, false)); CK(st_b.alloc(NS, false));
@@ -1078,6 +1094,7 @@ int glue_impl(cdbg_ctx* c) {
         CDBG_LAUNCH(k_emit, (uint32_t)((NP + GLUE_THREADS - 1) / GLUE_THREADS), GLUE_THREADS, s, ep);
     }
     float ms_fin = 0; CK(t.stop(&ms_fin));
+    hm.mark("glue: rank + heads + emit");
     c->st.ms_glue = ms_join + ms_fin;
     CK(check_device_error(c, "glue"));
     uint64_t cur[2]; CK(read_u64(c->cursors.p + 2, cur, 2));

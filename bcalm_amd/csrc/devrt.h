@@ -56,6 +56,7 @@ CDBG_DEV uint64_t ld_agent_u64(const uint64_t* p) {
 }
 CDBG_DEV uint32_t ld_volatile_u32(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 CDBG_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+CDBG_DEV uint32_t atomic_sub_u32(uint32_t* p, uint32_t v) { return atomicSub(p, v); }
 CDBG_DEV uint32_t atomic_or_u32(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 CDBG_DEV uint32_t atomic_cas_u32(uint32_t* p, uint32_t cmp, uint32_t v) { return atomicCAS(p, cmp, v); }
 CDBG_DEV uint32_t atomic_max_u32(uint32_t* p, uint32_t v) { return atomicMax(p, v); }

@@ -27,6 +27,20 @@ namespace cdbg {
 // measured 13 % faster than 64-record batches at 2 workgroups per CU.
 constexpr uint32_t COUNT_CHUNK = 32768;                // solid entries a workgroup reserves per device atomic
 constexpr uint32_t TRAV_FLAG = 0x80000000u;          // in a count word: this entry is a traveller copy
+// Abundances are 31-bit and SATURATE (gatb-core's own ceiling is its `-abundance-max` default 2147483647 [UPSTREAM-RECALL]):
+// exact below COUNT_SAT, reported as COUNT_MAX = 2^31 - 1 from there on.  The one-pass kernel (k_count_fast.h) cannot
+// reach the ceiling -- it defers every partition of 2^23 records (>= 2^31 - 2^23 member k-mers) or more to the kernels
+// of this file -- so its hot add stays a plain ds_add_u32.  Here an add that finds the count at or above COUNT_SAT takes
+// its increment back: the stored value never gets within 4096 in-flight increments of bit 31 (the traveller flag) and
+// ends at exactly min(count, COUNT_SAT) whatever the interleaving.
+constexpr uint32_t COUNT_MAX = 0x7FFFFFFFu, COUNT_SAT = COUNT_MAX - 4095u;
+constexpr uint32_t COUNT_FAST_MAX_RECORDS = 1u << 23;   // 255 members x (2^23 - 1) records < COUNT_SAT
+CDBG_DEV void count_add_sat(uint32_t* p) {
+    const uint32_t old = atomic_add_u32(p, 1u);
+    if ((old & COUNT_MAX) >= COUNT_SAT) atomic_sub_u32(p, 1u);
+}
+CDBG_HD uint32_t count_value(uint32_t word) { const uint32_t n = word & COUNT_MAX; return n >= COUNT_SAT ? COUNT_MAX : n; }   // abundance of a count word
+CDBG_HD uint32_t count_word_out(uint32_t word) { return (word & TRAV_FLAG) | count_value(word); }                            // what the solid array holds
 // Multi-word keys (W > 1) are claimed through their TOP word: a k-mer or (k-1)-mer of k < 32 W (the span rule) leaves
 // the two top bits of that word clear, so all-ones can mean "empty" and bit 63 "claimed, lower words not written
 // yet".  One 64-bit compare-and-swap per probe, no separate state array.
@@ -253,6 +267,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
     CDBG_SHARED uint32_t s_fill, s_over, s_nsolid, s_wr, s_members;
     CDBG_SHARED uint64_t s_base;
     CDBG_SHARED uint32_t s_stat[4];
+    CDBG_SHARED uint64_t s_occ;                          // home occurrences of the partition (64 bit: one k-mer may hold 2^31 - 1 of them)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t p = P.part_list ? P.part_list[item] : item;
@@ -286,6 +301,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
     for (;;) {                                                    // attempts with npass, 2 npass, ...
         if (tid == 0) { s_nsolid = 0; s_wr = 0; s_over = 0; }
         if (tid < 4) s_stat[tid] = 0;
+        if (tid == 4) s_occ = 0;
         if (!GLOBAL && npass > 1 && !have_ub) {                   // member k-mers of the partition (first byte of every record)
             if (tid == 0) s_members = 0;
             block_sync<GLOBAL>();
@@ -370,7 +386,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                                         if (!GLOBAL && fi < LIST_CAP) l_used[fi] = (uint16_t)s;
                                     }
                                     const bool trav = (t == 0 && Q.first_trav()) || (t == qn - 1 && Q.last_trav());
-                                    atomic_add_u32(&cnt[s], 1u);
+                                    count_add_sat(&cnt[s]);
                                     if (trav) atomic_or_u32(&cnt[s], TRAV_FLAG);
                                 }
                             }
@@ -387,7 +403,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     if (GLOBAL) {                                  // an HBM table's fill can exceed the solid capacity
                         uint32_t my_solid = 0;                    // (sized for members / amin): count the solid entries first
                         for (uint32_t s = tid; s < cap; s += NT)
-                            if (ktable_used<W>(T, s) && (cnt[s] & ~TRAV_FLAG) >= P.amin) ++my_solid;
+                            if (ktable_used<W>(T, s) && count_value(cnt[s]) >= P.amin) ++my_solid;
 #pragma unroll
                         for (int d = 32; d >= 1; d >>= 1) my_solid += __shfl_xor(my_solid, d);
                         if (lane == 0 && my_solid) atomic_add_u32(&s_nsolid, my_solid);
@@ -406,13 +422,13 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     }
                     block_sync<GLOBAL>();
                     const bool wr_ok = s_base != ~0ull; const uint64_t obase = wr_ok ? s_base : 0;
-                    uint32_t st_dist = 0, st_occ = 0, st_sh = 0, st_st = 0;
+                    uint32_t st_dist = 0, st_sh = 0, st_st = 0; uint64_t st_occ = 0;
                     const uint32_t nfill = s_fill;
                     const bool by_list = !GLOBAL && nfill <= LIST_CAP;
                     for (uint32_t i = tid; i < (by_list ? nfill : cap); i += NT) {
                         const uint32_t s = by_list ? (uint32_t)l_used[i] : i;
                         if (!by_list && !ktable_used<W>(T, s)) continue;
-                        const uint32_t c = cnt[s], n = c & ~TRAV_FLAG; const bool trav = c & TRAV_FLAG;
+                        const uint32_t c = count_word_out(cnt[s]), n = c & ~TRAV_FLAG; const bool trav = c & TRAV_FLAG;
                         if (!trav) { ++st_dist; st_occ += n; }
                         if (n >= P.amin) {
                             if (trav) ++st_st; else ++st_sh;
@@ -430,10 +446,11 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     clean = by_list;
                     // (full 32-bit sums: a giant partition -- one bucket for the whole input -- overflows 16-bit fields)
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) { st_dist += __shfl_xor(st_dist, d); st_occ += __shfl_xor(st_occ, d); st_sh += __shfl_xor(st_sh, d); st_st += __shfl_xor(st_st, d); }
+                    for (int d = 32; d >= 1; d >>= 1) { st_dist += __shfl_xor(st_dist, d); st_sh += __shfl_xor(st_sh, d); st_st += __shfl_xor(st_st, d); }
+                    st_occ = wave_sum_u64(st_occ);
                     if (lane == 0) {
                         if (st_dist) atomic_add_u32(&s_stat[0], st_dist);
-                        if (st_occ) atomic_add_u32(&s_stat[1], st_occ);
+                        if (st_occ) atomic_add_u64(&s_occ, st_occ);
                         if (st_sh) atomic_add_u32(&s_stat[2], st_sh);
                         if (st_st) atomic_add_u32(&s_stat[3], st_st);
                     }
@@ -451,10 +468,10 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                 // ---- multi-pass, one phase: statistics and solid entries of this pass in one sweep ----
                 if (onephase) {
                     const uint64_t obase = s_base; const bool wr_ok = s_over == 0;
-                    uint32_t st_dist = 0, st_occ = 0, st_sh = 0, st_st = 0;
+                    uint32_t st_dist = 0, st_sh = 0, st_st = 0; uint64_t st_occ = 0;
                     for (uint32_t s = tid; s < cap; s += NT) {
                         if (!ktable_used<W>(T, s)) continue;
-                        const uint32_t c = cnt[s], n = c & ~TRAV_FLAG; const bool trav = c & TRAV_FLAG;
+                        const uint32_t c = count_word_out(cnt[s]), n = c & ~TRAV_FLAG; const bool trav = c & TRAV_FLAG;
                         if (!trav) { ++st_dist; st_occ += n; }
                         if (n >= P.amin) {
                             if (trav) ++st_st; else ++st_sh;
@@ -467,10 +484,11 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     }
                     // (full 32-bit sums: a giant partition -- one bucket for the whole input -- overflows 16-bit fields)
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) { st_dist += __shfl_xor(st_dist, d); st_occ += __shfl_xor(st_occ, d); st_sh += __shfl_xor(st_sh, d); st_st += __shfl_xor(st_st, d); }
+                    for (int d = 32; d >= 1; d >>= 1) { st_dist += __shfl_xor(st_dist, d); st_sh += __shfl_xor(st_sh, d); st_st += __shfl_xor(st_st, d); }
+                    st_occ = wave_sum_u64(st_occ);
                     if (lane == 0) {
                         if (st_dist) atomic_add_u32(&s_stat[0], st_dist);
-                        if (st_occ) atomic_add_u32(&s_stat[1], st_occ);
+                        if (st_occ) atomic_add_u64(&s_occ, st_occ);
                         if (st_sh) atomic_add_u32(&s_stat[2], st_sh);
                         if (st_st) atomic_add_u32(&s_stat[3], st_st);
                     }
@@ -480,10 +498,10 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                 }
                 // ---- sweep: statistics + number of solid entries (phase 0) ----
                 if (phase == 0) {
-                    uint32_t my_solid = 0, st_dist = 0, st_occ = 0, st_sh = 0, st_st = 0;
+                    uint32_t my_solid = 0, st_dist = 0, st_sh = 0, st_st = 0; uint64_t st_occ = 0;
                     for (uint32_t s = tid; s < cap; s += NT) {
                         if (!ktable_used<W>(T, s)) continue;
-                        const uint32_t c = cnt[s], n = c & ~TRAV_FLAG; const bool trav = c & TRAV_FLAG;
+                        const uint32_t c = count_word_out(cnt[s]), n = c & ~TRAV_FLAG; const bool trav = c & TRAV_FLAG;
                         if (!trav) { ++st_dist; st_occ += n; }
                         if (n >= P.amin) { ++my_solid; if (trav) ++st_st; else ++st_sh; }
                     }
@@ -491,13 +509,14 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     // lane by lane by the compiler), then one LDS atomic per wave and counter
 #pragma unroll
                     for (int d = 32; d >= 1; d >>= 1) {
-                        my_solid += __shfl_xor(my_solid, d); st_dist += __shfl_xor(st_dist, d); st_occ += __shfl_xor(st_occ, d);
+                        my_solid += __shfl_xor(my_solid, d); st_dist += __shfl_xor(st_dist, d);
                         st_sh += __shfl_xor(st_sh, d); st_st += __shfl_xor(st_st, d);
                     }
+                    st_occ = wave_sum_u64(st_occ);
                     if (lane == 0) {
                         if (my_solid) atomic_add_u32(&s_nsolid, my_solid);
                         if (st_dist) atomic_add_u32(&s_stat[0], st_dist);
-                        if (st_occ) atomic_add_u32(&s_stat[1], st_occ);
+                        if (st_occ) atomic_add_u64(&s_occ, st_occ);
                         if (st_sh) atomic_add_u32(&s_stat[2], st_sh);
                         if (st_st) atomic_add_u32(&s_stat[3], st_st);
                     }
@@ -523,7 +542,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                     if (s_nsolid) {
                         for (uint32_t s = tid; s < cap; s += NT) {
                             if (!ktable_used<W>(T, s)) continue;
-                            const uint32_t c = cnt[s];
+                            const uint32_t c = count_word_out(cnt[s]);
                             if ((c & ~TRAV_FLAG) < P.amin) continue;
                             const uint64_t o = obase + atomic_add_u32(&s_wr, 1u);
                             for (int i = 0; i < W; ++i) P.solid_keys[o * W + i] = T.keys[(uint64_t)s * W + i];
@@ -556,7 +575,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
             return;
         }
     }
-    if (tid == 0) for (int i = 0; i < 4; ++i) acc[i] += (uint64_t)s_stat[i];
+    if (tid == 0) { for (int i = 0; i < 4; ++i) acc[i] += (uint64_t)s_stat[i]; acc[1] += s_occ; }
     if (!GLOBAL) {                                                // adapt the starting pass count of this workgroup
         if (npass > start_np) { if (++strikes >= 2) { start_np = npass; strikes = 0; } }
         else if (strikes) --strikes;
@@ -591,18 +610,45 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(GLOBAL ? 1024 : (size_t
 }
 
 // ---- capped-layout repair: gather a spilled partition's region + spill records contiguously ----
+// Entirely on the device (the host only reads two totals): partitions whose fill exceeds the region capacity are
+// flagged and compacted into a list (two prefix sums), their regions are copied into one array of back-to-back runs, and
+// every spilled record finds its run through the partition -> list index map and takes the next free place in it with
+// one device atomic.  (The first version read the spill list back, sorted it on the host and uploaded an order array:
+// 66 ms per step at the config-5 share, where 1 % of the partitions hold two minimizer loci and overflow their region.)
 struct RepairParams {
-    const uint64_t* records; const uint64_t* spill_recs; const uint32_t* order; const uint64_t* soff;
-    const uint64_t* item_off; const uint32_t* item_part; uint32_t part_cap; int RW; uint64_t* out;
+    const uint64_t* records; const uint64_t* spill_recs; const uint32_t* spill_part; uint64_t n_spill;
+    const uint32_t* part_fill; uint64_t npl; uint32_t part_cap; int RW;
+    uint32_t* flag;              // [npl]  1 = spilled
+    const uint64_t* ridx;        // [npl + 1] exclusive scan of flag: list index of a spilled partition
+    uint32_t* item_part;         // [nsp]  spilled partitions, ascending
+    uint32_t* item_size;         // [nsp]  records of the gathered run (= fill)
+    const uint64_t* item_off;    // [nsp + 1] exclusive scan of item_size
+    uint32_t* item_fill;         // [nsp]  spilled records placed so far (zeroed)
+    uint64_t* out;
 };
-__global__ void k_repair_gather(RepairParams P) {
+__global__ void k_repair_flag(RepairParams P) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P.npl) P.flag[p] = P.part_fill[p] > P.part_cap ? 1u : 0u;
+}
+__global__ void k_repair_list(RepairParams P) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P.npl || !P.flag[p]) return;
+    const uint64_t i = P.ridx[p];
+    P.item_part[i] = (uint32_t)p; P.item_size[i] = P.part_fill[p];
+}
+__global__ void k_repair_gather(RepairParams P) {        // one workgroup per spilled partition: its region
     const uint32_t it = blockIdx.x;
     const uint64_t o0 = P.item_off[it] * P.RW, p = P.item_part[it];
     const uint64_t nreg = (uint64_t)P.part_cap * P.RW;
     for (uint64_t i = threadIdx.x; i < nreg; i += blockDim.x) P.out[o0 + i] = P.records[p * nreg + i];
-    const uint64_t s0 = P.soff[it], s1 = P.soff[it + 1];
-    for (uint64_t i = threadIdx.x; i < (s1 - s0) * P.RW; i += blockDim.x)
-        P.out[o0 + nreg + i] = P.spill_recs[(uint64_t)P.order[s0 + i / P.RW] * P.RW + i % P.RW];
+}
+__global__ void k_repair_scatter(RepairParams P) {       // one thread per spilled record
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < P.n_spill; o += stride) {
+        const uint64_t it = P.ridx[P.spill_part[o]];
+        const uint64_t dst = (P.item_off[it] + P.part_cap + atomic_add_u32(&P.item_fill[it], 1u)) * P.RW;
+        for (int w = 0; w < P.RW; ++w) P.out[dst + w] = P.spill_recs[o * P.RW + w];
+    }
 }
 
 

@@ -43,7 +43,7 @@ template <int W, int TS, int NT>
 struct CountFastLds {
     uint64_t keys[TS * W];
     uint32_t cnt[TS];
-    uint64_t stage[(NT / 64) * COUNT_CB * RecFmt<W>::RW + 2];   // + 2: the dword window of the last record may over-read
+    uint64_t stage[(NT / 64) * COUNT_CB * RecFmt<W>::RW + 2];   // + 2: the dword window of the last record may over-read (up to 4 dwords)
     uint64_t smask[(NT / 64) * CountGeom<W>::MASKW];
     uint64_t tmask[(NT / 64) * CountGeom<W>::MASKW];
     uint16_t rbase[(NT / 64) * COUNT_CB];
@@ -96,18 +96,16 @@ CDBG_DEV void count_wave_share(const CountRange& rg, int wave, uint64_t& w0, uin
     if (w0 > end) w0 = end;
     w1 = (w0 + per_wave < end) ? w0 + per_wave : end;
 }
-// Multi-word k-mers (W > 1): a partition holds few records (tens) of very unequal size (1 .. CAPB - k + 1 members), so equal
-// RECORD shares left the last wave of a workgroup 40 % of its time at the barrier (k = 127) and every wave 31 % (k = 55).
-// There wave w takes members [M w / NW, M (w + 1) / NW) of the partition's M member k-mers in record order: it walks the
-// 64-record chunks that overlap its range and a record may be split between two waves (a wave stages it with the index of
-// its first member).  M needs the member counts of all records before the first insert: the first chunk arrives whole with
-// the prefetch, the meta words of the next COUNT_NPRE chunks ride along with it (one dword per lane each), later chunks
-// (rare) are summed in a loop.  Balancing every chunk by itself instead was measured: a partition of 68 records then costs
-// every wave a fourth, nearly empty step for the 4 records of its second chunk (k = 55: count 180 -> 205 ms).
-// One-word k-mers keep the record shares: ~48 records per wave even out by themselves, and eight waves reading all ~380
-// records would cost more than the barrier wait it removes.
-template <int W> struct CountBal { static constexpr bool ON = W > 1; };
-constexpr int COUNT_NPRE = 2;
+// Three- and four-word k-mers (k >= 64): a partition holds few records (~20) of very unequal size (1 .. CAPB - k + 1
+// members), so equal RECORD shares left the last wave of a workgroup 40 % of its time at the barrier (k = 127: the first
+// wave of four took ceil(n / 4) records, the last what remained).  There every wave walks ALL records of the partition and
+// takes an equal share of the MEMBERS of each 64-record chunk: a record may be split between two waves (a wave stages it
+// with the index of its first member).  Measured at the config-5 share: count 526 -> 481 ms.  Not for two-word k-mers
+// (k = 55: ~68 records per partition over 8 waves): balancing every chunk by itself costs every wave a fourth, nearly
+// empty step for the 4 records of the second chunk (count 180 -> 205 ms), and balancing the whole partition (meta words
+// of the next chunks prefetched with the first) was no better than the record shares (200 ms): eight waves reading and
+// prefix-summing all records eat what the shorter barrier wait gives.  One-word k-mers: ~48 records per wave even out.
+template <int W> struct CountBal { static constexpr bool ON = W > 2; };
 template <int W, int NW>
 CDBG_DEV void count_share(const CountRange& rg, int wave, uint64_t& w0, uint64_t& w1) {
     if (CountBal<W>::ON) { w0 = rg.rec0; w1 = rg.rec0 + rg.n; }
@@ -123,18 +121,6 @@ CDBG_DEV void count_load_chunk(const CountParams& P, uint64_t first, uint64_t en
         for (int i = 0; i < RW; ++i) R.r[i] = P.records[(first + lane) * RW + i];
     }
 }
-// meta words (member count in the low byte) of the records of chunks 1 .. COUNT_NPRE of [first, end); 0 beyond the end
-template <int W>
-CDBG_DEV void count_load_metas(const CountParams& P, uint64_t first, uint64_t end, int lane, uint32_t (&mx)[COUNT_NPRE]) {
-    constexpr int RW = RecFmt<W>::RW;
-#pragma unroll
-    for (int j = 0; j < COUNT_NPRE; ++j) {
-        const uint64_t i = first + 64u * (uint64_t)(j + 1) + (uint64_t)lane;
-        mx[j] = 0;
-        if (i < end) mx[j] = (uint32_t)P.records[i * RW];
-    }
-}
-CDBG_DEV uint32_t wave_total_u32(uint32_t v) { return wave_readlane_u32(wave_incl_sum_u32(v), 63); }
 struct CountAcc { uint32_t dist, sh, st; uint64_t occ;
 #ifdef CDBG_PROFILE_PHASES
     uint64_t ph[8], t_prev;
@@ -149,7 +135,7 @@ struct CountAcc { uint32_t dist, sh, st; uint64_t occ;
 // The loop is unrolled twice over two register sets (ping-pong): a register COPY of a requested value would be its
 // first use and put the wait for it at the end of the partition that issued the request.
 template <int W, int CAPPED>
-struct CountSet { RecView<W> R; CountRaw<CAPPED> raw; uint32_t mx[COUNT_NPRE]; };   // mx: (balanced shares) meta words of the chunks after the first    // R: this wave's records of a partition; raw: range words of the partition after it
+struct CountSet { RecView<W> R; CountRaw<CAPPED> raw; };    // R: this wave's records of a partition; raw: range words of the partition after it    // R: this wave's records of a partition; raw: range words of the partition after it
 template <int W, int CAPPED>
 struct CountAhead { CountSet<W, CAPPED>* cur; CountSet<W, CAPPED>* nxt; CountRange rg_nxt; uint32_t item_nxt, item_nn; bool issued; };
 // resolve the next partition's range from the words requested one partition ago, request this wave's share of its
@@ -159,7 +145,6 @@ CDBG_DEV void count_issue_ahead(const CountParams& P, CountAhead<W, CAPPED>& A, 
     A.rg_nxt = count_raw_resolve<CAPPED>(P, A.item_nxt, A.cur->raw);
     uint64_t w0, w1; count_share<W, NW>(A.rg_nxt, wave, w0, w1);
     count_load_chunk<W>(P, w0, w1, lane, A.nxt->R);
-    if (CountBal<W>::ON) count_load_metas<W>(P, w0, w1, lane, A.nxt->mx);
     A.nxt->raw = count_raw_load<CAPPED>(P, A.item_nn);
     A.issued = true;
 }
@@ -188,37 +173,16 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
     CDBG_FPH(0);
     uint32_t n_new = 0;                                                       // wave-uniform: keys this wave added
     RecView<W> R = A.cur->R;
-    // balanced shares: this wave's member range [m_lo, m_hi) of the partition, and the member totals of the first chunks
-    uint64_t m_lo = 0, m_hi = 0, g0c = 0;                                     // g0c: members in the chunks before the current one
-    uint32_t tpre[COUNT_NPRE + 1] = {};
-    if (CountBal<W>::ON) {
-        tpre[0] = wave_total_u32((uint64_t)lane < w1 - w0 ? (uint32_t)R.n() : 0u);
-        uint64_t mtot = tpre[0];
-#pragma unroll
-        for (int j = 0; j < COUNT_NPRE; ++j) { tpre[j + 1] = wave_total_u32(A.cur->mx[j] & 0xFFu); mtot += tpre[j + 1]; }
-        for (uint64_t c0 = w0 + 64u * (COUNT_NPRE + 1); c0 < w1; c0 += 64) {  // (partitions of more than 192 records: rare)
-            const uint64_t i = c0 + (uint64_t)lane;
-            mtot += wave_total_u32(i < w1 ? (uint32_t)P.records[i * RW] & 0xFFu : 0u);
-        }
-        m_lo = mtot * (uint64_t)wave / (uint64_t)NW; m_hi = mtot * ((uint64_t)wave + 1u) / (uint64_t)NW;
-    }
-    uint32_t ci = 0;                                                          // chunk index
-    for (uint64_t c0 = w0; c0 < w1; c0 += 64, ++ci) {                         // wave-uniform
-        if (CountBal<W>::ON && ci <= (uint32_t)COUNT_NPRE) {                  // a chunk outside this wave's range is not even loaded
-            const uint32_t tc = ci == 0 ? tpre[0] : ci == 1 ? tpre[1] : tpre[COUNT_NPRE];
-            static_assert(COUNT_NPRE == 2, "select chain over tpre");
-            if (g0c + tc <= m_lo || g0c >= m_hi) { g0c += tc; continue; }
-        }
+    for (uint64_t c0 = w0; c0 < w1; c0 += 64) {                               // wave-uniform
         if (c0 != w0) count_load_chunk<W>(P, c0, w1, lane, R);                 // (the first 64 records came prefetched)
         const int nrec = (int)((w1 - c0) < 64 ? (w1 - c0) : 64);
         const uint32_t nfull = lane < nrec ? (uint32_t)R.n() : 0u;             // members of the lane's record
         uint32_t n = nfull, first = 0;                                        // ... of which this wave takes [first, first + n)
         if (CountBal<W>::ON) {
-            const uint32_t gi = wave_incl_sum_u32(nfull), mc = wave_readlane_u32(gi, 63);
-            const uint64_t ge = g0c + (gi - nfull), gn = g0c + gi;            // the record's members in partition coordinates
-            const uint64_t sb = ge > m_lo ? ge : m_lo, se = gn < m_hi ? gn : m_hi;
-            n = se > sb ? (uint32_t)(se - sb) : 0u; first = (uint32_t)(sb - ge);
-            g0c += mc;
+            const uint32_t gi = wave_incl_sum_u32(nfull), mc = wave_readlane_u32(gi, 63), ge = gi - nfull;
+            const uint32_t m_lo = mc * (uint32_t)wave / (uint32_t)NW, m_hi = mc * ((uint32_t)wave + 1u) / (uint32_t)NW;   // (mc <= 64 * 248)
+            const uint32_t sb = ge > m_lo ? ge : m_lo, se = gi < m_hi ? gi : m_hi;
+            n = se > sb ? se - sb : 0u; first = sb - ge;
         }
         const uint32_t incl = wave_incl_sum_u32(n);
         // (the wave's records with members are consecutive lanes; the stage index of a record is its rank among them)
@@ -258,10 +222,16 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
                         const uint32_t lo32 = alignbit_u32(d1, d0, sh), hi32 = alignbit_u32(d2, d1, sh);
                         fw.w[0] = (((uint64_t)hi32 << 32) | lo32) & kmask1;
                     } else {
-                        RecView<W> Q;
+                        // the same dword window for W words: 2 W + 1 dwords from bit sh on, 2 W funnel shifts (a select chain
+                        // over the RW record words per output word before: ~110 v_cndmask per k-mer at W = 4)
+                        const uint32_t* dw = reinterpret_cast<const uint32_t*>(stage + slot * RW) + (sh >> 5);
+                        uint32_t in[2 * W + 1];
 #pragma unroll
-                        for (int i = 0; i < RW; ++i) Q.r[i] = stage[slot * RW + i];
-                        fw = Q.kmer((int)((RBITS - sh) / 2u) - k, k);
+                        for (int j = 0; j < 2 * W + 1; ++j) in[j] = dw[j];
+#pragma unroll
+                        for (int i = 0; i < W; ++i)
+                            fw.w[i] = ((uint64_t)alignbit_u32(in[2 * i + 2], in[2 * i + 1], sh) << 32) | alignbit_u32(in[2 * i + 1], in[2 * i], sh);
+                        fw.mask(k);
                     }
                     const Kmer<W> rc = fw.rc(k);
                     const Kmer<W>& can = (rc < fw) ? rc : fw;
@@ -415,16 +385,20 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, 
     CountRange rg_cur = count_raw_resolve<CAPPED>(P, blockIdx.x, count_raw_load<CAPPED>(P, blockIdx.x));
     CountSet<W, CAPPED> S0, S1;
     S0.raw = count_raw_load<CAPPED>(P, blockIdx.x + stride);
-    { uint64_t w0, w1; count_share<W, NW>(rg_cur, wave, w0, w1); count_load_chunk<W>(P, w0, w1, lane, S0.R); if (CountBal<W>::ON) count_load_metas<W>(P, w0, w1, lane, S0.mx); }
-    uint32_t par = 0, misses = 0;                        // misses: consecutive partitions that did not fit one pass
+    { uint64_t w0, w1; count_share<W, NW>(rg_cur, wave, w0, w1); count_load_chunk<W>(P, w0, w1, lane, S0.R); }
+    uint32_t par = 0, misses = 0, deferred = 0;          // misses: consecutive partitions that did not fit one pass; deferred: partitions sent on untried since
     auto one_partition = [&](CountSet<W, CAPPED>& cur, CountSet<W, CAPPED>& nxt, const uint32_t item) {
         CountAhead<W, CAPPED> A;
         A.cur = &cur; A.nxt = &nxt; A.item_nxt = item + stride; A.item_nn = item + 2 * stride; A.issued = false;
         if (rg_cur.n) {                                  // uniform
             bool done = false;
-            if (misses < 4) {
+            // after four misses in a row (an input of mostly distinct k-mers) the workgroup stops trying -- but looks again every
+            // 16th partition: one heavy locus must not send the rest of the workgroup's stride to the slower tiers
+            bool try_fast = misses < 4;
+            if (!try_fast && ++deferred >= 16u) { try_fast = true; deferred = 0; }
+            if (try_fast && rg_cur.n < COUNT_FAST_MAX_RECORDS) {   // (a partition that could carry a count to the 31-bit ceiling goes to the saturating kernels)
                 done = count_partition_fast<W, TS, NT, CAPPED>(P, L, rg_cur, A, par, chunk_base, chunk_left, ca);
-                if (done) { par ^= 1u; misses = 0; }
+                if (done) { par ^= 1u; misses = 0; deferred = 0; }
                 else {                                   // leave a clean table and known counters behind
                     CDBG_LDS_BARRIER();
                     count_fast_clear<W, TS, NT>(L);
@@ -432,7 +406,7 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, 
                     CDBG_LDS_BARRIER();
                 }
             }
-            if (!done && tid == 0) {                     // (after four misses in a row the workgroup stops trying: an input of mostly distinct k-mers)
+            if (!done && tid == 0) {
                 const uint32_t i = atomic_add_u32(FP.retry_count, 1u);
                 FP.retry_list[i] = rg_cur.p;
             }

@@ -365,24 +365,59 @@ __global__ void k_copy_u64(const uint64_t* src, uint64_t* dst, uint64_t n) {
 
 // ---- counter-based synthetic reads, resident in HBM ----
 // identical bit-for-bit to oracle/cdbg_oracle.c:orc_synth_reads
+//   cfg 0 .. 255       the plain generator: uniform random genome at 30x, uniform read starts, 1 % substitutions
+//   cfg | GEN_HOSTILE  the same reads over a HOSTILE genome (what uniform random data never exercises): 1 block in 20 of
+//                      4096 bases is two-letter low complexity, up to 1000 exact copies of one 5 kbp repeat, 50 homopolymer
+//                      runs of 600 bases, and a third of the reads start inside 1/40 of the genome (~20x coverage skew)
+//   cfg < 0            every base 'A' (test hook: ONE k-mer seen n_reads * (read_len - k + 1) times, count saturation)
+constexpr int GEN_HOSTILE = 0x100;
+CDBG_HD uint32_t gen_genome_base(uint64_t gp, uint64_t G, uint64_t seed_g, bool hostile) {
+    const uint32_t plain = (uint32_t)(mix64(seed_g + gp) >> 62);
+    if (!hostile) return plain;
+    const uint64_t hp_stride = G / 50;                    // homopolymer runs
+    if (hp_stride >= 2400) {
+        const uint64_t off = gp % hp_stride;
+        if (off >= hp_stride / 2 && off < hp_stride / 2 + 600) return (uint32_t)((gp / hp_stride) & 3u);
+    }
+    uint64_t nc = G / 50000; if (nc > 1000) nc = 1000;    // copies of the 5 kbp repeat
+    if (nc) {
+        const uint64_t rs = G / nc, off = gp % rs;
+        if (off >= rs / 4 && off < rs / 4 + 5000) return (uint32_t)(mix64((seed_g ^ 0x5EED0000ULL) + (off - rs / 4)) >> 62);
+    }
+    const uint64_t bh = mix64(seed_g + 0x10C0000000ULL + (gp >> 12));   // two-letter blocks
+    if (bh % 20 == 0) {
+        const uint32_t a = (uint32_t)(bh >> 8) & 3u, b2 = (a + 1u + (uint32_t)((bh >> 16) % 3)) & 3u;
+        return (plain & 2u) ? a : b2;
+    }
+    return plain;
+}
+CDBG_HD uint64_t gen_read_start(uint64_t u, uint64_t G, uint64_t L, bool hostile) {
+    if (hostile && (u >> 32) % 3 == 0) {
+        uint64_t hot = G / 40; if (hot < L) hot = L;
+        return G / 2 - hot / 2 + u % (hot - L + 1);
+    }
+    return u % (G - L + 1);
+}
 struct GenParams {
     uint8_t* out; uint64_t first_read, n_reads, total_reads, read_len; int cfg;
 };
 __global__ void k_gen_reads(GenParams P) {
     const uint64_t L1 = P.read_len + 1;
     const uint64_t total = P.n_reads * L1, stride = (uint64_t)gridDim.x * blockDim.x;
+    const bool hostile = P.cfg >= 0 && (P.cfg & GEN_HOSTILE);
     for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
     const uint64_t i = idx / L1, j = idx % L1;
     if (j == P.read_len) { P.out[idx] = '\n'; continue; }
+    if (P.cfg < 0) { P.out[idx] = 'A'; continue; }
     const uint64_t SEED_G = 0xBCA10000ULL + (uint64_t)P.cfg, SEED_R = 0xBCA11000ULL + (uint64_t)P.cfg,
                    SEED_E = 0xBCA12000ULL + (uint64_t)P.cfg;
     uint64_t G = (P.total_reads * P.read_len + 29) / 30;
     if (G < P.read_len) G = P.read_len;
     const uint64_t r = P.first_read + i;
-    const uint64_t start = mix64(SEED_R + 2 * r) % (G - P.read_len + 1);
+    const uint64_t start = gen_read_start(mix64(SEED_R + 2 * r), G, P.read_len, hostile);
     const int strand = (int)(mix64(SEED_R + 2 * r + 1) & 1ULL);
     const uint64_t gp = strand ? start + P.read_len - 1 - j : start + j;
-    uint32_t b = (uint32_t)(mix64(SEED_G + gp) >> 62);
+    uint32_t b = gen_genome_base(gp, G, SEED_G, hostile);
     if (strand) b = 3u - b;
     const uint64_t x = mix64(SEED_E + r * P.read_len + j);
     if (x % 10000 < 100) b = (b + 1 + (uint32_t)((x >> 32) % 3)) & 3u;

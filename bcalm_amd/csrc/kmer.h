@@ -157,8 +157,23 @@ struct Kmer {
     CDBG_HD Kmer rc(int k) const {
         Kmer r;
         if (W == 1) { r.w[0] = (~rev2(w[0])) >> (64 - 2 * k); return r; }   // one word: no cross-word funnel (k <= 31)
-        for (int i = 0; i < W; ++i) r.w[i] = ~rev2(w[W - 1 - i]);
-        r = r.shr(64 * W - 2 * k);
+        Kmer t;
+        for (int i = 0; i < W; ++i) t.w[i] = ~rev2(w[W - 1 - i]);
+        // shift right by s = 64 W - 2 k bits.  Under the span rule (32 (W - 1) <= k < 32 W; the (k-1)-mers of junctions one
+        // base shorter) s is 2 .. 66: at most one whole word, decided by a wave-uniform branch on k -- no select chain over
+        // the words (the general shr() costs 2 W of them per word: the rc of every member k-mer paid ~60 v_cndmask at W = 4)
+        const int s = 64 * W - 2 * k;
+        if (s < 64) {
+#pragma unroll
+            for (int i = 0; i < W; ++i) r.w[i] = (t.w[i] >> s) | (i + 1 < W ? t.w[i + 1 < W ? i + 1 : 0] << (64 - s) : 0ULL);
+        } else if (s < 128) {
+            const int b = s - 64;
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const uint64_t lo = i + 1 < W ? t.w[i + 1 < W ? i + 1 : 0] : 0ULL, hi = i + 2 < W ? t.w[i + 2 < W ? i + 2 : 0] : 0ULL;
+                r.w[i] = b ? ((lo >> b) | (hi << (64 - b))) : lo;
+            }
+        } else r = t.shr(s);
         return r;                               // high bits are already zero after the shift
     }
     CDBG_HD Kmer canonical(int k) const {

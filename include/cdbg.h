@@ -88,7 +88,11 @@ int cdbg_push_text(cdbg_ctx* ctx, const char* text, uint64_t nbytes);
  * while the caller is still parsing and pushing the rest (single GPU; README.md:45-50 inputs through the CLI). */
 int cdbg_expect_input(cdbg_ctx* ctx, uint64_t text_bytes);
 /* Synthetic reads generated directly in HBM (BASELINE.md section 2 generator): reads
- * [first_read, first_read + n_reads) of a set of total_reads reads of read_len bases. */
+ * [first_read, first_read + n_reads) of a set of total_reads reads of read_len bases.
+ * cfg 0 .. 255: uniform random genome at 30x coverage, 1 % substitutions (the seed).  cfg | 0x100: the same reads over a
+ * HOSTILE genome -- two-letter low-complexity blocks (1 in 20), up to 1000 exact copies of one 5 kbp repeat, 50 homopolymer
+ * runs of 600 bases, a third of the reads inside 1/40 of the genome (~20x coverage skew).  cfg < 0: every base 'A' (test
+ * hook for the abundance ceiling).  oracle/cdbg_oracle.c:orc_synth_reads writes the same bytes. */
 int cdbg_generate_reads(cdbg_ctx* ctx, uint64_t first_read, uint64_t n_reads, uint64_t total_reads,
                         uint64_t read_len, int cfg);
 /* copy (part of) the resident read text back to the host (tests, FASTA dumps) */
@@ -194,6 +198,8 @@ int cdbg_fetch_unitigs(cdbg_ctx* ctx, uint64_t first, uint64_t n, char* seq_buf,
  * ab_off[n+1] offsets into ab; unitig i has LN-k+1 values in the orientation of its sequence
  * (the `ab:Z:` vector of /root/reference/README.md:74-80) */
 int cdbg_fetch_unitig_abundances(cdbg_ctx* ctx, uint64_t first, uint64_t n, uint32_t* ab, uint64_t* ab_off);
+/* Abundances are 31-bit and saturate: exact below 2^31 - 4096, reported as 2147483647 from there on (KC sums the reported
+ * values in 64 bits).  README.md:62-72 (KC = sum of abundances); gatb-core's `-abundance-max` default is the same number. */
 int cdbg_stats(cdbg_ctx* ctx, cdbg_stats_t* out);
 /* Digests of the resident result, computed on the device (bench.py checks them at sizes no oracle follows):
  * out[0] = sum of KC over the unitigs, out[1] = sum of the solid k-mers' counts (must equal out[0]),

@@ -104,6 +104,8 @@ struct orc_result {
     char** utg_seq; uint64_t* utg_len; uint64_t* utg_kc; int* utg_circ;
 };
 
+#define ORC_COUNT_MAX 0x7FFFFFFFu
+#define ORC_COUNT_SAT (ORC_COUNT_MAX - 4095u)
 #define ORC_W 1
 #include "oracle_impl.h"
 #undef ORC_W
@@ -167,28 +169,61 @@ uint64_t orc_synth_genome_len(uint64_t n_reads, uint64_t read_len) {
     uint64_t g = (n_reads * read_len + 29) / 30;
     return g < read_len ? read_len : g;
 }
+/* cfg 0 .. 255: the plain generator.  cfg | ORC_GEN_HOSTILE: the same reads over a hostile genome (two-letter blocks,
+ * up to 1000 copies of one 5 kbp repeat, 50 homopolymer runs of 600 bases, a third of the reads inside 1/40 of the
+ * genome).  cfg < 0: every base 'A'.  Bit for bit what bcalm_amd/csrc/k_scan.h:k_gen_reads writes. */
+#define ORC_GEN_HOSTILE 0x100
+static unsigned orc_genome_base(uint64_t gp, uint64_t G, uint64_t seed_g, int hostile) {
+    const unsigned plain = (unsigned)(orc_mix(seed_g + gp) >> 62);
+    if (!hostile) return plain;
+    const uint64_t hp_stride = G / 50;
+    if (hp_stride >= 2400) {
+        const uint64_t off = gp % hp_stride;
+        if (off >= hp_stride / 2 && off < hp_stride / 2 + 600) return (unsigned)((gp / hp_stride) & 3u);
+    }
+    uint64_t nc = G / 50000; if (nc > 1000) nc = 1000;
+    if (nc) {
+        const uint64_t rs = G / nc, off = gp % rs;
+        if (off >= rs / 4 && off < rs / 4 + 5000) return (unsigned)(orc_mix((seed_g ^ 0x5EED0000ULL) + (off - rs / 4)) >> 62);
+    }
+    const uint64_t bh = orc_mix(seed_g + 0x10C0000000ULL + (gp >> 12));
+    if (bh % 20 == 0) {
+        const unsigned a = (unsigned)(bh >> 8) & 3u, b2 = (a + 1u + (unsigned)((bh >> 16) % 3)) & 3u;
+        return (plain & 2u) ? a : b2;
+    }
+    return plain;
+}
+static uint64_t orc_read_start(uint64_t u, uint64_t G, uint64_t L, int hostile) {
+    if (hostile && (u >> 32) % 3 == 0) {
+        uint64_t hot = G / 40; if (hot < L) hot = L;
+        return G / 2 - hot / 2 + u % (hot - L + 1);
+    }
+    return u % (G - L + 1);
+}
 /* writes n_reads * (read_len + 1) bytes: each read followed by '\n' */
 void orc_synth_reads(char* out, uint64_t first_read, uint64_t n_reads, uint64_t total_reads,
                      uint64_t read_len, int cfg) {
     const uint64_t SEED_G = 0xBCA10000ULL + (uint64_t)cfg, SEED_R = 0xBCA11000ULL + (uint64_t)cfg,
                    SEED_E = 0xBCA12000ULL + (uint64_t)cfg;
     const uint64_t G = orc_synth_genome_len(total_reads, read_len);
+    const int hostile = cfg >= 0 && (cfg & ORC_GEN_HOSTILE);
     for (uint64_t i = 0; i < n_reads; ++i) {
         uint64_t r = first_read + i;
-        uint64_t start = orc_mix(SEED_R + 2 * r) % (G - read_len + 1);
-        int strand = (int)(orc_mix(SEED_R + 2 * r + 1) & 1);
         char* dst = out + i * (read_len + 1);
+        dst[read_len] = '\n';
+        if (cfg < 0) { memset(dst, 'A', read_len); continue; }
+        uint64_t start = orc_read_start(orc_mix(SEED_R + 2 * r), G, read_len, hostile);
+        int strand = (int)(orc_mix(SEED_R + 2 * r + 1) & 1);
         for (uint64_t j = 0; j < read_len; ++j) {
             /* j-th base of the read as sequenced; on the reverse strand it is the
              * complement of genome base start+L-1-j */
             uint64_t gp = strand ? start + read_len - 1 - j : start + j;
-            unsigned b = (unsigned)(orc_mix(SEED_G + gp) >> 62);
+            unsigned b = orc_genome_base(gp, G, SEED_G, hostile);
             if (strand) b = 3u - b;
             uint64_t x = orc_mix(SEED_E + r * read_len + j);
             if (x % 10000 < 100) b = (b + 1 + (unsigned)((x >> 32) % 3)) & 3u;
             dst[j] = "ACGT"[b];
         }
-        dst[read_len] = '\n';
     }
 }
 

@@ -119,8 +119,10 @@ static void FN(tab_grow)(TAB* t) {
 static inline void FN(tab_add)(TAB* t, const KM* key, uint32_t by) {
     if ((t->n + 1) * 10 > t->cap * 7) FN(tab_grow)(t);
     uint64_t s = FN(tab_slot)(t, key);
+    /* abundances saturate: exact below ORC_COUNT_SAT, 2^31 - 1 from there on (the 31-bit ceiling the product documents in
+     * include/cdbg.h; gatb-core's own `-abundance-max` default is 2147483647 [UPSTREAM-RECALL]) */
     uint64_t c = (uint64_t)t->cnt[s] + by;
-    t->cnt[s] = c > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)c;
+    t->cnt[s] = c >= ORC_COUNT_SAT ? ORC_COUNT_MAX : (uint32_t)c;
 }
 
 /* ---- stage 1: count canonical k-mers.  Any byte that is not ACGT/acgt breaks

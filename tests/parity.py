@@ -1,6 +1,63 @@
-"""Shared parity helpers: run a libcdbg build (HIP or simulator) and compare with the oracle."""
+"""Shared parity helpers: run a libcdbg build (HIP or simulator) and compare with the oracle -- and, whenever a real
+BCALM 2 binary is reachable ($BCALM_BIN or `bcalm` on PATH), with the reference itself (the only door out of "parity
+unpinned": /root/reference/test/simple_test.sh:5-9 does exactly this diff)."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
 import oracle_lib
 from bcalm_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def reference_binary():
+    """a real BCALM 2 executable, or None: $BCALM_BIN, else `bcalm` on PATH -- never this repo's own CLI"""
+    cand = os.environ.get("BCALM_BIN") or shutil.which("bcalm")
+    own = {os.path.realpath(os.path.join(ROOT, "bcalm_amd", "_build", "bcalm")),
+           os.path.realpath(os.path.join(ROOT, "tests", "hostsim", "_build", "bcalm_hostsim"))}
+    if cand and os.path.isfile(cand) and os.access(cand, os.X_OK) and os.path.realpath(cand) not in own:
+        return cand
+    return None
+
+
+def reference_unitigs(ref_bin, text, k, amin, cores=None, timeout=3600):
+    """run the reference on a FASTA dump of `text` (bytes or str, reads separated by any non-ACGT byte) exactly as its README
+    says (README.md:11: bcalm -in X -kmer-size K -abundance-min A) and parse <prefix>.unitigs.fa (README.md:62-72)
+    -> ([(sequence, KC)], seconds)"""
+    import time
+    if isinstance(text, bytes):
+        text = text.decode()
+    with tempfile.TemporaryDirectory() as t:
+        fa = os.path.join(t, "reads.fa")
+        with open(fa, "w") as f:
+            for i, r in enumerate(x for x in re.split(r"[^ACGTacgt]+", text) if x):
+                f.write(">r%d\n%s\n" % (i, r))
+        t0 = time.time()
+        subprocess.run([ref_bin, "-in", fa, "-kmer-size", str(k), "-abundance-min", str(amin), "-nb-cores", str(cores or os.cpu_count() or 1)],
+                       cwd=t, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+        dt = time.time() - t0
+        out = []
+        with open(os.path.join(t, "reads.unitigs.fa")) as f:
+            kc = None
+            for line in f:
+                if line.startswith(">"):
+                    kc = int(re.search(r"KC:i:(\d+)", line).group(1))
+                elif line.strip():
+                    out.append((line.strip(), kc))
+    return out, dt
+
+
+def diff_against_reference(oracle, ref_bin, text, k, amin, ours):
+    """canonical (sequence, KC) sets: ours (list of (seq, KC)) vs the reference binary's output on the same reads"""
+    ref, dt = reference_unitigs(ref_bin, text, k, amin)
+    a = oracle_lib.canonical_set(oracle, ours, k)
+    b = oracle_lib.canonical_set(oracle, ref, k)
+    sa, sb = set(a), set(b)
+    return {"equal": a == b, "ours": len(a), "reference": len(b), "only_ours": sorted(sa - sb)[:5], "only_reference": sorted(sb - sa)[:5],
+            "reference_seconds": dt, "reference_binary": ref_bin}
 
 
 def run_graph(lib, text, k, amin, **kw):
@@ -35,8 +92,15 @@ def assert_parity(oracle, lib, text, k, amin, **kw):
 
 
 def config2_genome(oracle):
-    """BASELINE config 2 shape: one 4.64 Mbp sequence (E. coli MG1655 length; the FASTA itself is not available
-    offline, so a seeded synthetic genome with planted direct and inverted repeats stands in) -> bytes with '\n'"""
+    """BASELINE config 2: $CDBG_ECOLI_FASTA (E. coli MG1655, one sequence) when set; otherwise -- the FASTA is not
+    available offline -- a seeded synthetic genome of the same length with planted direct and inverted repeats -> bytes with '\n'"""
+    real = os.environ.get("CDBG_ECOLI_FASTA")
+    if real and os.path.isfile(real):                    # SURVEY.md 8(d) config 2: the real NC_000913.3 when the box has it
+        import gzip
+        op = gzip.open if real.endswith(".gz") else open
+        with op(real, "rt") as f:
+            seq = "".join(line.strip() for line in f if not line.startswith(">"))
+        return seq.upper().encode() + b"\n"
     comp = bytes.maketrans(b"ACGT", b"TGCA")
     g0 = bytearray(oracle.synth_reads(1, 4_641_652, 2)[:-1])
     for i in range(7):                                   # 7 x 5 kbp repeats, alternating strands

@@ -199,6 +199,44 @@ def test_four_million_reads_against_the_multithreaded_restatement(oracle, hip):
     assert st["unitig_bases"] == cpu["unitig_bases"]
 
 
+def test_hostile_four_million_reads(oracle, hip):
+    """what uniform random reads never exercise, at a size where the fallbacks stop being rare: 4 M x 150 bp reads of the HOSTILE
+    generator (cfg | 0x100: two-letter low-complexity blocks, 400 exact copies of a 5 kbp repeat, 50 homopolymer runs, 20x
+    coverage skew) generated on the device, against oracle/cpu_mt.cpp on the same bytes: counts, KC sum, set digest.  The
+    partitions that overflow (spill repair, second count tier, multi-pass, HBM tables) are reported by the statistics."""
+    import bcalm_amd
+    cfg = 3 | 0x100
+    g = bcalm_amd.Graph(31, 2, lib=hip)
+    g.generate_reads(4_000_000, 150, cfg)
+    text = g.read_text(0, 4_000_000 * 151)
+    assert text[:151 * 1000] == oracle.synth_reads(1000, 150, cfg, first=0, total=4_000_000)
+    cpu = oracle_lib.cpu_mt_run(text, 31, 2, os.cpu_count() or 8)
+    g.run()
+    st = g.stats(); d = g.digest(); g.close()
+    assert st["n_occurrences"] == cpu["occurrences"] == 4_000_000 * 120
+    assert (st["n_distinct"], st["n_solid"], st["n_unitigs"]) == (cpu["distinct"], cpu["solid"], cpu["unitigs"])
+    assert d["kc_sum"] == cpu["kc_sum"] and d["set_digest"] == cpu["set_digest"]
+    assert st["unitig_bases"] == cpu["unitig_bases"]
+    assert st["n_multipass_partitions"] + st["n_big_partitions"] > 0          # the hostile input did reach the fallback tiers
+
+
+@pytest.mark.parametrize("log_np", [-1, 0])
+def test_abundance_saturates_at_31_bits(hip, log_np):
+    """one k-mer seen more than 2^31 times (2.3 M reads of 1000 x 'A', k = 31): the count must clamp at 2^31 - 1 -- not carry
+    into bit 31 of the count word, the traveller flag.  Expected by hand: ONE distinct k-mer A^31 whose only
+    edge is the self-loop, so one unitig of 31 bases with KC = 2147483647 (README.md:62-72: KC is the sum of abundances)"""
+    import bcalm_amd
+    n_reads, L, k = 2_300_000, 1000, 31
+    assert n_reads * (L - k + 1) > (1 << 31)
+    g = bcalm_amd.Graph(k, 2, lib=hip, log2_partitions=log_np)
+    g.generate_reads(n_reads, L, -1)
+    g.run()
+    st = g.stats(); ut = g.unitigs(); solid = g.solid_kmers() if hasattr(g, "solid_kmers") else None
+    g.close()
+    assert st["n_distinct"] == 1 and st["n_solid"] == 1 and st["n_unitigs"] == 1
+    assert ut == [("A" * 31, (1 << 31) - 1)]
+
+
 def test_streaming_scan_while_ingesting_gpu(oracle, oracle_1m, hip, monkeypatch):
     """cdbg_expect_input on the device: the single-pass scan runs on the tiles that have landed while later chunks are
     still being pushed through the pinned staging buffers (copy stream -> event -> compute stream); 1 M reads vs the oracle"""

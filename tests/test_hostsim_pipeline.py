@@ -54,13 +54,31 @@ def test_random_low_complexity(oracle, sim, seed):
                   minimizer_size=rng.choice([2, 3, 4]))
 
 
-def test_synthetic_generator_matches_oracle(oracle, sim):
+@pytest.mark.parametrize("cfg,first,total", [(3, 5, 1000), (3 | 0x100, 5, 1000), (3 | 0x100, 70000, 200000), (4 | 0x100, 123456, 400000), (-1, 0, 400)])
+def test_synthetic_generator_matches_oracle(oracle, sim, cfg, first, total):
+    """plain, hostile (cfg | 0x100: low-complexity blocks, repeat copies, homopolymer runs, coverage skew) and all-'A' modes:
+    the device generator and the oracle's write the same bytes"""
     from bcalm_amd import api
     g = api.Graph(31, 2, lib=sim)
-    g.generate_reads(40, 150, 3, first_read=5, total_reads=100)
-    got = g.read_text(0, 40 * 151)
+    g.generate_reads(400, 150, cfg, first_read=first, total_reads=total)
+    got = g.read_text(0, 400 * 151)
     g.close()
-    assert got == oracle.synth_reads(40, 150, 3, first=5, total=100)
+    exp = oracle.synth_reads(400, 150, cfg, first=first, total=total)
+    assert got == exp
+    if cfg >= 0x100 and total >= 200000:
+        # the hostile features are really there: exact repeat copies make some 31-mers far more frequent than 30x
+        whole = oracle.synth_reads(20000, 150, cfg, first=0, total=total).decode()
+        from collections import Counter
+        c = Counter(whole[i:i + 16] for i in range(0, len(whole) - 16, 7))
+        assert c.most_common(1)[0][1] > 200
+
+
+def test_hostile_reads_parity(oracle, sim):
+    """the hostile generator (cfg | 0x100) through the whole pipeline: low-complexity blocks and skewed coverage overfill
+    partitions, so the capped scan spills and the count tiers defer (every tier forced by the small partition count)"""
+    text = oracle.synth_reads(1500, 150, 3 | 0x100, first=0, total=1500).decode()
+    assert_parity(oracle, sim, text, 31, 2, log2_partitions=4)
+    assert_parity(oracle, sim, text, 21, 1, log2_partitions=7, minimizer_size=8)
 
 
 def test_synthetic_reads_parity(oracle, sim):
