@@ -23,7 +23,7 @@ class CdbgError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("k", C.c_int), ("abundance_min", C.c_int), ("minimizer_size", C.c_int),
                 ("log2_partitions", C.c_int), ("device_id", C.c_int), ("world_size", C.c_int),
-                ("rank", C.c_int), ("all_abundance_counts", C.c_int), ("emit_replicated", C.c_int)]
+                ("rank", C.c_int), ("all_abundance_counts", C.c_int), ("emit_replicated", C.c_int), ("reads_replicated", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -42,9 +42,7 @@ class Stats(C.Structure):
 EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
            "cdbg_generate_reads", "cdbg_expect_input", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
            "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats", "cdbg_digest",
-           "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", "cdbg_exchange_sizes", "cdbg_exchange_export", "cdbg_exchange_begin", "cdbg_exchange_add", "cdbg_exchange_end", "cdbg_glue_join", "cdbg_glue_links_export", "cdbg_glue_links_import",
-           "cdbg_exchange_sizes_packed", "cdbg_exchange_export_packed", "cdbg_exchange_add_packed",
-           "cdbg_exchange_abundance_values", "cdbg_exchange_export_abundances", "cdbg_exchange_add_abundances",
+           "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", 
            "cdbg_set_transport", "cdbg_comm_unique_id", "cdbg_comm_init_rccl", "cdbg_comm_bytes"]
 
 
@@ -95,17 +93,6 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_link.argtypes = [vp]
     lib.cdbg_num_links.argtypes = [vp, C.POINTER(u64)]
     lib.cdbg_fetch_links.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_uint32)]
-    lib.cdbg_exchange_sizes.argtypes = [vp, C.POINTER(u64)]
-    lib.cdbg_exchange_export.argtypes = [vp, i32, vp, u64]
-    lib.cdbg_exchange_begin.argtypes = [vp, u64, u64, u64]
-    lib.cdbg_exchange_add.argtypes = [vp, u64, u64, u64, vp, vp, vp, vp, vp, vp]
-    lib.cdbg_exchange_end.argtypes = [vp]
-    lib.cdbg_glue_join.argtypes = [vp, C.POINTER(u64)]
-    lib.cdbg_exchange_sizes_packed.argtypes = [vp, C.POINTER(u64)]
-    lib.cdbg_exchange_export_packed.argtypes = [vp, vp, u64]
-    lib.cdbg_exchange_add_packed.argtypes = [vp, u64, u64, u64, u64, vp, vp, vp, vp, vp]
-    lib.cdbg_glue_links_export.argtypes = [vp, vp, u64]
-    lib.cdbg_glue_links_import.argtypes = [vp, vp, u64]
     lib.cdbg_set_transport.argtypes = [vp, vp]
     lib.cdbg_comm_unique_id.argtypes = [vp]
     lib.cdbg_comm_init_rccl.argtypes = [vp, C.c_char_p]
@@ -121,11 +108,11 @@ class Graph:
 
     def __init__(self, k: int, abundance_min: int = 2, minimizer_size: int = 0, log2_partitions: int = -1,
                  device_id: int = 0, world_size: int = 1, rank: int = 0, lib: C.CDLL | None = None,
-                 all_abundance_counts: bool = False, emit_replicated: bool = False):
+                 all_abundance_counts: bool = False, emit_replicated: bool = False, reads_replicated: bool = False):
         self.lib = lib or load()
         self.k = k
         p = Params(k, abundance_min, minimizer_size, log2_partitions, device_id, world_size, rank, 1 if all_abundance_counts else 0,
-                   1 if emit_replicated else 0)
+                   1 if emit_replicated else 0, 1 if reads_replicated else 0)
         self._h = C.c_void_p()
         self._ck(self.lib.cdbg_create(C.byref(p), C.byref(self._h)))
 
@@ -226,49 +213,6 @@ class Graph:
             out.append(l)
         return out
 
-    # ---- multi-GPU exchange (see bcalm_amd/dist.py) ----
-    def exchange_sizes(self):
-        out = (C.c_uint64 * 3)()
-        self._ck(self.lib.cdbg_exchange_sizes(self._h, out))
-        return tuple(out)
-
-    def exchange_export(self, what, dst_ptr, nbytes):
-        self._ck(self.lib.cdbg_exchange_export(self._h, what, C.c_void_p(dst_ptr), nbytes))
-
-    def exchange_begin(self, total_pieces, total_bases, total_glog):
-        self._ck(self.lib.cdbg_exchange_begin(self._h, total_pieces, total_bases, total_glog))
-
-    def exchange_add(self, n_pieces, n_bases, n_glog, ptrs):
-        self._ck(self.lib.cdbg_exchange_add(self._h, n_pieces, n_bases, n_glog, *[C.c_void_p(p) for p in ptrs]))
-
-    def exchange_end(self):
-        self._ck(self.lib.cdbg_exchange_end(self._h))
-
-    def exchange_sizes_packed(self):
-        """packs this rank's piece bases; -> (piece ids, bases once unpacked, glue-log records, packed bytes)"""
-        out = (C.c_uint64 * 4)()
-        self._ck(self.lib.cdbg_exchange_sizes_packed(self._h, out))
-        return tuple(int(x) for x in out)
-
-    def exchange_export_packed(self, dst_ptr, nbytes):
-        self._ck(self.lib.cdbg_exchange_export_packed(self._h, C.c_void_p(dst_ptr), nbytes))
-
-    def exchange_add_packed(self, n_pieces, n_bases, n_packed, n_glog, ptrs):
-        self._ck(self.lib.cdbg_exchange_add_packed(self._h, n_pieces, n_bases, n_packed, n_glog, *[C.c_void_p(p) for p in ptrs]))
-
-    def glue_join(self):
-        """sharded junction join; -> number of piece ends (length of the int32 link array)"""
-        n = C.c_uint64()
-        self._ck(self.lib.cdbg_glue_join(self._h, C.byref(n)))
-        return n.value
-
-    def glue_links_export(self, dst_ptr, nbytes):
-        self._ck(self.lib.cdbg_glue_links_export(self._h, C.c_void_p(dst_ptr), nbytes))
-
-    def glue_links_import(self, src_ptr, nbytes):
-        self._ck(self.lib.cdbg_glue_links_import(self._h, C.c_void_p(src_ptr), nbytes))
-
-    # ---- results ----
     def stats(self) -> dict:
         s = Stats()
         self._ck(self.lib.cdbg_stats(self._h, C.byref(s)))

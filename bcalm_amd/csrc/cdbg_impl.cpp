@@ -186,17 +186,17 @@ struct cdbg_ctx {
     DBuf<uint64_t> glog_keys; DBuf<uint32_t> glog_tag; uint64_t glog_cap = 0, n_glog = 0;
     uint64_t n_pieces = 0, n_piece_bases = 0;
 
-    // multi-GPU merge staging (cdbg_exchange_*)
+    // multi-GPU merge staging (xchg_*)
     DBuf<uint32_t> mg_n, mg_gtag; DBuf<uint64_t> mg_kc, mg_boff, mg_gkeys; DBuf<uint8_t> mg_bases;
     DBuf<uint32_t> mg_ab, xp_ab;                         // -all-abundance-counts: merged per-base abundances / this rank's gap-free stream
     DBuf<uint64_t> xp_aoff, xr_aoff; uint64_t xp_nab = 0; bool xp_ab_ready = false;
-    uint64_t last_add_np = 0, last_add_nb = 0, last_add_pieces = 0;   // where the latest cdbg_exchange_add_packed put its pieces
+    uint64_t last_add_np = 0, last_add_nb = 0, last_add_pieces = 0;   // where the latest xchg_add_packed put its pieces
     uint64_t mg_np = 0, mg_nb = 0, mg_nl = 0, mg_cap_p = 0, mg_cap_b = 0, mg_cap_l = 0; bool mg_open = false;
     // junction join result (cdbg_glue_join / first half of cdbg_glue): partner end of every piece end
     DBuf<uint32_t> link; bool joined = false; uint64_t n_join_local = 0;
-    // packed exchange (cdbg_exchange_sizes_packed / _add_packed): this rank's piece bases, 4 per byte, no gaps
+    // packed exchange (xchg_sizes_packed / _add_packed): this rank's piece bases, 4 per byte, no gaps
     DBuf<uint8_t> xp_bases, xp_dense; DBuf<uint32_t> xp_lens; DBuf<uint64_t> xp_uoff; uint64_t xp_bytes = 0, xp_unpacked = 0;
-    DBuf<uint32_t> xr_lens; DBuf<uint64_t> xr_uoff;      // receiver-side scratch of cdbg_exchange_add_packed
+    DBuf<uint32_t> xr_lens; DBuf<uint64_t> xr_uoff;      // receiver-side scratch of xchg_add_packed
 
     DBuf<uint64_t> unitig_off; DBuf<uint32_t> unitig_len; DBuf<uint64_t> unitig_kc; DBuf<uint8_t> unitig_bases;
     uint64_t n_unitigs = 0, unitig_total = 0;
@@ -276,7 +276,16 @@ int ingest_append(cdbg_ctx* c, const char* src, uint64_t n) {
 // text complete: last partial buffer out, all copies done, tail padded with separators
 int upload_pending(cdbg_ctx* c) {
     if (c->reads_final) return CDBG_OK;
-    if (!c->pin[0] || (c->n_dev == 0 && c->pin_fill == 0)) return CDBG_OK;     // nothing was pushed
+    if (!c->pin[0] || (c->n_dev == 0 && c->pin_fill == 0)) {                   // nothing was pushed
+        // a rank of a multi-GPU job may receive no reads at all (a small input dealt out in chunks): it still takes part
+        // in every collective, with an empty text of separators
+        if (c->prm.world_size > 1 || c->force_multi) {
+            CK(c->reads.alloc(512, false));
+            HIPCK(hipMemset(c->reads.p, '\n', 512));
+            c->nbytes = 0; c->nbytes_padded = 256; c->reads_final = true;
+        }
+        return CDBG_OK;
+    }
     CK(ingest_flush(c));
     const uint64_t n = c->n_dev;
     const uint64_t np = ((n + 15) / 16) * 16 + 256;
@@ -363,6 +372,7 @@ void launch_scan_mode(cdbg_ctx* c, ScanParams& sp, uint64_t grid) {
     hipStream_t s = c->stream;
     const bool fast_scan = c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX;
     sp.n_tiles = grid;
+    if (grid == 0) return;                                   // (a rank without reads)
     // compile-time minimizer windows (k - m): the k = 31 family m = 16 .. 12 and k = 55, m = 16 (config 4)
 #define CDBG_SCAN_WNT(WW, WNT_)                                                                                                  \
     if (fast_scan && W == WW && c->k - c->m == WNT_) {                                                                           \
@@ -449,22 +459,43 @@ int stream_scan_dispatch(cdbg_ctx* c) {
     switch (c->W) { case 1: return stream_scan_advance<1>(c); case 2: return stream_scan_advance<2>(c); case 3: return stream_scan_advance<3>(c); default: return stream_scan_advance<4>(c); }
 }
 
+// Several ranks: a rank-local failure between two collectives (out of memory, a device error, a bad input) must not leave
+// the other ranks waiting inside the transport.  Before each collective stage the ranks exchange a status word; if any
+// rank failed, every rank returns an error together.
+int agree(cdbg_ctx* c, int rc, const char* where) {
+    if (!(c->prm.world_size > 1 || c->force_multi) || !c->have_tr) return rc;
+    const std::string mine = rc != CDBG_OK ? g_err : std::string();
+    std::vector<uint64_t> all(c->prm.world_size); const uint64_t st = (uint64_t)(int64_t)rc;
+    if (c->tr.all_gather_u64(c->tr.user, &st, all.data(), 1) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed (%s)", where);
+    if (rc != CDBG_OK) { g_err = mine; return rc; }
+    for (int r = 0; r < c->prm.world_size; ++r)
+        if (all[r] != 0) return fail(CDBG_E_INTERNAL, "%s: rank %d reported error %lld; all ranks stop", where, r, (long long)(int64_t)all[r]);
+    return CDBG_OK;
+}
+
 template <int W>
 int count_impl(cdbg_ctx* c) {
     constexpr int RW = RecFmt<W>::RW;
     constexpr int TS = Cfg<W>::TSC;
-    CK(upload_pending(c));
-    if (!c->reads.p || c->nbytes == 0) return fail(CDBG_E_STATE, "no reads: call cdbg_push_reads/cdbg_push_text/cdbg_generate_reads first");
-    // multi-GPU: the reads are sharded over the ranks; every rank must choose the same partitioning, so the input
-    // volume that drives configure() is the sum over the ranks
-    const bool multi = c->prm.world_size > 1 || c->force_multi;
+    const bool multi_ctx = c->prm.world_size > 1 || c->force_multi;
     const int world = c->prm.world_size;
+    if (multi_ctx && !c->have_tr) return fail(CDBG_E_STATE, "world_size %d but no transport: call cdbg_comm_init_rccl or cdbg_set_transport first", world);
+    {
+        int rc = upload_pending(c);
+        if (rc == CDBG_OK && (!c->reads.p || (c->nbytes == 0 && !multi_ctx))) rc = fail(CDBG_E_STATE, "no reads: call cdbg_push_reads/cdbg_push_text/cdbg_generate_reads first");
+        CK(agree(c, rc, "count: input"));
+    }
+    // multi-GPU, reads SHARDED over the ranks (X1): the scan fills the partitions of every rank and the records travel to
+    // their owners; every rank must choose the same partitioning, so the input volume that drives configure() is the sum
+    // over the ranks.  Reads REPLICATED (X0): every rank scans the whole text for its own partitions, nothing travels.
+    const bool multi = multi_ctx && !c->prm.reads_replicated;
     uint64_t total_bytes = c->nbytes;
-    if (multi) {
-        if (!c->have_tr) return fail(CDBG_E_STATE, "world_size %d but no transport: call cdbg_comm_init_rccl or cdbg_set_transport first", world);
+    if (multi_ctx) {
         std::vector<uint64_t> all(world); const uint64_t mine = c->nbytes;
         if (c->tr.all_gather_u64(c->tr.user, &mine, all.data(), 1) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
-        total_bytes = 0; for (uint64_t v : all) total_bytes += v;
+        if (multi) { total_bytes = 0; for (uint64_t v : all) total_bytes += v; }
+        else for (uint64_t v : all) if (v != mine) return fail(CDBG_E_PARAM, "reads_replicated: the ranks hold different texts (%llu vs %llu bytes)", (unsigned long long)mine, (unsigned long long)v);
+        if (total_bytes == 0) return fail(CDBG_E_STATE, "no reads on any rank");
     }
     if (!c->ss_on) configure(c, total_bytes);             // (a streaming scan fixed the partitioning from the announced volume)
     const uint64_t NPL = c->n_local_parts;
@@ -499,10 +530,13 @@ int count_impl(cdbg_ctx* c) {
     //                    capped: ONE scan into fixed-capacity partition regions sized from a sampled
     //                            histogram; the rare records that do not fit go to a spill list and their
     //                            partitions are repaired (gathered contiguously) before counting.
-    bool capped = tiles > 8192 && !multi;                    // (sharded reads: the exact layout is what travels -- no slack on the wire)
-    if (const char* e = getenv("CDBG_SCAN_MODE"); e && !multi) { if (!strcmp(e, "exact")) capped = false; else if (!strcmp(e, "capped")) capped = true; }
+    // (sharded reads: the exact layout is what travels -- no slack on the wire; a single-pass scan into capped regions is
+    //  squeezed into it by k_pack_regions, which costs one pass over the rank's records instead of a second pass over its reads)
+    bool capped = tiles > 8192;
+    if (const char* e = getenv("CDBG_SCAN_MODE")) { if (!strcmp(e, "exact")) capped = false; else if (!strcmp(e, "capped")) capped = true; }
+    if (tiles == 0) capped = false;                          // (a rank without reads: nothing to sample)
     uint64_t n_records = 0, hs[2] = {0, 0};
-    uint32_t part_cap = 0; uint64_t n_spill = 0;
+    uint32_t part_cap = 0; uint64_t n_spill = 0; bool packed_exact = false;
     uint64_t n_spilled_parts = 0;                            // partitions whose region overflowed (capped mode): counted from gathered copies
     Timer t;
     uint64_t spill_cap = 0;
@@ -517,15 +551,15 @@ int count_impl(cdbg_ctx* c) {
             sp.tile_stride = (uint32_t)stride;
             LAUNCH_SCAN(SCAN_HIST, ns);
             CK(exscan(c->part_count.p));
-            uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPL, &sample_records));
+            uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPS, &sample_records));
             CK(t.stop(&c->st.ms_scan_hist));
-            const double mean = (double)sample_records * (double)tiles / (double)ns / (double)NPL;
-            capped_capacities(mean, NPL, part_cap, spill_cap);
-            if ((double)part_cap * (double)NPL * RW * 8.0 > 200e9) fits = false;       // would not fit: use the exact layout
+            const double mean = (double)sample_records * (double)tiles / (double)ns / (double)NPS;
+            capped_capacities(mean, NPS, part_cap, spill_cap);
+            if ((double)part_cap * (double)NPS * RW * 8.0 > 200e9) fits = false;       // would not fit: use the exact layout
             else {
-                CK(c->records.alloc((uint64_t)part_cap * NPL * RW, false));
+                CK(c->records.alloc((uint64_t)part_cap * NPS * RW, false));
                 CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
-                HIPCK(hipMemsetAsync(c->part_count.p, 0, NPL * sizeof(uint32_t), s));
+                HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
                 HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
             }
         }
@@ -542,13 +576,20 @@ int count_impl(cdbg_ctx* c) {
             CK(exscan(c->part_count.p));                     // only for the total number of records
             CK(t.stop(&c->st.ms_scan_emit));
             hm.mark("count: sample + capped scan");
-            CK(read_u64(c->part_off.p + NPL, &n_records));
+            CK(read_u64(c->part_off.p + NPS, &n_records));
             CK(read_u64(c->dstats.p, hs, 2));
             CK(read_u64(c->cursors.p + 6, &n_spill));
             uint32_t derr = 0; CK(read_u32(c->derr.p, &derr));
             c->ss_on = false;                                // (the streamed part is accounted for; a re-count scans everything)
-            if (derr == 6 || n_spill > spill_cap) {          // estimate was off (very skewed input): exact layout instead
-                capped = false; HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t)));
+            if (derr == 6 || n_spill > spill_cap || (multi && n_spill)) {   // estimate was off (very skewed input): exact layout instead
+                capped = false; HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t))); HIPCK(hipMemset(c->cursors.p + 6, 0, sizeof(uint64_t)));
+            } else if (multi) {
+                // what travels is the exact owner-major layout: squeeze the regions (part_off = exclusive scan of the fills)
+                CK(c->xrecs.alloc(std::max<uint64_t>(n_records, 1) * RW, false));
+                PackRegionParams pk{ c->records.p, c->part_count.p, c->part_off.p, NPS, part_cap, RW, c->xrecs.p };
+                CDBG_LAUNCH(k_pack_regions, std::min<uint64_t>((NPS + 3) / 4, 256 * 16), 256, s, pk);
+                c->records.swap(c->xrecs);
+                capped = false; packed_exact = true;
             } else if (n_spill) {
                 // repair: gather region + spilled records of each spilled partition into one contiguous run (k_count.h)
                 RepairParams rp{};
@@ -572,7 +613,7 @@ int count_impl(cdbg_ctx* c) {
             }
         }
     }
-    if (!capped) {
+    if (!capped && !packed_exact) {
         sp.tile_stride = 1; sp.part_cap = 0;
         HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
@@ -874,7 +915,7 @@ int compact_impl(cdbg_ctx* c) {
 }
 
 // Glue, first half: hash-join the piece ends on their junction (k-1)-mers -> link[end] = partner end.
-// sharded (multi-GPU, after cdbg_exchange_*): this rank joins only the junctions whose key hash selects it --
+// sharded (multi-GPU, after xchg_*): this rank joins only the junctions whose key hash selects it --
 // 1/world of the device atomics -- and leaves the other ends at NONE; the caller combines the link arrays of all
 // ranks with an element-wise MAX all-reduce (every end is set by exactly one rank) before cdbg_glue.
 template <int W>
@@ -940,15 +981,197 @@ int glue_join_impl(cdbg_ctx* c, bool sharded) {
     return CDBG_OK;
 }
 
+// ---- the replicated glue exchange, step by step (internal; the caller-driven variant of this API was removed in round 3:
+// a context with world_size > 1 always exchanges through its transport) ----
+// ---- multi-GPU exchange: the pieces and glue records of every rank are gathered (RCCL all-gather
+// driven by the caller through torch.distributed; this library only copies device-to-device into / out
+// of caller-provided device buffers) and merged in rank order, after which cdbg_glue runs on the union ----
+int xchg_export(cdbg_ctx* c, int what, void* dst_dev, uint64_t nbytes) {
+    if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage != 2) return fail(CDBG_E_STATE, "xchg_export before cdbg_compact");
+    if (c->direct_join && what >= 4) return fail(CDBG_E_STATE, "this single-rank context keeps no junction log (CDBG_GLUE_LOG=1 keeps it)");
+    const void* src = nullptr; uint64_t have = 0;
+    switch (what) {
+        case 0: src = c->piece_n.p; have = c->n_pieces * sizeof(uint32_t); break;
+        case 1: src = c->piece_kc.p; have = c->n_pieces * sizeof(uint64_t); break;
+        case 2: src = c->piece_boff.p; have = c->n_pieces * sizeof(uint64_t); break;
+        case 3: src = c->piece_bases.p; have = c->n_piece_bases; break;
+        case 4: src = c->glog_keys.p; have = c->n_glog * (uint64_t)c->W * sizeof(uint64_t); break;
+        case 5: src = c->glog_tag.p; have = c->n_glog * sizeof(uint32_t); break;
+        default: return fail(CDBG_E_PARAM, "unknown export kind %d", what);
+    }
+    if (nbytes < have) return fail(CDBG_E_PARAM, "export buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)have);
+    if (have) HIPCK(hipMemcpyAsync(dst_dev, src, have, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return CDBG_OK;
+}
+int xchg_begin(cdbg_ctx* c, uint64_t total_pieces, uint64_t total_bases, uint64_t total_glog) {
+    if (!c) return fail(CDBG_E_PARAM, "null context");
+    if (c->stage != 2) return fail(CDBG_E_STATE, "xchg_begin before cdbg_compact");
+    // the merged arrays are swapped with the context's own in xchg_end: give them at least the same
+    // capacity, so that a re-run after cdbg_reset finds arrays that are large enough and never reallocates
+    CK(c->mg_n.alloc(total_pieces, false, c->piece_n.cap)); CK(c->mg_kc.alloc(total_pieces, false, c->piece_kc.cap));
+    CK(c->mg_boff.alloc(total_pieces, false, c->piece_boff.cap));
+    const uint64_t bases_slack = 64ull * 4096;               // the packed exchange starts every rank's bases on a 64-byte boundary
+    CK(c->mg_bases.alloc(total_bases + bases_slack, false, c->piece_bases.cap));
+    CK(c->mg_gkeys.alloc(total_glog * c->W, false, c->glog_keys.cap)); CK(c->mg_gtag.alloc(total_glog, false, c->glog_tag.cap));
+    if (c->prm.all_abundance_counts) CK(c->mg_ab.alloc(total_bases + bases_slack, false, c->piece_ab.cap));
+    c->mg_np = c->mg_nb = c->mg_nl = 0; c->mg_cap_p = total_pieces; c->mg_cap_b = total_bases + bases_slack; c->mg_cap_l = total_glog; c->mg_open = true;
+    return CDBG_OK;
+}
+// ---- packed variant of the exchange: bases travel as 2 bits (pieces padded to whole bytes, reservation gaps squeezed
+// out) and the per-piece base offsets do not travel at all -- the receiver recomputes them from the piece lengths ----
+int xchg_sizes_packed(cdbg_ctx* c, uint64_t out[4]) {
+    if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage != 2) return fail(CDBG_E_STATE, "xchg_* needs a compacted, not yet glued context");
+    if (c->direct_join) return fail(CDBG_E_STATE, "this single-rank context joined its junction records in place and keeps no log to exchange (create it with world_size > 1, or set CDBG_GLUE_LOG=1)");
+    hipStream_t s = c->stream;
+    const uint64_t NP = c->n_pieces;
+    CK(c->xp_lens.alloc(NP, false)); CK(c->xp_uoff.alloc(NP + 1, false));
+    if (NP) {
+        PackLenParams lp{ NP, c->k, c->piece_n.p, c->xp_lens.p };
+        CDBG_LAUNCH(k_pack_lens, (NP + 255) / 256, 256, s, lp);
+    }
+    CK(exscan_u32(c, c->xp_lens.p, c->xp_uoff.p, NP));
+    HIPCK(hipStreamSynchronize(s));
+    CK(read_u64(c->xp_uoff.p + NP, &c->xp_unpacked));
+    const uint64_t chunks = (c->xp_unpacked + 63) / 64;      // 64 bases -> 16 bytes per lane
+    c->xp_bytes = chunks * 16;
+    CK(c->xp_dense.alloc(chunks * 64 + 64, false)); CK(c->xp_bases.alloc(c->xp_bytes + 16, false));
+    if (chunks) HIPCK(hipMemsetAsync(c->xp_dense.p + (chunks - 1) * 64, 'A', 64, s));     // tail padding of the last chunk
+    if (NP) {
+        SqueezeParams sq{ NP, c->xp_lens.p, c->xp_uoff.p, c->piece_boff.p, c->piece_bases.p, c->xp_dense.p };
+        CDBG_LAUNCH(k_squeeze_bases, (NP + 255) / 256, 256, s, sq);
+    }
+    if (chunks) {
+        StreamPackParams pp{ chunks, c->xp_dense.p, c->xp_bases.p, c->xp_unpacked };
+        CDBG_LAUNCH(k_pack_stream, (chunks + 255) / 256, 256, s, pp);
+    }
+    HIPCK(hipStreamSynchronize(s));
+    out[0] = NP; out[1] = c->xp_unpacked; out[2] = c->n_glog; out[3] = c->xp_bytes;
+    return CDBG_OK;
+}
+int xchg_export_packed(cdbg_ctx* c, void* dst_dev, uint64_t nbytes) {
+    if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage != 2 || !c->xp_bases.p) return fail(CDBG_E_STATE, "xchg_export_packed before xchg_sizes_packed");
+    if (nbytes < c->xp_bytes) return fail(CDBG_E_PARAM, "export buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)c->xp_bytes);
+    if (c->xp_bytes) HIPCK(hipMemcpyAsync(dst_dev, c->xp_bases.p, c->xp_bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    return CDBG_OK;
+}
+int xchg_add_packed(cdbg_ctx* c, uint64_t n_pieces, uint64_t n_bases, uint64_t n_packed, uint64_t n_glog, const void* piece_n, const void* piece_kc,
+                             const void* packed_bases, const void* glog_keys, const void* glog_tag) {
+    if (!c) return fail(CDBG_E_PARAM, "null context");
+    if (!c->mg_open) return fail(CDBG_E_STATE, "xchg_add_packed without xchg_begin");
+    c->mg_nb = (c->mg_nb + 63) / 64 * 64;                    // 16-byte stores of the streaming unpack
+    if (c->mg_np + n_pieces > c->mg_cap_p || c->mg_nb + n_bases > c->mg_cap_b || c->mg_nl + n_glog > c->mg_cap_l)
+        return fail(CDBG_E_PARAM, "xchg_add_packed exceeds the totals given to xchg_begin");
+    if (2 * (c->mg_np + n_pieces) >= 0x7FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 31-bit end ids");
+    if (n_packed != (n_bases + 63) / 64 * 16) return fail(CDBG_E_PARAM, "packed size %llu does not match %llu bases", (unsigned long long)n_packed, (unsigned long long)n_bases);
+    hipStream_t s = c->stream;
+    // offsets of the source rank's pieces inside its gap-free stream, recomputed here from its piece_n
+    // (context members: a step must not allocate or free device memory once the buffers of the first step exist)
+    DBuf<uint32_t>& lens = c->xr_lens; DBuf<uint64_t>& uoff = c->xr_uoff;
+    CK(lens.alloc(n_pieces, false)); CK(uoff.alloc(n_pieces + 1, false));
+    if (n_pieces) {
+        PackLenParams lp{ n_pieces, c->k, (const uint32_t*)piece_n, lens.p };
+        CDBG_LAUNCH(k_pack_lens, (n_pieces + 255) / 256, 256, s, lp);
+    }
+    CK(exscan_u32(c, lens.p, uoff.p, n_pieces));
+    HIPCK(hipStreamSynchronize(s));
+    uint64_t tu = 0; CK(read_u64(uoff.p + n_pieces, &tu));
+    if (tu != n_bases) return fail(CDBG_E_PARAM, "piece lengths (%llu bases) do not match the packed stream (%llu bases)", (unsigned long long)tu, (unsigned long long)n_bases);
+    const uint64_t chunks = (n_bases + 63) / 64;
+    if (chunks) {
+        StreamUnpackParams up{ chunks, (const uint8_t*)packed_bases, c->mg_bases.p + c->mg_nb, n_bases };
+        CDBG_LAUNCH(k_unpack_stream, (chunks + 255) / 256, 256, s, up);
+    }
+    MergeParams mp{ n_pieces, n_glog, c->mg_np, c->mg_nb, c->mg_nl, c->W,
+                    (const uint32_t*)piece_n, (const uint64_t*)piece_kc, uoff.p, (const uint64_t*)glog_keys, (const uint32_t*)glog_tag,
+                    c->mg_n.p, c->mg_kc.p, c->mg_boff.p, c->mg_gkeys.p, c->mg_gtag.p };
+    const uint64_t work = std::max(n_pieces, n_glog);
+    if (work) CDBG_LAUNCH(k_merge_append, std::min<uint64_t>((work + 255) / 256, MAX_GRID), 256, s, mp);
+    HIPCK(hipStreamSynchronize(s));
+    c->last_add_np = c->mg_np; c->last_add_nb = c->mg_nb; c->last_add_pieces = n_pieces;
+    c->mg_np += n_pieces; c->mg_nb += n_bases; c->mg_nl += n_glog;
+    return CDBG_OK;
+}
+// -all-abundance-counts: the abundances of this rank's pieces as a gap-free stream, one u32 per k-mer, in the piece
+// order of xchg_sizes_packed
+int xchg_abundance_values(cdbg_ctx* c, uint64_t* n_values) {
+    if (!c || !n_values) return fail(CDBG_E_PARAM, "null argument");
+    if (!c->prm.all_abundance_counts) return fail(CDBG_E_STATE, "context was created without all_abundance_counts");
+    if (c->stage != 2) return fail(CDBG_E_STATE, "xchg_* needs a compacted, not yet glued context");
+    CK(c->xp_aoff.alloc(c->n_pieces + 1, false));
+    CK(exscan_u32(c, c->piece_n.p, c->xp_aoff.p, c->n_pieces));
+    HIPCK(hipStreamSynchronize(c->stream));
+    CK(read_u64(c->xp_aoff.p + c->n_pieces, &c->xp_nab));
+    *n_values = c->xp_nab; c->xp_ab_ready = true;
+    return CDBG_OK;
+}
+int xchg_export_abundances(cdbg_ctx* c, void* dst_dev, uint64_t nbytes) {
+    if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage != 2 || !c->xp_ab_ready) return fail(CDBG_E_STATE, "xchg_export_abundances before xchg_abundance_values");
+    const uint64_t NP = c->n_pieces;
+    if (nbytes < c->xp_nab * sizeof(uint32_t)) return fail(CDBG_E_PARAM, "export buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)(c->xp_nab * sizeof(uint32_t)));
+    if (NP) {
+        AbStreamParams ap{ NP, c->k, 0, c->piece_n.p, c->xp_aoff.p, nullptr, c->piece_boff.p, 0, c->piece_ab.p, (uint32_t*)dst_dev };
+        CDBG_LAUNCH(k_ab_stream, (NP + 255) / 256, 256, c->stream, ap);
+    }
+    HIPCK(hipStreamSynchronize(c->stream));
+    return CDBG_OK;
+}
+// ... and the stream of the rank whose pieces the latest xchg_add_packed appended
+int xchg_add_abundances(cdbg_ctx* c, const void* ab_stream, uint64_t n_values) {
+    if (!c || !ab_stream) return fail(CDBG_E_PARAM, "null argument");
+    if (!c->prm.all_abundance_counts) return fail(CDBG_E_STATE, "context was created without all_abundance_counts");
+    if (!c->mg_open) return fail(CDBG_E_STATE, "xchg_add_abundances without xchg_begin");
+    const uint64_t NP = c->last_add_pieces;
+    CK(c->xr_aoff.alloc(NP + 1, false));
+    CK(exscan_u32(c, c->mg_n.p + c->last_add_np, c->xr_aoff.p, NP));
+    HIPCK(hipStreamSynchronize(c->stream));
+    uint64_t tot = 0; CK(read_u64(c->xr_aoff.p + NP, &tot));
+    if (n_values != tot) return fail(CDBG_E_PARAM, "abundance stream of %llu values does not match the %llu k-mers of the pieces added last", (unsigned long long)n_values, (unsigned long long)tot);
+    if (NP) {
+        AbStreamParams ap{ NP, c->k, 1, c->mg_n.p + c->last_add_np, c->xr_aoff.p, c->xr_uoff.p, nullptr, c->last_add_nb, c->mg_ab.p, (uint32_t*)ab_stream };
+        CDBG_LAUNCH(k_ab_stream, (NP + 255) / 256, 256, c->stream, ap);
+    }
+    HIPCK(hipStreamSynchronize(c->stream));
+    return CDBG_OK;
+}
+int xchg_end(cdbg_ctx* c) {
+    if (!c) return fail(CDBG_E_PARAM, "null context");
+    if (!c->mg_open) return fail(CDBG_E_STATE, "xchg_end without xchg_begin");
+    c->piece_n.swap(c->mg_n); c->piece_kc.swap(c->mg_kc); c->piece_boff.swap(c->mg_boff);
+    c->piece_bases.swap(c->mg_bases); c->glog_keys.swap(c->mg_gkeys); c->glog_tag.swap(c->mg_gtag);
+    if (c->prm.all_abundance_counts) c->piece_ab.swap(c->mg_ab);
+    c->n_pieces = c->mg_np; c->n_piece_bases = c->mg_nb; c->n_glog = c->mg_nl; c->glog_cap = c->mg_cap_l;
+    c->mg_open = false;
+    HIPCK(hipStreamSynchronize(c->stream));
+    return CDBG_OK;
+}
+
+// ---- multi-GPU: sharded junction join.  After xchg_end every rank holds the union of the glue records;
+// instead of every rank joining all of them, xchg_glue_join joins this rank's share of the junctions, the caller
+// MAX-all-reduces the int32 link arrays (cdbg_glue_links_export / _import) and cdbg_glue then ranks and emits ----
+int xchg_glue_join(cdbg_ctx* c, uint64_t* n_ends) {
+    if (!c || !n_ends) return fail(CDBG_E_PARAM, "null argument");
+    if (c->stage != 2) return fail(CDBG_E_STATE, "xchg_glue_join needs a compacted, not yet glued context");
+    int rc;
+    switch (c->W) { case 1: rc = glue_join_impl<1>(c, true); break; case 2: rc = glue_join_impl<2>(c, true); break; case 3: rc = glue_join_impl<3>(c, true); break; default: rc = glue_join_impl<4>(c, true); }
+    if (rc == CDBG_OK) *n_ends = 2 * c->n_pieces;
+    return rc;
+}
+
 // ---- multi-GPU glue exchange, driven by the library through the context's transport: every rank's pieces (lengths,
 // abundance sums, bases packed 4 per byte, no offsets) and junction log are all-gathered and merged in rank order
-// (cdbg_exchange_*); the junction hash-join is sharded by key hash and its result, one partner id per piece end, is
+// (xchg_*); the junction hash-join is sharded by key hash and its result, one partner id per piece end, is
 // combined with ONE MAX all-reduce (every end is set by exactly one rank) ----
 int glue_exchange(cdbg_ctx* c) {
     const int world = c->prm.world_size, W = c->W;
     hipStream_t s = c->stream;
     Timer t; CK(t.start(s));
-    uint64_t mine[4]; CK(cdbg_exchange_sizes_packed(c, mine));          // pieces, bases once unpacked, glue-log records, packed bytes
+    uint64_t mine[4]; CK(xchg_sizes_packed(c, mine));          // pieces, bases once unpacked, glue-log records, packed bytes
     std::vector<uint64_t> all((size_t)world * 4);
     if (c->tr.all_gather_u64(c->tr.user, mine, all.data(), 4) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
     auto col = [&](int r, int j) { return all[(size_t)r * 4 + j]; };
@@ -962,8 +1185,8 @@ int glue_exchange(cdbg_ctx* c) {
         CK(c->xg[a].alloc(tot + 16, false));
         const uint64_t nb = rcnt[a][c->prm.rank];
         CK(sendbuf.alloc(nb + 16, false));
-        if (a == 2) CK(cdbg_exchange_export_packed(c, sendbuf.p, nb + 16));
-        else CK(cdbg_exchange_export(c, a == 0 ? 0 : a == 1 ? 1 : a == 3 ? 4 : 5, sendbuf.p, nb + 16));
+        if (a == 2) CK(xchg_export_packed(c, sendbuf.p, nb + 16));
+        else CK(xchg_export(c, a == 0 ? 0 : a == 1 ? 1 : a == 3 ? 4 : 5, sendbuf.p, nb + 16));
         if (c->tr.all_gather_v(c->tr.user, sendbuf.p, nb, c->xg[a].p, roff[a].data(), rcnt[a].data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_v failed");
         for (int r = 0; r < world; ++r) if (r != c->prm.rank) c->comm_bytes += nb + rcnt[a][r];
     }
@@ -972,7 +1195,7 @@ int glue_exchange(cdbg_ctx* c) {
     // -all-abundance-counts: a sixth array, one u32 per k-mer of the rank's pieces
     std::vector<uint64_t> aoff(world), acnt(world);
     if (c->prm.all_abundance_counts) {
-        uint64_t nv = 0; CK(cdbg_exchange_abundance_values(c, &nv));
+        uint64_t nv = 0; CK(xchg_abundance_values(c, &nv));
         std::vector<uint64_t> allv(world);
         if (c->tr.all_gather_u64(c->tr.user, &nv, allv.data(), 1) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
         uint64_t tot = 0;
@@ -980,19 +1203,19 @@ int glue_exchange(cdbg_ctx* c) {
         CK(c->xp_ab.alloc(tot / 4 + 4, false));
         const uint64_t nb = acnt[c->prm.rank];
         CK(sendbuf.alloc(nb + 16, false));
-        CK(cdbg_exchange_export_abundances(c, sendbuf.p, nb + 16));
+        CK(xchg_export_abundances(c, sendbuf.p, nb + 16));
         if (c->tr.all_gather_v(c->tr.user, sendbuf.p, nb, c->xp_ab.p, aoff.data(), acnt.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_v failed");
         for (int r = 0; r < world; ++r) if (r != c->prm.rank) c->comm_bytes += nb + acnt[r];
     }
-    CK(cdbg_exchange_begin(c, tp, tb, tl));
+    CK(xchg_begin(c, tp, tb, tl));
     for (int r = 0; r < world; ++r) {
-        CK(cdbg_exchange_add_packed(c, col(r, 0), col(r, 1), col(r, 3), col(r, 2), c->xg[0].p + roff[0][r], c->xg[1].p + roff[1][r],
+        CK(xchg_add_packed(c, col(r, 0), col(r, 1), col(r, 3), col(r, 2), c->xg[0].p + roff[0][r], c->xg[1].p + roff[1][r],
                                     c->xg[2].p + roff[2][r], c->xg[3].p + roff[3][r], c->xg[4].p + roff[4][r]));
-        if (c->prm.all_abundance_counts) CK(cdbg_exchange_add_abundances(c, (const uint8_t*)c->xp_ab.p + aoff[r], acnt[r] / 4));
+        if (c->prm.all_abundance_counts) CK(xchg_add_abundances(c, (const uint8_t*)c->xp_ab.p + aoff[r], acnt[r] / 4));
     }
-    CK(cdbg_exchange_end(c));
+    CK(xchg_end(c));
     // sharded junction join
-    uint64_t n_ends = 0; CK(cdbg_glue_join(c, &n_ends));
+    uint64_t n_ends = 0; CK(xchg_glue_join(c, &n_ends));
     if (c->tr.all_reduce_max_i32(c->tr.user, c->link.p, n_ends) != 0) return fail(CDBG_E_INTERNAL, "transport all_reduce_max_i32 failed");
     c->comm_bytes += 2 * n_ends * 4 * (uint64_t)(world - 1) / (uint64_t)world;          // (ring all-reduce volume per rank)
     float ms = 0; CK(t.stop(&ms)); c->st.ms_exchange += ms;
@@ -1281,38 +1504,6 @@ int cdbg_count(cdbg_ctx* c) {
 }
 int cdbg_compact(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); (void)hipSetDevice(c->prm.device_id); DISPATCH_W(compact_impl) }
 int cdbg_glue(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); (void)hipSetDevice(c->prm.device_id); DISPATCH_W(glue_impl) }
-// ---- multi-GPU: sharded junction join.  After cdbg_exchange_end every rank holds the union of the glue records;
-// instead of every rank joining all of them, cdbg_glue_join joins this rank's share of the junctions, the caller
-// MAX-all-reduces the int32 link arrays (cdbg_glue_links_export / _import) and cdbg_glue then ranks and emits ----
-int cdbg_glue_join(cdbg_ctx* c, uint64_t* n_ends) {
-    if (!c || !n_ends) return fail(CDBG_E_PARAM, "null argument");
-    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_glue_join needs a compacted, not yet glued context");
-    int rc;
-    switch (c->W) { case 1: rc = glue_join_impl<1>(c, true); break; case 2: rc = glue_join_impl<2>(c, true); break; case 3: rc = glue_join_impl<3>(c, true); break; default: rc = glue_join_impl<4>(c, true); }
-    if (rc == CDBG_OK) *n_ends = 2 * c->n_pieces;
-    return rc;
-}
-int cdbg_glue_links_export(cdbg_ctx* c, void* dst_dev, uint64_t nbytes) {
-    if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
-    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    if (!c->joined) return fail(CDBG_E_STATE, "cdbg_glue_links_export before cdbg_glue_join");
-    const uint64_t have = 2 * c->n_pieces * sizeof(uint32_t);
-    if (nbytes < have) return fail(CDBG_E_PARAM, "link buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)have);
-    if (have) HIPCK(hipMemcpyAsync(dst_dev, c->link.p, have, hipMemcpyDeviceToDevice, c->stream));
-    HIPCK(hipStreamSynchronize(c->stream));
-    return CDBG_OK;
-}
-int cdbg_glue_links_import(cdbg_ctx* c, const void* src_dev, uint64_t nbytes) {
-    if (!c || !src_dev) return fail(CDBG_E_PARAM, "null argument");
-    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    if (!c->joined) return fail(CDBG_E_STATE, "cdbg_glue_links_import before cdbg_glue_join");
-    const uint64_t have = 2 * c->n_pieces * sizeof(uint32_t);
-    if (nbytes < have) return fail(CDBG_E_PARAM, "link buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)have);
-    if (have) HIPCK(hipMemcpyAsync(c->link.p, src_dev, have, hipMemcpyDeviceToDevice, c->stream));
-    HIPCK(hipStreamSynchronize(c->stream));
-    return CDBG_OK;
-}
 int cdbg_run(cdbg_ctx* c) { CK(cdbg_count(c)); CK(cdbg_compact(c)); return cdbg_glue(c); }
 int cdbg_link(cdbg_ctx* c) { if (!c) return fail(CDBG_E_PARAM, "null context"); (void)hipSetDevice(c->prm.device_id); DISPATCH_W(link_impl) }
 int cdbg_num_links(cdbg_ctx* c, uint64_t* n) {
@@ -1401,208 +1592,6 @@ int cdbg_fetch_unitigs(cdbg_ctx* c, uint64_t first, uint64_t n, char* seq_buf, u
     seq_off[n] = w;
     return CDBG_OK;
 }
-// ---- multi-GPU exchange: the pieces and glue records of every rank are gathered (RCCL all-gather
-// driven by the caller through torch.distributed; this library only copies device-to-device into / out
-// of caller-provided device buffers) and merged in rank order, after which cdbg_glue runs on the union ----
-int cdbg_exchange_sizes(cdbg_ctx* c, uint64_t out[3]) {
-    if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
-    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    if (c->prm.all_abundance_counts) return fail(CDBG_E_PARAM, "-all-abundance-counts travels with the packed exchange only (cdbg_exchange_sizes_packed)");
-    if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
-    if (c->direct_join) return fail(CDBG_E_STATE, "this single-rank context joined its junction records in place and keeps no log to exchange (create it with world_size > 1, or set CDBG_GLUE_LOG=1)");
-    out[0] = c->n_pieces; out[1] = c->n_piece_bases; out[2] = c->n_glog;
-    return CDBG_OK;
-}
-int cdbg_exchange_export(cdbg_ctx* c, int what, void* dst_dev, uint64_t nbytes) {
-    if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
-    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_export before cdbg_compact");
-    if (c->direct_join && what >= 4) return fail(CDBG_E_STATE, "this single-rank context keeps no junction log (CDBG_GLUE_LOG=1 keeps it)");
-    const void* src = nullptr; uint64_t have = 0;
-    switch (what) {
-        case 0: src = c->piece_n.p; have = c->n_pieces * sizeof(uint32_t); break;
-        case 1: src = c->piece_kc.p; have = c->n_pieces * sizeof(uint64_t); break;
-        case 2: src = c->piece_boff.p; have = c->n_pieces * sizeof(uint64_t); break;
-        case 3: src = c->piece_bases.p; have = c->n_piece_bases; break;
-        case 4: src = c->glog_keys.p; have = c->n_glog * (uint64_t)c->W * sizeof(uint64_t); break;
-        case 5: src = c->glog_tag.p; have = c->n_glog * sizeof(uint32_t); break;
-        default: return fail(CDBG_E_PARAM, "unknown export kind %d", what);
-    }
-    if (nbytes < have) return fail(CDBG_E_PARAM, "export buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)have);
-    if (have) HIPCK(hipMemcpyAsync(dst_dev, src, have, hipMemcpyDeviceToDevice, c->stream));
-    HIPCK(hipStreamSynchronize(c->stream));
-    return CDBG_OK;
-}
-int cdbg_exchange_begin(cdbg_ctx* c, uint64_t total_pieces, uint64_t total_bases, uint64_t total_glog) {
-    if (!c) return fail(CDBG_E_PARAM, "null context");
-    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_begin before cdbg_compact");
-    // the merged arrays are swapped with the context's own in cdbg_exchange_end: give them at least the same
-    // capacity, so that a re-run after cdbg_reset finds arrays that are large enough and never reallocates
-    CK(c->mg_n.alloc(total_pieces, false, c->piece_n.cap)); CK(c->mg_kc.alloc(total_pieces, false, c->piece_kc.cap));
-    CK(c->mg_boff.alloc(total_pieces, false, c->piece_boff.cap));
-    const uint64_t bases_slack = 64ull * 4096;               // the packed exchange starts every rank's bases on a 64-byte boundary
-    CK(c->mg_bases.alloc(total_bases + bases_slack, false, c->piece_bases.cap));
-    CK(c->mg_gkeys.alloc(total_glog * c->W, false, c->glog_keys.cap)); CK(c->mg_gtag.alloc(total_glog, false, c->glog_tag.cap));
-    if (c->prm.all_abundance_counts) CK(c->mg_ab.alloc(total_bases + bases_slack, false, c->piece_ab.cap));
-    c->mg_np = c->mg_nb = c->mg_nl = 0; c->mg_cap_p = total_pieces; c->mg_cap_b = total_bases + bases_slack; c->mg_cap_l = total_glog; c->mg_open = true;
-    return CDBG_OK;
-}
-int cdbg_exchange_add(cdbg_ctx* c, uint64_t n_pieces, uint64_t n_bases, uint64_t n_glog, const void* piece_n, const void* piece_kc,
-                      const void* piece_boff, const void* bases, const void* glog_keys, const void* glog_tag) {
-    if (!c) return fail(CDBG_E_PARAM, "null context");
-    if (!c->mg_open) return fail(CDBG_E_STATE, "cdbg_exchange_add without cdbg_exchange_begin");
-    if (c->mg_np + n_pieces > c->mg_cap_p || c->mg_nb + n_bases > c->mg_cap_b || c->mg_nl + n_glog > c->mg_cap_l)
-        return fail(CDBG_E_PARAM, "cdbg_exchange_add exceeds the totals given to cdbg_exchange_begin");
-    if (2 * (c->mg_np + n_pieces) >= 0x7FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 31-bit end ids");
-    if (n_bases) HIPCK(hipMemcpyAsync(c->mg_bases.p + c->mg_nb, bases, n_bases, hipMemcpyDeviceToDevice, c->stream));
-    MergeParams mp{ n_pieces, n_glog, c->mg_np, c->mg_nb, c->mg_nl, c->W,
-                    (const uint32_t*)piece_n, (const uint64_t*)piece_kc, (const uint64_t*)piece_boff, (const uint64_t*)glog_keys, (const uint32_t*)glog_tag,
-                    c->mg_n.p, c->mg_kc.p, c->mg_boff.p, c->mg_gkeys.p, c->mg_gtag.p };
-    const uint64_t work = std::max(n_pieces, n_glog);
-    if (work) CDBG_LAUNCH(k_merge_append, std::min<uint64_t>((work + 255) / 256, MAX_GRID), 256, c->stream, mp);
-    HIPCK(hipStreamSynchronize(c->stream));
-    c->mg_np += n_pieces; c->mg_nb += n_bases; c->mg_nl += n_glog;
-    return CDBG_OK;
-}
-// ---- packed variant of the exchange: bases travel as 2 bits (pieces padded to whole bytes, reservation gaps squeezed
-// out) and the per-piece base offsets do not travel at all -- the receiver recomputes them from the piece lengths ----
-int cdbg_exchange_sizes_packed(cdbg_ctx* c, uint64_t out[4]) {
-    if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
-    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
-    if (c->direct_join) return fail(CDBG_E_STATE, "this single-rank context joined its junction records in place and keeps no log to exchange (create it with world_size > 1, or set CDBG_GLUE_LOG=1)");
-    hipStream_t s = c->stream;
-    const uint64_t NP = c->n_pieces;
-    CK(c->xp_lens.alloc(NP, false)); CK(c->xp_uoff.alloc(NP + 1, false));
-    if (NP) {
-        PackLenParams lp{ NP, c->k, c->piece_n.p, c->xp_lens.p };
-        CDBG_LAUNCH(k_pack_lens, (NP + 255) / 256, 256, s, lp);
-    }
-    CK(exscan_u32(c, c->xp_lens.p, c->xp_uoff.p, NP));
-    HIPCK(hipStreamSynchronize(s));
-    CK(read_u64(c->xp_uoff.p + NP, &c->xp_unpacked));
-    const uint64_t chunks = (c->xp_unpacked + 63) / 64;      // 64 bases -> 16 bytes per lane
-    c->xp_bytes = chunks * 16;
-    CK(c->xp_dense.alloc(chunks * 64 + 64, false)); CK(c->xp_bases.alloc(c->xp_bytes + 16, false));
-    if (chunks) HIPCK(hipMemsetAsync(c->xp_dense.p + (chunks - 1) * 64, 'A', 64, s));     // tail padding of the last chunk
-    if (NP) {
-        SqueezeParams sq{ NP, c->xp_lens.p, c->xp_uoff.p, c->piece_boff.p, c->piece_bases.p, c->xp_dense.p };
-        CDBG_LAUNCH(k_squeeze_bases, (NP + 255) / 256, 256, s, sq);
-    }
-    if (chunks) {
-        StreamPackParams pp{ chunks, c->xp_dense.p, c->xp_bases.p, c->xp_unpacked };
-        CDBG_LAUNCH(k_pack_stream, (chunks + 255) / 256, 256, s, pp);
-    }
-    HIPCK(hipStreamSynchronize(s));
-    out[0] = NP; out[1] = c->xp_unpacked; out[2] = c->n_glog; out[3] = c->xp_bytes;
-    return CDBG_OK;
-}
-int cdbg_exchange_export_packed(cdbg_ctx* c, void* dst_dev, uint64_t nbytes) {
-    if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
-    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    if (c->stage != 2 || !c->xp_bases.p) return fail(CDBG_E_STATE, "cdbg_exchange_export_packed before cdbg_exchange_sizes_packed");
-    if (nbytes < c->xp_bytes) return fail(CDBG_E_PARAM, "export buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)c->xp_bytes);
-    if (c->xp_bytes) HIPCK(hipMemcpyAsync(dst_dev, c->xp_bases.p, c->xp_bytes, hipMemcpyDeviceToDevice, c->stream));
-    HIPCK(hipStreamSynchronize(c->stream));
-    return CDBG_OK;
-}
-int cdbg_exchange_add_packed(cdbg_ctx* c, uint64_t n_pieces, uint64_t n_bases, uint64_t n_packed, uint64_t n_glog, const void* piece_n, const void* piece_kc,
-                             const void* packed_bases, const void* glog_keys, const void* glog_tag) {
-    if (!c) return fail(CDBG_E_PARAM, "null context");
-    if (!c->mg_open) return fail(CDBG_E_STATE, "cdbg_exchange_add_packed without cdbg_exchange_begin");
-    c->mg_nb = (c->mg_nb + 63) / 64 * 64;                    // 16-byte stores of the streaming unpack
-    if (c->mg_np + n_pieces > c->mg_cap_p || c->mg_nb + n_bases > c->mg_cap_b || c->mg_nl + n_glog > c->mg_cap_l)
-        return fail(CDBG_E_PARAM, "cdbg_exchange_add_packed exceeds the totals given to cdbg_exchange_begin");
-    if (2 * (c->mg_np + n_pieces) >= 0x7FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 31-bit end ids");
-    if (n_packed != (n_bases + 63) / 64 * 16) return fail(CDBG_E_PARAM, "packed size %llu does not match %llu bases", (unsigned long long)n_packed, (unsigned long long)n_bases);
-    hipStream_t s = c->stream;
-    // offsets of the source rank's pieces inside its gap-free stream, recomputed here from its piece_n
-    // (context members: a step must not allocate or free device memory once the buffers of the first step exist)
-    DBuf<uint32_t>& lens = c->xr_lens; DBuf<uint64_t>& uoff = c->xr_uoff;
-    CK(lens.alloc(n_pieces, false)); CK(uoff.alloc(n_pieces + 1, false));
-    if (n_pieces) {
-        PackLenParams lp{ n_pieces, c->k, (const uint32_t*)piece_n, lens.p };
-        CDBG_LAUNCH(k_pack_lens, (n_pieces + 255) / 256, 256, s, lp);
-    }
-    CK(exscan_u32(c, lens.p, uoff.p, n_pieces));
-    HIPCK(hipStreamSynchronize(s));
-    uint64_t tu = 0; CK(read_u64(uoff.p + n_pieces, &tu));
-    if (tu != n_bases) return fail(CDBG_E_PARAM, "piece lengths (%llu bases) do not match the packed stream (%llu bases)", (unsigned long long)tu, (unsigned long long)n_bases);
-    const uint64_t chunks = (n_bases + 63) / 64;
-    if (chunks) {
-        StreamUnpackParams up{ chunks, (const uint8_t*)packed_bases, c->mg_bases.p + c->mg_nb, n_bases };
-        CDBG_LAUNCH(k_unpack_stream, (chunks + 255) / 256, 256, s, up);
-    }
-    MergeParams mp{ n_pieces, n_glog, c->mg_np, c->mg_nb, c->mg_nl, c->W,
-                    (const uint32_t*)piece_n, (const uint64_t*)piece_kc, uoff.p, (const uint64_t*)glog_keys, (const uint32_t*)glog_tag,
-                    c->mg_n.p, c->mg_kc.p, c->mg_boff.p, c->mg_gkeys.p, c->mg_gtag.p };
-    const uint64_t work = std::max(n_pieces, n_glog);
-    if (work) CDBG_LAUNCH(k_merge_append, std::min<uint64_t>((work + 255) / 256, MAX_GRID), 256, s, mp);
-    HIPCK(hipStreamSynchronize(s));
-    c->last_add_np = c->mg_np; c->last_add_nb = c->mg_nb; c->last_add_pieces = n_pieces;
-    c->mg_np += n_pieces; c->mg_nb += n_bases; c->mg_nl += n_glog;
-    return CDBG_OK;
-}
-// -all-abundance-counts: the abundances of this rank's pieces as a gap-free stream, one u32 per k-mer, in the piece
-// order of cdbg_exchange_sizes_packed
-int cdbg_exchange_abundance_values(cdbg_ctx* c, uint64_t* n_values) {
-    if (!c || !n_values) return fail(CDBG_E_PARAM, "null argument");
-    (void)hipSetDevice(c->prm.device_id);
-    if (!c->prm.all_abundance_counts) return fail(CDBG_E_STATE, "context was created without all_abundance_counts");
-    if (c->stage != 2) return fail(CDBG_E_STATE, "cdbg_exchange_* needs a compacted, not yet glued context");
-    CK(c->xp_aoff.alloc(c->n_pieces + 1, false));
-    CK(exscan_u32(c, c->piece_n.p, c->xp_aoff.p, c->n_pieces));
-    HIPCK(hipStreamSynchronize(c->stream));
-    CK(read_u64(c->xp_aoff.p + c->n_pieces, &c->xp_nab));
-    *n_values = c->xp_nab; c->xp_ab_ready = true;
-    return CDBG_OK;
-}
-int cdbg_exchange_export_abundances(cdbg_ctx* c, void* dst_dev, uint64_t nbytes) {
-    if (!c || !dst_dev) return fail(CDBG_E_PARAM, "null argument");
-    (void)hipSetDevice(c->prm.device_id);
-    if (c->stage != 2 || !c->xp_ab_ready) return fail(CDBG_E_STATE, "cdbg_exchange_export_abundances before cdbg_exchange_abundance_values");
-    const uint64_t NP = c->n_pieces;
-    if (nbytes < c->xp_nab * sizeof(uint32_t)) return fail(CDBG_E_PARAM, "export buffer too small (%llu < %llu)", (unsigned long long)nbytes, (unsigned long long)(c->xp_nab * sizeof(uint32_t)));
-    if (NP) {
-        AbStreamParams ap{ NP, c->k, 0, c->piece_n.p, c->xp_aoff.p, nullptr, c->piece_boff.p, 0, c->piece_ab.p, (uint32_t*)dst_dev };
-        CDBG_LAUNCH(k_ab_stream, (NP + 255) / 256, 256, c->stream, ap);
-    }
-    HIPCK(hipStreamSynchronize(c->stream));
-    return CDBG_OK;
-}
-// ... and the stream of the rank whose pieces the latest cdbg_exchange_add_packed appended
-int cdbg_exchange_add_abundances(cdbg_ctx* c, const void* ab_stream, uint64_t n_values) {
-    if (!c || !ab_stream) return fail(CDBG_E_PARAM, "null argument");
-    (void)hipSetDevice(c->prm.device_id);
-    if (!c->prm.all_abundance_counts) return fail(CDBG_E_STATE, "context was created without all_abundance_counts");
-    if (!c->mg_open) return fail(CDBG_E_STATE, "cdbg_exchange_add_abundances without cdbg_exchange_begin");
-    const uint64_t NP = c->last_add_pieces;
-    CK(c->xr_aoff.alloc(NP + 1, false));
-    CK(exscan_u32(c, c->mg_n.p + c->last_add_np, c->xr_aoff.p, NP));
-    HIPCK(hipStreamSynchronize(c->stream));
-    uint64_t tot = 0; CK(read_u64(c->xr_aoff.p + NP, &tot));
-    if (n_values != tot) return fail(CDBG_E_PARAM, "abundance stream of %llu values does not match the %llu k-mers of the pieces added last", (unsigned long long)n_values, (unsigned long long)tot);
-    if (NP) {
-        AbStreamParams ap{ NP, c->k, 1, c->mg_n.p + c->last_add_np, c->xr_aoff.p, c->xr_uoff.p, nullptr, c->last_add_nb, c->mg_ab.p, (uint32_t*)ab_stream };
-        CDBG_LAUNCH(k_ab_stream, (NP + 255) / 256, 256, c->stream, ap);
-    }
-    HIPCK(hipStreamSynchronize(c->stream));
-    return CDBG_OK;
-}
-int cdbg_exchange_end(cdbg_ctx* c) {
-    if (!c) return fail(CDBG_E_PARAM, "null context");
-    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    if (!c->mg_open) return fail(CDBG_E_STATE, "cdbg_exchange_end without cdbg_exchange_begin");
-    c->piece_n.swap(c->mg_n); c->piece_kc.swap(c->mg_kc); c->piece_boff.swap(c->mg_boff);
-    c->piece_bases.swap(c->mg_bases); c->glog_keys.swap(c->mg_gkeys); c->glog_tag.swap(c->mg_gtag);
-    if (c->prm.all_abundance_counts) c->piece_ab.swap(c->mg_ab);
-    c->n_pieces = c->mg_np; c->n_piece_bases = c->mg_nb; c->n_glog = c->mg_nl; c->glog_cap = c->mg_cap_l;
-    c->mg_open = false;
-    HIPCK(hipStreamSynchronize(c->stream));
-    return CDBG_OK;
-}
-
 int cdbg_fetch_unitig_abundances(cdbg_ctx* c, uint64_t first, uint64_t n, uint32_t* ab, uint64_t* ab_off) {
     if (!c || !ab || !ab_off) return fail(CDBG_E_PARAM, "null argument");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)

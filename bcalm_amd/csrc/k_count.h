@@ -652,6 +652,20 @@ __global__ void k_repair_scatter(RepairParams P) {       // one thread per spill
 }
 
 
+// ---- multi-GPU, single-pass scan: squeeze the capped regions into the exact owner-major layout that travels ----
+// (slot = owner * npl + local partition; off = exclusive scan of the fill counts; one wave per slot, grid-stride)
+struct PackRegionParams { const uint64_t* regions; const uint32_t* fill; const uint64_t* off; uint64_t n_slots; uint32_t part_cap; int RW; uint64_t* out; };
+__global__ void k_pack_regions(PackRegionParams P) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t sl = wave; sl < P.n_slots; sl += n_waves) {
+        const uint64_t n = (uint64_t)P.fill[sl] * P.RW;
+        const uint64_t* src = P.regions + sl * P.part_cap * P.RW;
+        uint64_t* dst = P.out + P.off[sl] * P.RW;
+        for (uint64_t i = lane; i < n; i += 64) dst[i] = src[i];
+    }
+}
+
 // ---- multi-GPU (reads sharded over the ranks): merge the record blocks received from every rank ----
 // Sender s delivered, for each of this rank's partitions lp, xcnt[s][lp] records, sorted by lp, at record index
 // xbase[s] + xoff[s][lp] of the receive buffer.  Partition lp of the merged array = its segments in sender order.

@@ -38,8 +38,12 @@ typedef struct cdbg_params {
     int world_size;           /* GPUs sharing the minimizer space (power of two); 1 = single GPU */
     int rank;                 /* this context owns partitions p with p % world_size == rank */
     int all_abundance_counts; /* -all-abundance-counts (README.md:74-80): keep the abundance of every k-mer of every unitig */
-    int emit_replicated;      /* world_size > 1: 0 = every rank emits the unitigs whose first piece it owns (the union over the
+    int emit_replicated;      /* world_size > 1: 0 = every rank emits the unitigs whose head piece it owns (the union over the
                                  ranks is the graph); 1 = every rank emits the complete set (the CLI's rank 0 writes one file) */
+    int reads_replicated;     /* world_size > 1: 0 = every rank holds a SHARD of the reads and the super-k-mer records travel to
+                                 the partition owners; 1 = every rank holds ALL the reads and scans them for
+                                 its own partitions only -- no record exchange (X0: the better choice on 2-4 GPUs, where one
+                                 xGMI link would have to carry a large share of the records; free with cdbg_generate_reads) */
 } cdbg_params;
 
 typedef struct cdbg_stats_t {
@@ -140,50 +144,6 @@ int cdbg_comm_unique_id(void* out_128_bytes);
 int cdbg_comm_init_rccl(cdbg_ctx* ctx, const void* unique_id_128_bytes);
 /* bytes this rank sent + received through the transport since cdbg_reset (bench.py reports them) */
 int cdbg_comm_bytes(cdbg_ctx* ctx, uint64_t* out);
-
-/* Lower-level pieces of the glue exchange, kept for callers that move the bytes themselves and for tests: */
-/* (one process per GPU, minimizer partitions sharded by cdbg_params.world_size/rank; every
- * rank scans the same reads and counts / compacts only its own partitions).  After cdbg_compact the
- * pieces and glue records of all ranks are gathered -- the caller moves the bytes with an RCCL
- * all-gather (torch.distributed); this library only copies device-to-device -- and merged in rank order:
- *   cdbg_exchange_sizes   -> {piece ids, piece base bytes, glue-log records} of this rank
- *   cdbg_exchange_export  -> copy one array (what: 0 piece_n u32, 1 piece_kc u64, 2 piece_boff u64,
- *                            3 piece bases u8, 4 glue keys u64 x W, 5 glue tags u32) into dst_dev
- *   cdbg_exchange_begin / _add (once per rank, in rank order, own data included) / _end
- * then cdbg_glue runs on the union (every rank obtains the complete unitig set). */
-int cdbg_exchange_sizes(cdbg_ctx* ctx, uint64_t out[3]);
-int cdbg_exchange_export(cdbg_ctx* ctx, int what, void* dst_dev, uint64_t nbytes);
-int cdbg_exchange_begin(cdbg_ctx* ctx, uint64_t total_pieces, uint64_t total_bases, uint64_t total_glog);
-int cdbg_exchange_add(cdbg_ctx* ctx, uint64_t n_pieces, uint64_t n_bases, uint64_t n_glog, const void* piece_n,
-                      const void* piece_kc, const void* piece_boff, const void* bases, const void* glog_keys,
-                      const void* glog_tag);
-int cdbg_exchange_end(cdbg_ctx* ctx);
-/* Packed variant (what bcalm_amd/dist.py uses): the piece bases travel as ONE gap-free stream at 2 bits per base (padded
- * to 64 bases) and the base offsets do not travel -- the receiver recomputes them from the piece lengths.  cdbg_exchange_sizes_packed packs and returns {piece ids, bases once unpacked, glue-log records, packed bytes};
- * piece_n / piece_kc / glue-log arrays are exported with cdbg_exchange_export (what = 0, 1, 4, 5), the packed bases with
- * cdbg_exchange_export_packed; cdbg_exchange_begin takes the totals of the first three; one cdbg_exchange_add_packed per
- * rank in rank order; cdbg_exchange_end as before. */
-int cdbg_exchange_sizes_packed(cdbg_ctx* ctx, uint64_t out[4]);
-int cdbg_exchange_export_packed(cdbg_ctx* ctx, void* dst_dev, uint64_t nbytes);
-int cdbg_exchange_add_packed(cdbg_ctx* ctx, uint64_t n_pieces, uint64_t n_bases, uint64_t n_packed, uint64_t n_glog,
-                             const void* piece_n, const void* piece_kc, const void* packed_bases, const void* glog_keys,
-                             const void* glog_tag);
-/* Contexts created with all_abundance_counts = 1 (-all-abundance-counts, README.md:74-80, across ranks): the abundances of
- * a rank's pieces travel as one more gap-free stream, one u32 per k-mer, same piece order.  Sender:
- * cdbg_exchange_abundance_values (how many), cdbg_exchange_export_abundances; receiver: cdbg_exchange_add_abundances
- * right after the cdbg_exchange_add_packed of the same rank. */
-int cdbg_exchange_abundance_values(cdbg_ctx* ctx, uint64_t* n_values);
-int cdbg_exchange_export_abundances(cdbg_ctx* ctx, void* dst_dev, uint64_t nbytes);
-int cdbg_exchange_add_abundances(cdbg_ctx* ctx, const void* ab_stream, uint64_t n_values);
-/* Sharded junction join (optional, after cdbg_exchange_end): instead of every rank hash-joining ALL glue
- * records inside cdbg_glue, cdbg_glue_join joins only the junctions whose key hash selects this rank and
- * leaves link[end] = -1 for the others.  The caller exports the int32 link array (n_ends entries), combines
- * the arrays of all ranks with an element-wise MAX all-reduce (every end is set by exactly one rank), imports
- * the result and calls cdbg_glue, which then only ranks the chains and emits.  Without these calls cdbg_glue
- * performs the whole join itself on every rank. */
-int cdbg_glue_join(cdbg_ctx* ctx, uint64_t* n_ends);
-int cdbg_glue_links_export(cdbg_ctx* ctx, void* dst_dev, uint64_t nbytes);
-int cdbg_glue_links_import(cdbg_ctx* ctx, const void* src_dev, uint64_t nbytes);
 
 /* Results.  Solid k-mers: kmers has (k+1)-byte stride, NUL-terminated ASCII, canonical strand. */
 int cdbg_num_solid(cdbg_ctx* ctx, uint64_t* n);

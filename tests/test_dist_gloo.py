@@ -23,9 +23,23 @@ def _shard(text, world, rank):
 
 
 def _run_sharded(api, cdist, lib, orc, text, k, amin, world, rank, steps=1, **kw):
+    kw = dict(kw)
+    scan_mode = kw.pop("scan_mode", None)                # CDBG_SCAN_MODE: the single-pass capped scan + region packing at test sizes
+    empty_rank = kw.pop("empty_rank", None)              # this rank receives no reads at all (a small input dealt out in chunks)
+    if scan_mode:
+        os.environ["CDBG_SCAN_MODE"] = scan_mode
+    else:
+        os.environ.pop("CDBG_SCAN_MODE", None)
     g = api.Graph(k, amin, lib=lib, world_size=world, rank=rank, **kw)
     cdist.TorchTransport(dist).attach(g)
-    g.push_text(_shard(text, world, rank))
+    if kw.get("reads_replicated"):
+        g.push_text(text)                                # X0: every rank holds all the reads
+    elif empty_rank is not None:
+        if rank != empty_rank:
+            others = [r for r in range(world) if r != empty_rank]
+            g.push_text(_shard(text, world - 1, others.index(rank)))
+    else:
+        g.push_text(_shard(text, world, rank))
     out = None
     for i in range(steps):
         if i:
@@ -102,16 +116,20 @@ def test_two_rank_gloo():
     _launch(2, [(31, 2, 300, 150, 3, {"steps": 2}), (31, 1, 150, 150, 3, {"log2_partitions": 6}),
                 (55, 2, 200, 150, 4, {"log2_partitions": 5}), (127, 1, 40, 600, 5, {"log2_partitions": 4}),
                 (31, 2, 200, 150, 3, {"emit_replicated": True}),
-                (31, 2, 250, 150, 3, {"all_abundance_counts": True}), (55, 1, 100, 150, 4, {"all_abundance_counts": True, "emit_replicated": True})], 29500, 600)
+                (31, 2, 250, 150, 3, {"all_abundance_counts": True}), (55, 1, 100, 150, 4, {"all_abundance_counts": True, "emit_replicated": True}),
+                (31, 2, 300, 150, 3, {"reads_replicated": True}), (31, 2, 300, 150, 3, {"scan_mode": "capped", "log2_partitions": 6}),
+                (55, 2, 200, 150, 4, {"scan_mode": "capped", "reads_replicated": True}), (31, 2, 200, 150, 3, {"empty_rank": 1}),
+                (30, 2, 250, 150, 3, {}), (64, 1, 100, 300, 5, {"log2_partitions": 4})], 29500, 400)
 
 
 def test_four_rank_gloo():
-    _launch(4, [(31, 2, 400, 150, 3, {}), (55, 1, 160, 150, 4, {"log2_partitions": 7}), (127, 2, 80, 500, 5, {"log2_partitions": 5})], 31500, 600)
+    _launch(4, [(31, 2, 400, 150, 3, {}), (55, 1, 160, 150, 4, {"log2_partitions": 7}), (127, 2, 80, 500, 5, {"log2_partitions": 5}),
+                (31, 2, 400, 150, 3, {"reads_replicated": True}), (31, 2, 300, 150, 3, {"scan_mode": "capped", "empty_rank": 3})], 31500, 300)
 
 
 def test_eight_rank_gloo():
     """the world size of the full node: partitions split eight ways (3 rank bits), eight-way sharded join"""
-    _launch(8, [(31, 2, 400, 150, 3, {"log2_partitions": 7}), (55, 1, 160, 150, 4, {"log2_partitions": 7})], 33500, 900)
+    _launch(8, [(31, 2, 400, 150, 3, {"log2_partitions": 7}), (55, 1, 160, 150, 4, {"log2_partitions": 7})], 33500, 400)
 
 
 def test_multi_rank_needs_a_transport():

@@ -234,7 +234,7 @@ def test_abundance_saturates_at_31_bits(hip, log_np):
     st = g.stats(); ut = g.unitigs(); solid = g.solid_kmers() if hasattr(g, "solid_kmers") else None
     g.close()
     assert st["n_distinct"] == 1 and st["n_solid"] == 1 and st["n_unitigs"] == 1
-    assert ut == [("A" * 31, (1 << 31) - 1)]
+    assert len(ut) == 1 and ut[0][0] in ("A" * 31, "T" * 31) and ut[0][1] == (1 << 31) - 1      # (orientation is unspecified, README.md:84-87)
 
 
 def test_streaming_scan_while_ingesting_gpu(oracle, oracle_1m, hip, monkeypatch):
