@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #endif
 #include <cstring>
+#include <mutex>
+#include <string>
 #include <vector>
 
 namespace cdbg {
@@ -32,17 +34,22 @@ struct RcclApi {
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
-    void* lib = nullptr;
+    void* lib = nullptr;                                // published only after every symbol has resolved
+    std::mutex mu;
+    // (several host threads may initialise their contexts at once -- one thread per GPU in the CLI)
     bool load(std::string& err) {
+        std::lock_guard<std::mutex> g(mu);
         if (lib) return true;
+        void* h = nullptr;
         const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-        for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
-        if (!lib) { err = "cannot load librccl.so.1"; return false; }
-#define CDBG_RCCL_SYM(field, name) do { *(void**)(&field) = dlsym(lib, name); if (!field) { err = std::string("librccl lacks ") + name; return false; } } while (0)
+        for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) { err = "cannot load librccl.so.1"; return false; }
+#define CDBG_RCCL_SYM(field, name) do { *(void**)(&field) = dlsym(h, name); if (!field) { err = std::string("librccl lacks ") + name; return false; } } while (0)
         CDBG_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); CDBG_RCCL_SYM(CommInitRank, "ncclCommInitRank"); CDBG_RCCL_SYM(CommDestroy, "ncclCommDestroy");
         CDBG_RCCL_SYM(GroupStart, "ncclGroupStart"); CDBG_RCCL_SYM(GroupEnd, "ncclGroupEnd"); CDBG_RCCL_SYM(Send, "ncclSend"); CDBG_RCCL_SYM(Recv, "ncclRecv");
         CDBG_RCCL_SYM(AllGather, "ncclAllGather"); CDBG_RCCL_SYM(AllReduce, "ncclAllReduce"); CDBG_RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef CDBG_RCCL_SYM
+        lib = h;
         return true;
     }
 };
@@ -68,11 +75,13 @@ struct RcclComm {
     static int all_to_all_v(void* u, const void* send, const uint64_t* soff, const uint64_t* scnt, void* recv, const uint64_t* roff, const uint64_t* rcnt) {
         RcclComm* c = (RcclComm*)u; RcclApi& A = rccl_api();
         if (!c->ok(A.GroupStart(), "ncclGroupStart")) return -1;
-        for (int r = 0; r < c->world; ++r) {
+        bool good = true;
+        for (int r = 0; r < c->world && good; ++r) {
             if (r == c->rank) continue;                  // the own block is a device-to-device copy
-            if (scnt[r] && !c->ok(A.Send((const char*)send + soff[r], scnt[r], 1, r, c->comm, c->stream), "ncclSend")) return -1;
-            if (rcnt[r] && !c->ok(A.Recv((char*)recv + roff[r], rcnt[r], 1, r, c->comm, c->stream), "ncclRecv")) return -1;
+            if (scnt[r] && !c->ok(A.Send((const char*)send + soff[r], scnt[r], 1, r, c->comm, c->stream), "ncclSend")) good = false;
+            if (good && rcnt[r] && !c->ok(A.Recv((char*)recv + roff[r], rcnt[r], 1, r, c->comm, c->stream), "ncclRecv")) good = false;
         }
+        if (!good) { (void)A.GroupEnd(); return -1; }    // never leave the group open
         if (!c->ok(A.GroupEnd(), "ncclGroupEnd")) return -1;
         if (scnt[c->rank] && !c->hip_ok(hipMemcpyAsync((char*)recv + roff[c->rank], (const char*)send + soff[c->rank], scnt[c->rank], hipMemcpyDeviceToDevice, c->stream), "D2D")) return -1;
         return c->hip_ok(hipStreamSynchronize(c->stream), "sync") ? 0 : -1;
@@ -80,11 +89,13 @@ struct RcclComm {
     static int all_gather_v(void* u, const void* send, uint64_t nbytes, void* recv, const uint64_t* roff, const uint64_t* rcnt) {
         RcclComm* c = (RcclComm*)u; RcclApi& A = rccl_api();
         if (!c->ok(A.GroupStart(), "ncclGroupStart")) return -1;
-        for (int r = 0; r < c->world; ++r) {
+        bool good = true;
+        for (int r = 0; r < c->world && good; ++r) {
             if (r == c->rank) continue;
-            if (nbytes && !c->ok(A.Send(send, nbytes, 1, r, c->comm, c->stream), "ncclSend")) return -1;
-            if (rcnt[r] && !c->ok(A.Recv((char*)recv + roff[r], rcnt[r], 1, r, c->comm, c->stream), "ncclRecv")) return -1;
+            if (nbytes && !c->ok(A.Send(send, nbytes, 1, r, c->comm, c->stream), "ncclSend")) good = false;
+            if (good && rcnt[r] && !c->ok(A.Recv((char*)recv + roff[r], rcnt[r], 1, r, c->comm, c->stream), "ncclRecv")) good = false;
         }
+        if (!good) { (void)A.GroupEnd(); return -1; }
         if (!c->ok(A.GroupEnd(), "ncclGroupEnd")) return -1;
         if (nbytes && !c->hip_ok(hipMemcpyAsync((char*)recv + roff[c->rank], send, nbytes, hipMemcpyDeviceToDevice, c->stream), "D2D")) return -1;
         return c->hip_ok(hipStreamSynchronize(c->stream), "sync") ? 0 : -1;

@@ -81,6 +81,9 @@ struct JoinWaveLds { uint64_t keys[2 * JB_CAP * W]; uint32_t a[2 * JB_CAP], b[2 
 struct JoinBucketParams {
     const uint32_t* jfill; const uint64_t* jrecs; uint32_t n_buckets;
     uint32_t* link; uint64_t* stats;                    // stats[0] junctions joined
+    // multi-GPU sharded glue (k_dglue.h): the joined ends belong to other ranks -- instead of link[] writes, every joined
+    // junction appends the two pairs (end, partner), (partner, end) to a list (one reservation per bucket)
+    uint2* pairs; uint64_t* pair_cursor; uint64_t pair_cap; uint32_t* error;
 };
 template <int W>
 __global__ void __launch_bounds__(JB_THREADS) k_join_bucket(JoinBucketParams P) {
@@ -136,12 +139,28 @@ __global__ void __launch_bounds__(JB_THREADS) k_join_bucket(JoinBucketParams P) 
         }
         CDBG_WAVE_SYNC();
         // a junction with two ends, confirmed 1-1 by its owning bucket (a CONFIRM record, or the flag riding on an end)
+        uint64_t pbase = 0;
+        if (P.pairs) {                                   // pair output: count the bucket's joins first, ONE reservation
+            uint32_t nj = 0;
+            for (uint32_t s = lane; s < TSJ; s += 64) {
+                if (L.keys[(uint64_t)s * W + (W - 1)] == KEY_EMPTY) continue;
+                const uint32_t a = L.a[s], b = L.b[s];
+                if (a && b && (((a | b) & 0x80000000u) || L.conf[s])) ++nj;
+            }
+            const uint32_t incl = wave_incl_sum_u32(nj), tot = wave_readlane_u32(incl, 63);
+            uint32_t lo = 0, hi = 0;
+            if (lane == 0 && tot) { const uint64_t o = atomic_add_u64(P.pair_cursor, 2ull * tot); lo = (uint32_t)o; hi = (uint32_t)(o >> 32); }
+            pbase = (((uint64_t)wave_readlane_u32(hi, 0) << 32) | wave_readlane_u32(lo, 0)) + 2ull * (incl - nj);
+            if (tot && pbase + 2ull * nj > P.pair_cap) { *P.error = 9; pbase = ~0ull; }
+        }
         for (uint32_t s = lane; s < TSJ; s += 64) {
             if (L.keys[(uint64_t)s * W + (W - 1)] == KEY_EMPTY) continue;
             const uint32_t a = L.a[s], b = L.b[s];
             if (a && b && (((a | b) & 0x80000000u) || L.conf[s])) {
                 const uint32_t ea = (a & 0x7FFFFFFFu) - 1u, eb = (b & 0x7FFFFFFFu) - 1u;
-                P.link[ea] = eb; P.link[eb] = ea;
+                if (P.pairs) {
+                    if (pbase != ~0ull) { uint2 p0; p0.x = ea; p0.y = eb; uint2 p1; p1.x = eb; p1.y = ea; P.pairs[pbase] = p0; P.pairs[pbase + 1] = p1; pbase += 2; }
+                } else { P.link[ea] = eb; P.link[eb] = ea; }
                 ++joined;
             }
             L.keys[(uint64_t)s * W + (W - 1)] = KEY_EMPTY; L.a[s] = 0; L.b[s] = 0; L.conf[s] = 0;

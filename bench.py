@@ -191,6 +191,10 @@ def main():
                     help="N>1: sharded = ONE graph over --reads reads: reads and minimizer partitions split over the ranks, records and glue "
                          "data exchanged over RCCL inside libcdbg (strong scaling); independent = one read set per rank, no collective (weak scaling)")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded (collective) code path even with one rank (testing)")
+    ap.add_argument("--read-placement", dest="read_placement", choices=["auto", "replicated", "sharded"], default="auto",
+                    help="N>1, --mode sharded: replicated = every rank generates ALL reads and scans them for its own partitions, no record "
+                         "exchange (SURVEY.md 8e X0); sharded = every rank holds 1/N of the reads, super-k-mer records all-to-all-v'd to the "
+                         "partition owners (X1); auto = replicated on 2-4 GPUs (one xGMI link per peer would carry 1/N^2 of 25.6 GB), sharded on 8")
     a = ap.parse_args()
     CFG = {3: dict(k=31, read_len=150, reads=100_000_000, name="BASELINE config 3"),
            4: dict(k=55, read_len=150, reads=125_000_000, name="BASELINE config 4, the share of one of its 8 GPUs (1 G reads / 8)"),
@@ -237,15 +241,22 @@ def main():
         from bcalm_amd import dist as cdist
         if a.force_dist and world == 1:
             os.environ["CDBG_FORCE_MULTI"] = "1"
-        g = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank, world_size=world, rank=rank)
+        replicated = a.read_placement == "replicated" or (a.read_placement == "auto" and 1 < world <= 4)
+        g = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank, world_size=world, rank=rank, reads_replicated=replicated)
         cdist.init_rccl(g, dist, device=torch.device("cuda", local_rank))
-        share = (a.reads + world - 1) // world
-        first = rank * share
-        g.generate_reads(max(0, min(share, a.reads - first)), a.read_len, a.cfg, first_read=first, total_reads=a.reads)
+        if replicated:
+            g.generate_reads(a.reads, a.read_len, a.cfg, first_read=0, total_reads=a.reads)
+        else:
+            share = (a.reads + world - 1) // world
+            first = rank * share
+            g.generate_reads(max(0, min(share, a.reads - first)), a.read_len, a.cfg, first_read=first, total_reads=a.reads)
 
         def step():
             g.run()
-            return {"transport": "RCCL inside libcdbg.so (all-to-all-v of records, all-gather of pieces + junction log, MAX all-reduce of partner ids)",
+            return {"reads": "replicated on every rank (X0: no record exchange)" if replicated else "sharded (X1: records all-to-all-v'd to the partition owners)",
+                    "transport": "RCCL inside libcdbg.so: all-to-all-v only -- junction records to their key owners, joined pairs to the end owners, "
+                                 "ranking queries / replies per round, every piece once to the owner of its unitig's head",
+                    "ranking_rounds": g.stats()["n_glue_rounds"],
                     "bytes_sent_plus_received_by_rank0": g.comm_bytes()}
     else:
         # N == 1, or --mode independent: every rank runs the full path on its own read set
@@ -333,7 +344,7 @@ def main():
                                    % (CFG["name"], a.reads, a.read_len, "in total (one graph)" if sharded else "per GPU", a.k, a.abundance_min),
                        "timing_boundary": "reads resident in HBM (ASCII) -> unitigs + KC resident in HBM; includes the stages' host syncs",
                        "multi_gpu": ("single GPU" if world == 1 else
-                                     "sharded: reads split over the ranks, RCCL all-to-all-v of super-k-mer records to the partition owners, all-gather of pieces + junction log, sharded junction join, owner-sharded emission (one graph; set_digest comparable with the N=1 line)"
+                                     "sharded: minimizer partitions p mod N; reads replicated (2-4 GPUs) or split with an all-to-all-v of super-k-mer records (8 GPUs); glue sharded by owner -- junction records, joined pairs, ranking queries and pieces each travel once over RCCL all-to-all-v (one graph; set_digest comparable with the N=1 line)"
                                      if sharded else "independent read sets per rank (no collective)"),
                        "exchange": xinfo,
                        "minimizer_size": st["minimizer_size"], "log2_partitions": st["log2_partitions"]},

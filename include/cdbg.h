@@ -67,6 +67,8 @@ typedef struct cdbg_stats_t {
     uint64_t n_launch_scan, n_launch_count, n_launch_compact;   /* workgroups launched */
     uint64_t n_multipass_partitions; /* partitions whose distinct k-mers did not fit one LDS pass (multi-pass kernel) */
     uint64_t n_tiles_overlapped;     /* scan tiles processed while the input was still arriving (cdbg_expect_input) */
+    uint64_t n_glue_rounds;          /* multi-GPU sharded glue: query / reply rounds of the distributed list ranking (0: single GPU, or
+                                        the replicated exchange -- emit_replicated, or closed chains across ranks) */
 } cdbg_stats_t;
 
 /* error codes */

@@ -25,6 +25,7 @@ def _shard(text, world, rank):
 def _run_sharded(api, cdist, lib, orc, text, k, amin, world, rank, steps=1, **kw):
     kw = dict(kw)
     scan_mode = kw.pop("scan_mode", None)                # CDBG_SCAN_MODE: the single-pass capped scan + region packing at test sizes
+    kw.pop("expect_fallback", None)
     empty_rank = kw.pop("empty_rank", None)              # this rank receives no reads at all (a small input dealt out in chunks)
     if scan_mode:
         os.environ["CDBG_SCAN_MODE"] = scan_mode
@@ -51,7 +52,8 @@ def _run_sharded(api, cdist, lib, orc, text, k, amin, world, rank, steps=1, **kw
         dist.all_gather_object(gathered, (mine, st["n_distinct"], st["n_solid"], st["n_occurrences"]))
         out = {"union": sorted((orc.canonical_unitig(s, k), int(kc)) for part in gathered for s, kc in part[0]),
                "mine": mine, "distinct": sum(p[1] for p in gathered), "solid": sum(p[2] for p in gathered),
-               "occ": sum(p[3] for p in gathered), "comm_bytes": nbytes, "per_rank": [len(p[0]) for p in gathered], "ab": ab}
+               "occ": sum(p[3] for p in gathered), "comm_bytes": nbytes, "per_rank": [len(p[0]) for p in gathered], "ab": ab,
+               "rounds": st["n_glue_rounds"]}
     g.close()
     return out
 
@@ -67,7 +69,8 @@ def _worker(rank, world, port, q, cases):
     ok = []
     for case in cases:
         k, amin, n_reads, read_len, cfg, kw = case
-        text = orc.synth_reads(n_reads, read_len, cfg)
+        kw = dict(kw)
+        text = oracle_lib.read_input(cfg).encode() if isinstance(cfg, str) else orc.synth_reads(n_reads, read_len, cfg)
         exp = orc.run(text, k, amin)
         got = _run_sharded(api, cdist, lib, orc, text, k, amin, world, rank, steps=kw.pop("steps", 1), **kw)
         if kw.get("emit_replicated"):
@@ -78,6 +81,10 @@ def _worker(rank, world, port, q, cases):
             ok.append(got["union"] == exp["unitigs"])
         ok.append(got["distinct"] == exp["stats"]["distinct"] and got["solid"] == exp["stats"]["solid"] and got["occ"] == exp["stats"]["occurrences"])
         ok.append(got["comm_bytes"] > 0)
+        # which glue ran: the sharded one (distributed ranking rounds > 0) unless every rank emits everything, or -- the
+        # circular fixtures -- a closed chain crosses ranks and the replicated exchange takes over
+        if "rounds" in got:
+            ok.append((got["rounds"] > 0) == (not kw.get("emit_replicated") and not kw.get("expect_fallback")))
         if kw.get("all_abundance_counts"):
             # -all-abundance-counts across ranks: the vector of every unitig this rank emitted is the oracle's count of its k-mers
             solid = dict(orc.run(text, k, amin, want_solid=True)["solid"]); comp = str.maketrans("ACGT", "TGCA")
@@ -119,7 +126,10 @@ def test_two_rank_gloo():
                 (31, 2, 250, 150, 3, {"all_abundance_counts": True}), (55, 1, 100, 150, 4, {"all_abundance_counts": True, "emit_replicated": True}),
                 (31, 2, 300, 150, 3, {"reads_replicated": True}), (31, 2, 300, 150, 3, {"scan_mode": "capped", "log2_partitions": 6}),
                 (55, 2, 200, 150, 4, {"scan_mode": "capped", "reads_replicated": True}), (31, 2, 200, 150, 3, {"empty_rank": 1}),
-                (30, 2, 250, 150, 3, {}), (64, 1, 100, 300, 5, {"log2_partitions": 4})], 29500, 400)
+                (30, 2, 250, 150, 3, {}), (64, 1, 100, 300, 5, {"log2_partitions": 4}),
+                # closed chains across ranks (example/circular_unitigs_unittests): the distributed ranking gives up, the replicated exchange cuts them
+                (7, 1, 0, 0, "circ_test1", {"log2_partitions": 3, "minimizer_size": 3, "expect_fallback": True}),
+                (7, 1, 0, 0, "circ_test2", {"log2_partitions": 3, "minimizer_size": 3}), (9, 1, 0, 0, "pufferize_refs", {"log2_partitions": 4, "minimizer_size": 4})], 29500, 400)
 
 
 def test_four_rank_gloo():

@@ -126,8 +126,8 @@ def test_no_device_fallback_symbols(hip):
 
 def test_multi_gpu_path_single_rank_rccl(oracle, hip, monkeypatch):
     """the multi-GPU code path of the library with a ONE-rank RCCL communicator (CDBG_FORCE_MULTI): librccl bound at run
-    time, ncclCommInitRank, the all-gathers / all-reduce through RCCL, record exchange + merge kernels, glue exchange,
-    sharded join, owner-filtered emission; result against the oracle, repeated steps"""
+    time, ncclCommInitRank, the all-to-all-v's through RCCL (grouped ncclSend / ncclRecv), record exchange + merge kernels, the
+    sharded glue (junction records, pairs, ranking rounds, pieces); result against the oracle, repeated steps"""
     import torch.distributed as dist
     import bcalm_amd
     from bcalm_amd import dist as cdist
@@ -156,14 +156,19 @@ def test_multi_gpu_path_single_rank_rccl(oracle, hip, monkeypatch):
 @pytest.mark.parametrize("world,k,amin,n_reads,read_len,cfg,kw", [
     (2, 31, 2, 300000, 150, 3, {}), (4, 31, 1, 60000, 150, 3, {"log2_partitions": 12}),
     (2, 55, 2, 100000, 150, 4, {}), (2, 127, 2, 8000, 1000, 5, {}), (2, 31, 2, 100000, 150, 3, {"emit_replicated": True}),
-    (2, 31, 2, 60000, 150, 3, {"all_abundance_counts": True})])
-def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, read_len, cfg, kw):
+    (2, 31, 2, 60000, 150, 3, {"all_abundance_counts": True}),
+    (2, 31, 2, 200000, 150, 3, {"reads_replicated": True}), (4, 32, 2, 60000, 150, 4, {"reads_replicated": True}),
+    (2, 31, 2, 300000, 150, 3, {"scan_mode": "capped"}), (4, 77, 2, 6000, 1000, 5, {"scan_mode": "capped"})])
+def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, read_len, cfg, kw, monkeypatch):
     """the complete N-rank data path on the real device: N contexts on GPU 0 driven by N host threads, reads sharded,
     records / pieces / junction log / partner ids moved by an in-process loop-back transport (tests/loopback.py: RCCL
     refuses two ranks on one GPU).  The union of the ranks' unitigs must be the oracle's set, each unitig exactly once."""
     import threading
     import bcalm_amd
     from loopback import hip_loopback
+    kw = dict(kw)
+    if kw.pop("scan_mode", None):                # sharded reads through the single-pass capped scan + region packing
+        monkeypatch.setenv("CDBG_SCAN_MODE", "capped")
     text = oracle.synth_reads(n_reads, read_len, cfg)
     exp = oracle.run(text, k, amin)
     reads = [x for x in text.decode().split("\n") if x]
@@ -173,7 +178,7 @@ def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, rea
         try:
             g = bcalm_amd.Graph(k, amin, lib=hip, world_size=world, rank=r, **kw)
             ep = hub.endpoint(r); ep.attach(g)
-            g.push_text(("\n".join(reads[r::world]) + "\n").encode())
+            g.push_text(text if kw.get("reads_replicated") else ("\n".join(reads[r::world]) + "\n").encode())
             g.run()
             out[r] = (g.unitigs(), g.stats(), g.comm_bytes(), ep.error, g.unitig_abundances() if kw.get("all_abundance_counts") else None)
             g.close()
@@ -195,6 +200,7 @@ def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, rea
         union = sorted((oracle.canonical_unitig(s, k), int(kc)) for r in range(world) for s, kc in out[r][0])
         assert union == exp["unitigs"]
         assert all(len(out[r][0]) > 0 for r in range(world))
+        assert all(out[r][1]["n_glue_rounds"] > 0 for r in range(world))        # the sharded glue ran (k_dglue.h), not the replicated fallback
     assert sum(out[r][1]["n_distinct"] for r in range(world)) == exp["stats"]["distinct"]
     assert sum(out[r][1]["n_solid"] for r in range(world)) == exp["stats"]["solid"]
     assert all(out[r][2] > 0 for r in range(world))
