@@ -42,7 +42,7 @@ class Stats(C.Structure):
 EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
            "cdbg_generate_reads", "cdbg_expect_input", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
            "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats", "cdbg_digest",
-           "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", 
+           "cdbg_fetch_unitigs_packed", "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", 
            "cdbg_set_transport", "cdbg_comm_unique_id", "cdbg_comm_init_rccl", "cdbg_comm_bytes"]
 
 
@@ -87,6 +87,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_fetch_solid.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint32), u64, C.POINTER(u64)]
     lib.cdbg_num_unitigs.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     lib.cdbg_fetch_unitigs.argtypes = [vp, u64, u64, C.c_char_p, C.POINTER(u64), C.POINTER(u64)]
+    lib.cdbg_fetch_unitigs_packed.argtypes = [vp, C.POINTER(C.c_uint8), u64, C.POINTER(u64), C.POINTER(C.c_uint32), C.POINTER(u64)]
     lib.cdbg_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.cdbg_digest.argtypes = [vp, C.POINTER(u64)]
     lib.cdbg_fetch_unitig_abundances.argtypes = [vp, u64, u64, C.POINTER(C.c_uint32), C.POINTER(u64)]
@@ -179,6 +180,15 @@ class Graph:
 
     def reset(self):
         self._ck(self.lib.cdbg_reset(self._h))
+
+    def unitigs_packed(self):
+        """the unitig set at 2 bits per base as the glue stage leaves it in HBM: (arena bytes, base_off[], len[], kc[])"""
+        n = C.c_uint64(); tot = C.c_uint64()
+        self._ck(self.lib.cdbg_num_unitigs(self._h, C.byref(n), C.byref(tot)))
+        nb = (tot.value + 3) // 4
+        buf = (C.c_uint8 * max(nb, 1))(); off = (C.c_uint64 * max(n.value, 1))(); ln = (C.c_uint32 * max(n.value, 1))(); kc = (C.c_uint64 * max(n.value, 1))()
+        self._ck(self.lib.cdbg_fetch_unitigs_packed(self._h, buf, nb, off, ln, kc))
+        return bytes(buf)[:nb], list(off)[:n.value], list(ln)[:n.value], list(kc)[:n.value]
 
     def unitig_abundances(self):
         """-> per unitig (same order as unitigs()) the list of its k-mers' abundances (ab:Z: vector)"""

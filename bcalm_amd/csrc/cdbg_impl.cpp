@@ -199,7 +199,7 @@ struct cdbg_ctx {
     DBuf<uint8_t> xp_bases, xp_dense; DBuf<uint32_t> xp_lens; DBuf<uint64_t> xp_uoff; uint64_t xp_bytes = 0, xp_unpacked = 0;
     DBuf<uint32_t> xr_lens; DBuf<uint64_t> xr_uoff;      // receiver-side scratch of xchg_add_packed
 
-    DBuf<uint64_t> unitig_off; DBuf<uint32_t> unitig_len; DBuf<uint64_t> unitig_kc; DBuf<uint8_t> unitig_bases;
+    DBuf<uint64_t> unitig_off; DBuf<uint32_t> unitig_len; DBuf<uint64_t> unitig_kc; DBuf<uint8_t> unitig_bases, unitig_packed;   // packed: the same arena at 2 bits per base
     uint64_t n_unitigs = 0, unitig_total = 0;
     DBuf<uint32_t> piece_ab, unitig_ab;          // -all-abundance-counts
     DBuf<uint64_t> link_off; DBuf<uint32_t> link_to; uint64_t n_links = 0; bool linked = false;
@@ -561,6 +561,7 @@ int count_impl(cdbg_ctx* c) {
             capped_capacities(mean, NPS, part_cap, spill_cap);
             if ((double)part_cap * (double)NPS * RW * 8.0 > 200e9) fits = false;       // would not fit: use the exact layout
             else {
+                if (c->xrecs.cap > c->records.cap) c->records.swap(c->xrecs);   // (sharded reads: the previous step left the region buffer there)
                 CK(c->records.alloc((uint64_t)part_cap * NPS * RW, false));
                 CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
                 HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
@@ -1234,6 +1235,14 @@ int glue_exchange(cdbg_ctx* c) {
 // Returns DG_FALLBACK (every rank, together) when the distributed ranking does not converge -- closed chains that cross
 // ranks -- and the caller then runs the replicated exchange, which can cut cycles.
 // =======================================================================================
+// The stage's end state: the unitig arena at 2 bits per base next to the ASCII one (one streaming pass:
+// 64 bases -> 16 bytes per lane; base i of the arena = bits [2 (i & 3), 2 (i & 3) + 2) of byte i >> 2, A0 C1 G2 T3)
+int pack_unitigs(cdbg_ctx* c) {
+    const uint64_t chunks = (c->unitig_total + 63) / 64;
+    CK(c->unitig_packed.alloc(chunks * 16 + 16, false));
+    if (chunks) { StreamPackParams pp{ chunks, c->unitig_bases.p, c->unitig_packed.p, c->unitig_total }; CDBG_LAUNCH(k_pack_stream, (chunks + 255) / 256, 256, c->stream, pp); }
+    return CDBG_OK;
+}
 constexpr int DG_FALLBACK = 1;
 struct DgRoute { std::vector<uint64_t> scnt, soff, rcnt, roff, all; uint64_t n_send = 0, n_recv = 0, n_all = 0; };
 // positions of the n items whose destinations are in c->dg_dest: send-block counts / offsets, receive counts / offsets
@@ -1387,8 +1396,8 @@ int glue_sharded(cdbg_ctx* c) {
     }
     const uint64_t ucap = std::max<uint64_t>(hm[0], 1), ocap = std::max<uint64_t>(hm[1], 1);
     CK(c->unitig_off.alloc(ucap, false)); CK(c->unitig_len.alloc(ucap, false)); CK(c->unitig_kc.alloc(ucap, false));
-    CK(c->unitig_bases.alloc(ocap + 16, false));
-    if (c->prm.all_abundance_counts) CK(c->unitig_ab.alloc(ocap + 16, false));
+    CK(c->unitig_bases.alloc(ocap + 64, false));
+    if (c->prm.all_abundance_counts) CK(c->unitig_ab.alloc(ocap + 64, false));
     HIPCK(hipMemsetAsync(c->cursors.p + 2, 0, 2 * sizeof(uint64_t), s));
     HeadParams hp{};
     hp.n_states = NSl; hp.k = k; hp.link = c->link.p; hp.st = st; hp.hinfo = c->rank_a.p;
@@ -1484,11 +1493,11 @@ int glue_sharded(cdbg_ctx* c) {
         ep.piece_ab = c->prm.all_abundance_counts ? c->dg_rab.p : nullptr; ep.unitig_ab = c->unitig_ab.p;
         CDBG_LAUNCH(k_emit, (uint32_t)((NR + GLUE_THREADS - 1) / GLUE_THREADS), GLUE_THREADS, s, ep);
     }
+    { uint64_t cur[2]; CK(read_u64(c->cursors.p + 2, cur, 2)); c->n_unitigs = cur[0]; c->unitig_total = cur[1]; }
+    CK(pack_unitigs(c));
     float ms = 0; CK(t.stop(&ms));
     c->st.ms_glue = ms;
     CK(agree(c, check_device_error(c, "sharded glue"), "glue: emit"));
-    uint64_t cur[2]; CK(read_u64(c->cursors.p + 2, cur, 2));
-    c->n_unitigs = cur[0]; c->unitig_total = cur[1];
     c->joined = false; c->xchg_done = true;
     c->st.n_glue_joined = c->n_join_local; c->st.n_unitigs = c->n_unitigs; c->st.unitig_bases = c->unitig_total;
     c->st.ms_total += c->st.ms_glue;
@@ -1580,7 +1589,7 @@ int glue_impl(cdbg_ctx* c) {
     const uint64_t ucap = std::max<uint64_t>(NP, 1);
     const uint64_t ocap = std::max<uint64_t>(c->n_piece_bases, 1);
     CK(c->unitig_off.alloc(ucap, false)); CK(c->unitig_len.alloc(ucap, false)); CK(c->unitig_kc.alloc(ucap, false));
-    CK(c->unitig_bases.alloc(ocap, false));
+    CK(c->unitig_bases.alloc(ocap + 64, false));             // (+ 64: the 2-bit packing pass reads whole 64-base chunks)
     if (c->prm.all_abundance_counts) CK(c->unitig_ab.alloc(ocap, false));
     HIPCK(hipMemsetAsync(c->cursors.p + 2, 0, 2 * sizeof(uint64_t), s));
     if (NS) {
@@ -1598,12 +1607,12 @@ int glue_impl(cdbg_ctx* c) {
         ep.piece_ab = c->prm.all_abundance_counts ? c->piece_ab.p : nullptr; ep.unitig_ab = c->unitig_ab.p;
         CDBG_LAUNCH(k_emit, (uint32_t)((NP + GLUE_THREADS - 1) / GLUE_THREADS), GLUE_THREADS, s, ep);
     }
+    { uint64_t cur[2]; CK(read_u64(c->cursors.p + 2, cur, 2)); c->n_unitigs = cur[0]; c->unitig_total = cur[1]; }
+    CK(pack_unitigs(c));
     float ms_fin = 0; CK(t.stop(&ms_fin));
     hm.mark("glue: rank + heads + emit");
     c->st.ms_glue = ms_join + ms_fin;
     CK(check_device_error(c, "glue"));
-    uint64_t cur[2]; CK(read_u64(c->cursors.p + 2, cur, 2));
-    c->n_unitigs = cur[0]; c->unitig_total = cur[1];
     c->joined = false;
     c->st.n_glue_joined = c->n_join_local; c->st.n_unitigs = c->n_unitigs; c->st.unitig_bases = c->unitig_total; c->st.n_cycles += n_cycles_cut;
     c->st.ms_total += c->st.ms_glue;
@@ -1871,6 +1880,21 @@ int cdbg_fetch_unitigs(cdbg_ctx* c, uint64_t first, uint64_t n, char* seq_buf, u
         HIPCK(hipMemcpy(seq_buf, dense.p, w, hipMemcpyDeviceToHost));
     }
     seq_off[n] = w;
+    return CDBG_OK;
+}
+int cdbg_fetch_unitigs_packed(cdbg_ctx* c, uint8_t* packed, uint64_t packed_capacity, uint64_t* base_off, uint32_t* len, uint64_t* kc) {
+    if (!c || !packed || !base_off || !len || !kc) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
+    if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_fetch_unitigs_packed before cdbg_glue");
+    const uint64_t nbytes = (c->unitig_total + 3) / 4;
+    if (packed_capacity < nbytes) return fail(CDBG_E_PARAM, "packed buffer too small (%llu < %llu bytes)", (unsigned long long)packed_capacity, (unsigned long long)nbytes);
+    const uint64_t n = c->n_unitigs;
+    if (nbytes) HIPCK(hipMemcpy(packed, c->unitig_packed.p, nbytes, hipMemcpyDeviceToHost));
+    if (n) {
+        HIPCK(hipMemcpy(base_off, c->unitig_off.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(len, c->unitig_len.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(kc, c->unitig_kc.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
     return CDBG_OK;
 }
 int cdbg_fetch_unitig_abundances(cdbg_ctx* c, uint64_t first, uint64_t n, uint32_t* ab, uint64_t* ab_off) {

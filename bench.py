@@ -14,10 +14,13 @@ roofline = the dominant kernel's ALGORITHMIC bytes (SURVEY.md section 8d stage-i
           model, evaluated with the measured n_occ / S / P / U) / its launch duration,
           measured with HIP events on the library's own stream (cdbg_stats ms_*), against
           the 8 TB/s HBM3E peak.  `pipeline` inside it is the same for the whole step.
-cpu_baseline = the CPU oracle (oracle/cdbg_oracle.c, a spec restatement: kind "port",
-          one core) timed on a bounded sample of the same workload shape.  It is a
-          reported baseline, not the target.  The reference binary itself is not
-          buildable (gatb-core submodule absent).
+cpu_baseline = on the GPU box's host cores, a bounded sample of the same workload (10 M reads
+          at k <= 31): a real BCALM 2 binary when one is reachable ($BCALM_BIN / `bcalm` on PATH;
+          kind "reference", its unitig set is then diffed against the GPU's), otherwise the
+          multithreaded CPU restatement of the spec oracle/cpu_mt.cpp (kind "port", all cores,
+          one shared lock-free table; its set digest must equal the GPU's on the same sample).
+          A reported baseline, not the target.  The reference itself cannot be built here
+          (its gatb-core submodule is absent).
 """
 import argparse
 import json
@@ -123,9 +126,24 @@ def cpu_baseline(k, amin, read_len, cfg, sample_reads):
                 subprocess.run([ref, "-in", fa, "-kmer-size", str(k), "-abundance-min", str(amin), "-nb-cores", str(cores)],
                                cwd=t, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
                 dt = time.time() - t0
+                # "also diff its canonicalised unitig set against ours" -- the reference's output on
+                # this sample against the HIP path's (tests/parity.py), printed with the line
+                import re as _re
+                ref_ut, kc = [], None
+                for line in open(os.path.join(t, "sample.unitigs.fa")):
+                    if line.startswith(">"):
+                        kc = int(_re.search(r"KC:i:(\d+)", line).group(1))
+                    elif line.strip():
+                        ref_ut.append((line.strip(), kc))
             distinct = orc.run(text, k, amin)["stats"]["distinct"]
+            import bcalm_amd
+            g = bcalm_amd.Graph(k, amin, lib=bcalm_amd.load())
+            g.push_text(text.encode()); g.run(); ours = g.unitigs(); g.close()
+            a = oracle_lib.canonical_set(orc, ours, k); b = oracle_lib.canonical_set(orc, ref_ut, k)
             return {"value": distinct / dt, "unit": "kmers/s", "cores": cores, "kind": "reference",
-                    "sample": f"{sample_reads} x {read_len} bp synthetic reads through {ref} in {dt:.1f} s"}
+                    "sample": f"{sample_reads} x {read_len} bp synthetic reads through {ref} in {dt:.1f} s",
+                    "unitig_sets_equal": a == b, "unitigs_ours": len(a), "unitigs_reference": len(b),
+                    "only_ours": sorted(set(a) - set(b))[:3], "only_reference": sorted(set(b) - set(a))[:3]}
         except Exception:
             pass                                             # fall through to the port
     if k <= 31:
@@ -364,6 +382,9 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cb = cpu_baseline(a.k, a.abundance_min, a.read_len, a.cfg, a.cpu_sample_reads)
+            if "unitig_sets_equal" in cb:
+                out["checks"]["reference binary and GPU agree on the baseline sample (canonical unitig sets)"] = cb["unitig_sets_equal"]
+                out["checks_passed"] = all(out["checks"].values())
             if "set_digest" in cb:
                 # the same sample through the GPU path: CPU restatement and HIP kernels must agree on the whole unitig set
                 g2 = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank)

@@ -156,6 +156,11 @@ int cdbg_fetch_solid(cdbg_ctx* ctx, char* kmers, uint32_t* counts, uint64_t capa
  * unspecified, as in the reference (README.md:84-87). */
 int cdbg_num_unitigs(cdbg_ctx* ctx, uint64_t* n, uint64_t* total_bases);
 int cdbg_fetch_unitigs(cdbg_ctx* ctx, uint64_t first, uint64_t n, char* seq_buf, uint64_t* seq_off, uint64_t* kc);
+/* The same set at 2 bits per base, the form the glue stage leaves resident in HBM next to the ASCII arena (SURVEY.md 8d:
+ * "canonical unitigs + KC resident in HBM (2-bit packed)").  All n = cdbg_num_unitigs unitigs at once: `packed` receives
+ * ceil(total_bases / 4) bytes of ONE arena; unitig i is bases [base_off[i], base_off[i] + len[i]) of it; base j of the
+ * arena = bits [2 (j & 3), 2 (j & 3) + 2) of byte j >> 2, codes A0 C1 G2 T3. */
+int cdbg_fetch_unitigs_packed(cdbg_ctx* ctx, uint8_t* packed, uint64_t packed_capacity, uint64_t* base_off, uint32_t* len, uint64_t* kc);
 /* per-k-mer abundances of unitigs [first, first+n) (contexts created with all_abundance_counts = 1):
  * ab_off[n+1] offsets into ab; unitig i has LN-k+1 values in the orientation of its sequence
  * (the `ab:Z:` vector of /root/reference/README.md:74-80) */

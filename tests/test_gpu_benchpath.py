@@ -106,6 +106,25 @@ def test_reference_checker_accepts_hip_unitigs(oracle, hip, tmp_path):
     assert "REPEATED" not in final
 
 
+def test_against_a_real_bcalm_binary(oracle, hip):
+    """the only door out of "parity unpinned" (/root/reference/test/simple_test.sh:5-9 diffs unitig sets the same way): when a
+    real BCALM 2 executable is reachable ($BCALM_BIN, or `bcalm` on PATH that is not this repo's CLI), run it on a FASTA dump of
+    200 K synthetic reads and compare the canonical (sequence, KC) sets with the HIP output.  Skips cleanly when there is none
+    (the expected case: gatb-core is absent from /root/reference and nothing can be installed)."""
+    import bcalm_amd
+    from parity import diff_against_reference, reference_binary
+    ref = reference_binary()
+    if not ref:
+        pytest.skip("no BCALM 2 binary on this box ($BCALM_BIN / `bcalm` on PATH)")
+    for k, amin, cfg in ((31, 2, 3), (21, 1, 2)):
+        text = oracle.synth_reads(200_000, 150, cfg)
+        g = bcalm_amd.Graph(k, amin, lib=hip)
+        g.push_text(text); g.run()
+        ours = g.unitigs(); g.close()
+        d = diff_against_reference(oracle, ref, text, k, amin, ours)
+        assert d["equal"], d
+
+
 def _parse_fa(path, k):
     recs = []
     lines = open(path).read().split("\n")

@@ -73,6 +73,20 @@ def test_synthetic_generator_matches_oracle(oracle, sim, cfg, first, total):
         assert c.most_common(1)[0][1] > 200
 
 
+def test_packed_unitigs_match_ascii(oracle, sim):
+    """the 2-bit arena the glue stage leaves resident (cdbg_fetch_unitigs_packed; SURVEY.md 8d end state) decodes to the
+    ASCII unitigs, KC included"""
+    from bcalm_amd import api
+    for k, text in ((31, oracle.synth_reads(300, 150, 3)), (8, oracle_lib.read_input("even_k8").encode()), (77, oracle_lib.read_input("rand_w3").encode())):
+        g = api.Graph(k, 1, lib=sim, log2_partitions=4)
+        g.push_text(text); g.run()
+        ascii_set = g.unitigs()
+        arena, off, ln, kc = g.unitigs_packed()
+        g.close()
+        dec = [("".join("ACGT"[(arena[j >> 2] >> (2 * (j & 3))) & 3] for j in range(o, o + n)), c) for o, n, c in zip(off, ln, kc)]
+        assert dec == ascii_set and len(dec) > 0
+
+
 def test_hostile_reads_parity(oracle, sim):
     """the hostile generator (cfg | 0x100) through the whole pipeline: low-complexity blocks and skewed coverage overfill
     partitions, so the capped scan spills and the count tiers defer (every tier forced by the small partition count)"""
