@@ -1256,7 +1256,7 @@ int dg_route(cdbg_ctx* c, uint64_t n, DgRoute& R) {
     for (int d = 0; d < world; ++d) R.soff[d + 1] = R.soff[d] + R.scnt[d];
     R.n_send = R.soff[world];
     HIPCK(hipMemcpy(c->dg_cnt.p + DG_MAX_WORLD, R.soff.data(), world * sizeof(uint64_t), hipMemcpyHostToDevice));
-    if (n) CDBG_LAUNCH(k_route_place, std::min<uint64_t>((n + DG_THREADS - 1) / DG_THREADS, 256 * 8), DG_THREADS, s, rp);
+    if (n) CDBG_LAUNCH(k_route_place, std::min<uint64_t>((n + DG_THREADS * DG_ITEMS - 1) / (DG_THREADS * DG_ITEMS), 256 * 8), DG_THREADS, s, rp);
     if (c->tr.all_gather_u64(c->tr.user, R.scnt.data(), R.all.data(), world) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
     R.n_all = 0;
     for (int r = 0; r < world; ++r) { R.rcnt[r] = R.all[(size_t)r * world + me]; for (int d = 0; d < world; ++d) R.n_all += R.all[(size_t)r * world + d]; }
@@ -1336,8 +1336,11 @@ int glue_sharded(cdbg_ctx* c) {
         HIPCK(hipMemsetAsync(c->cursors.p + 7, 0, sizeof(uint64_t), s));
         WireScatterParams wp{ c->dg_wire_r.p, n, log_jb, c->jfill.p, c->jrecs.p, c->derr.p };
         if (n) CDBG_LAUNCH((k_join_scatter_wire<W>), grid(n), 256, s, wp);
-        CK(c->dg_pairs.alloc(n + 2, false));
-        JoinBucketParams bp{ c->jfill.p, c->jrecs.p, (uint32_t)JB, nullptr, c->dstats.p, c->dg_pairs.p, c->cursors.p + 7, n + 2, c->derr.p };
+        // (pair list: <= n entries used, in per-wave chunks whose tails stay unused -- pre-filled with the 'no pair' marker)
+        const uint64_t pair_cap = n + 2 + (uint64_t)JB_PAIR_CHUNK * std::min<uint64_t>((JB + 3) / 4, 256 * 16) * (JB_THREADS / 64);
+        CK(c->dg_pairs.alloc(pair_cap, false));
+        HIPCK(hipMemsetAsync(c->dg_pairs.p, 0xFF, pair_cap * sizeof(uint2), s));
+        JoinBucketParams bp{ c->jfill.p, c->jrecs.p, (uint32_t)JB, nullptr, c->dstats.p, c->dg_pairs.p, c->cursors.p + 7, pair_cap, c->derr.p };
         CDBG_LAUNCH((k_join_bucket<W>), std::min<uint64_t>((JB + 3) / 4, 256 * 16), JB_THREADS, s, bp);
         HIPCK(hipStreamSynchronize(s));
         uint32_t e = 0; CK(read_u32(c->derr.p, &e));

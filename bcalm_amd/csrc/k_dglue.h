@@ -52,19 +52,29 @@ __global__ void __launch_bounds__(DG_THREADS) k_route_count(RouteParams P) {
     __syncthreads();
     if ((int)threadIdx.x < P.world && h[threadIdx.x]) atomic_add_u64(&P.cnt[threadIdx.x], (uint64_t)h[threadIdx.x]);
 }
+constexpr int DG_ITEMS = 4;                              // items per thread and tile: three barriers per 1024 items
 __global__ void __launch_bounds__(DG_THREADS) k_route_place(RouteParams P) {
     CDBG_SHARED uint32_t h[DG_MAX_WORLD]; CDBG_SHARED uint64_t base[DG_MAX_WORLD];
-    const uint64_t tiles = (P.n + DG_THREADS - 1) / DG_THREADS;
+    constexpr uint64_t TILE = (uint64_t)DG_THREADS * DG_ITEMS;
+    const uint64_t tiles = (P.n + TILE - 1) / TILE;
     for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {          // uniform trip count per workgroup
         if (threadIdx.x < DG_MAX_WORLD) h[threadIdx.x] = 0;
         __syncthreads();
-        const uint64_t i = t * DG_THREADS + threadIdx.x;
-        uint8_t d = DG_NODEST; uint32_t r = 0;
-        if (i < P.n) { d = P.dest[i]; if (d != DG_NODEST) r = atomic_add_u32(&h[d], 1u); }
+        uint8_t d[DG_ITEMS]; uint32_t r[DG_ITEMS];
+#pragma unroll
+        for (int j = 0; j < DG_ITEMS; ++j) {
+            const uint64_t i = t * TILE + (uint64_t)j * DG_THREADS + threadIdx.x;
+            d[j] = DG_NODEST; r[j] = 0;
+            if (i < P.n) { d[j] = P.dest[i]; if (d[j] != DG_NODEST) r[j] = atomic_add_u32(&h[d[j]], 1u); }
+        }
         __syncthreads();
         if ((int)threadIdx.x < P.world && h[threadIdx.x]) base[threadIdx.x] = atomic_add_u64(&P.cur[threadIdx.x], (uint64_t)h[threadIdx.x]);
         __syncthreads();
-        if (d != DG_NODEST) P.pos[i] = P.off[d] + base[d] + r;
+#pragma unroll
+        for (int j = 0; j < DG_ITEMS; ++j) {
+            const uint64_t i = t * TILE + (uint64_t)j * DG_THREADS + threadIdx.x;
+            if (d[j] != DG_NODEST) P.pos[i] = P.off[d[j]] + base[d[j]] + r[j];
+        }
         __syncthreads();
     }
 }
@@ -114,11 +124,11 @@ __global__ void k_join_scatter_wire(WireScatterParams P) {
 struct PairRouteParams { const uint2* pairs; uint64_t n; DgOwners own; uint8_t* dest; const uint64_t* pos; uint2* wire; };
 __global__ void k_pair_dest(PairRouteParams P) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) P.dest[i] = (uint8_t)P.own.of_piece(P.pairs[i].x >> 1);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) { const uint32_t e = P.pairs[i].x; P.dest[i] = e == NONE32 ? DG_NODEST : (uint8_t)P.own.of_piece(e >> 1); }   // (NONE32: unused tail of a wave's chunk)
 }
 __global__ void k_pair_write(PairRouteParams P) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) P.wire[P.pos[i]] = P.pairs[i];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += stride) if (P.dest[i] != DG_NODEST) P.wire[P.pos[i]] = P.pairs[i];
 }
 struct PairApplyParams { const uint2* pairs; uint64_t n; uint32_t end_base; uint32_t* link; };
 __global__ void k_pair_apply(PairApplyParams P) {

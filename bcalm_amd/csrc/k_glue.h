@@ -59,6 +59,7 @@ __global__ void k_glue_resolve(GlueResolveParams P) {
 // L2-resident array -- and one plain store per record), then ONE WAVE joins each bucket in an LDS table of 2 JB_CAP slots
 // and writes the mutual links.  The global-table kernels above remain the fallback (a bucket that overflows).
 constexpr int JB_THREADS = 256;                         // 4 independent waves per workgroup
+constexpr uint32_t JB_PAIR_CHUNK = 2048;                // pairs a wave reserves per device atomic (sharded glue: pair output)
 struct JoinScatterParams {
     const uint64_t* glog_keys; const uint32_t* glog_tag; uint64_t n_records; int log_jb;
     uint32_t* jfill; uint64_t* jrecs; uint32_t* error;   // a bucket record = W key words + the tag word: ONE scattered store
@@ -94,6 +95,8 @@ __global__ void __launch_bounds__(JB_THREADS) k_join_bucket(JoinBucketParams P) 
     for (uint32_t i = lane; i < TSJ; i += 64) { L.keys[(uint64_t)i * W + (W - 1)] = KEY_EMPTY; L.a[i] = 0; L.b[i] = 0; L.conf[i] = 0; }
     CDBG_WAVE_SYNC();
     uint32_t joined = 0;
+    uint64_t pchunk_base = 0; uint32_t pchunk_left = 0;  // (pair output: this wave's reservation -- one device atomic per JB_PAIR_CHUNK pairs,
+                                                         //  not per bucket: 2 M buckets on ONE cursor word ran at the single-address rate, 25 ms)
     const uint32_t n_waves = gridDim.x * (JB_THREADS / 64);
     for (uint32_t bk = blockIdx.x * (JB_THREADS / 64) + (uint32_t)wave; bk < P.n_buckets; bk += n_waves) {
         uint32_t n = uni_u32(P.jfill[bk]); if (n > JB_CAP) n = JB_CAP;
@@ -148,9 +151,14 @@ __global__ void __launch_bounds__(JB_THREADS) k_join_bucket(JoinBucketParams P) 
                 if (a && b && (((a | b) & 0x80000000u) || L.conf[s])) ++nj;
             }
             const uint32_t incl = wave_incl_sum_u32(nj), tot = wave_readlane_u32(incl, 63);
-            uint32_t lo = 0, hi = 0;
-            if (lane == 0 && tot) { const uint64_t o = atomic_add_u64(P.pair_cursor, 2ull * tot); lo = (uint32_t)o; hi = (uint32_t)(o >> 32); }
-            pbase = (((uint64_t)wave_readlane_u32(hi, 0) << 32) | wave_readlane_u32(lo, 0)) + 2ull * (incl - nj);
+            if (2u * tot > pchunk_left) {                // (uniform) a new chunk; the tail of the old one stays unused: the list has gaps
+                uint32_t lo = 0, hi = 0;
+                const uint32_t want = 2u * tot > JB_PAIR_CHUNK ? 2u * tot : JB_PAIR_CHUNK;
+                if (lane == 0) { const uint64_t o = atomic_add_u64(P.pair_cursor, (uint64_t)want); lo = (uint32_t)o; hi = (uint32_t)(o >> 32); }
+                pchunk_base = ((uint64_t)wave_readlane_u32(hi, 0) << 32) | wave_readlane_u32(lo, 0); pchunk_left = want;
+            }
+            pbase = pchunk_base + 2ull * (incl - nj);
+            pchunk_base += 2ull * tot; pchunk_left -= 2u * tot;
             if (tot && pbase + 2ull * nj > P.pair_cap) { *P.error = 9; pbase = ~0ull; }
         }
         for (uint32_t s = lane; s < TSJ; s += 64) {
@@ -447,7 +455,9 @@ __global__ void k_squeeze_bases(SqueezeParams P) {
     const uint32_t len = P.lens[i];
     const uint8_t* src = P.bases + P.boff[i];
     uint8_t* dst = P.dense + P.uoff[i];
-    for (uint32_t j = 0; j < len; ++j) dst[j] = src[j];
+    uint32_t j = 0;
+    for (; j + 8 <= len; j += 8) st_unaligned_u64(dst + j, ld_unaligned_u64(src + j));     // (a byte per store was 13 ms for 0.9 GB)
+    for (; j < len; ++j) dst[j] = src[j];
 }
 // sender, step 2 / receiver: streaming 64 ASCII bases <-> 16 packed bytes per lane (dense is padded to 64 bytes)
 // -all-abundance-counts across ranks: the abundances of a rank's pieces as one gap-free u32 stream, n values per piece
