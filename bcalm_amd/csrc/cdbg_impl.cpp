@@ -108,8 +108,10 @@ template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMP
 #define CDBG_TSW2 256
 #endif
 template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, TSK2 = 2 * TS_COMPACT_2, NTC = 512, TSW = CDBG_TSW2; };
+// (W >= 3: 512 threads with member-balanced wave shares and 8-record batches: 2 x 8 waves per CU instead of 2 x 4;
+//  config-5 share: count tier 1 257 -> 214 ms, tier 2 87 -> 62 ms.  Before the balanced shares 512 threads LOST: 341 -> 464 ms)
 #ifndef CDBG_NTC4
-#define CDBG_NTC4 256
+#define CDBG_NTC4 512
 #endif
 #ifndef CDBG_TSW4
 #define CDBG_TSW4 256
@@ -556,10 +558,17 @@ int count_impl(cdbg_ctx* c) {
             LAUNCH_SCAN(SCAN_HIST, ns);
             CK(exscan(c->part_count.p));
             uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPS, &sample_records));
+            // the fullest partition of the sample: a skewed input (repeats, low complexity, coverage peaks) puts far more
+            // into some partitions than any capacity covers; the capped pass would then hammer a few fill counters and spill
+            // (145 ms at the hostile config-3 line before falling back) -- such inputs go straight to the exact two-pass layout
+            HIPCK(hipMemsetAsync(c->dstats.p + 31, 0, sizeof(uint64_t), s));
+            CDBG_LAUNCH(k_max_u32, std::min<uint64_t>((NPS + 255) / 256, 4096), 256, s, (const uint32_t*)c->part_count.p, NPS, c->dstats.p + 31);
+            uint64_t sample_max = 0; CK(read_u64(c->dstats.p + 31, &sample_max));
             CK(t.stop(&c->st.ms_scan_hist));
             const double mean = (double)sample_records * (double)tiles / (double)ns / (double)NPS;
             capped_capacities(mean, NPS, part_cap, spill_cap);
             if ((double)part_cap * (double)NPS * RW * 8.0 > 200e9) fits = false;       // would not fit: use the exact layout
+            if ((double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && getenv("CDBG_SCAN_MODE") == nullptr) fits = false;
             else {
                 if (c->xrecs.cap > c->records.cap) c->records.swap(c->xrecs);   // (sharded reads: the previous step left the region buffer there)
                 CK(c->records.alloc((uint64_t)part_cap * NPS * RW, false));
@@ -757,9 +766,18 @@ int count_impl(cdbg_ctx* c) {
         std::sort(bl.begin(), bl.end());
         std::vector<uint64_t> offs(nbig + 1, 0);
         const uint64_t nmax = (uint64_t)RecFmt<W>::CAPB - c->k + 1;
+        // (records of every listed partition: one bulk copy of the fill / offset array when the list is long -- a skewed input
+        //  lists 10^4 partitions, and a synchronous 4-byte copy each cost 77 ms per step at the hostile config-3 line)
+        std::vector<uint32_t> h_fill; std::vector<uint64_t> h_off;
+        if (nbig > 64) {
+            if (capped) { h_fill.resize(NPL); CK(read_u32(c->part_count.p, h_fill.data(), NPL)); }
+            else { h_off.resize(NPL + 1); CK(read_u64(c->part_off.p, h_off.data(), NPL + 1)); }
+        }
         for (uint32_t i = 0; i < nbig; ++i) {
             uint64_t nrec_p;
-            if (capped) { uint32_t f = 0; CK(read_u32(c->part_count.p + bl[i], &f)); nrec_p = f; }
+            if (!h_fill.empty()) nrec_p = h_fill[bl[i]];
+            else if (!h_off.empty()) nrec_p = h_off[bl[i] + 1] - h_off[bl[i]];
+            else if (capped) { uint32_t f = 0; CK(read_u32(c->part_count.p + bl[i], &f)); nrec_p = f; }
             else { uint64_t po[2]; CK(read_u64(c->part_off.p + bl[i], po, 2)); nrec_p = po[1] - po[0]; }
             const uint64_t occ = nrec_p * nmax;
             offs[i + 1] = offs[i] + pow2_at_least(2 * occ + 4 * 256);
@@ -881,8 +899,11 @@ int compact_impl(cdbg_ctx* c) {
             std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list.p, bl.data(), nbig));
             std::sort(bl.begin(), bl.end());
             std::vector<uint64_t> offs(nbig + 1, 0);
+            std::vector<uint32_t> h_segn;
+            if (nbig > 64) { h_segn.resize(NPL); CK(read_u32(c->seg_n.p, h_segn.data(), NPL)); }   // (one bulk copy, not one per bucket)
             for (uint32_t i = 0; i < nbig; ++i) {
-                uint32_t e = 0; CK(read_u32(c->seg_n.p + bl[i], &e));
+                uint32_t e = 0;
+                if (!h_segn.empty()) e = h_segn[bl[i]]; else CK(read_u32(c->seg_n.p + bl[i], &e));
                 offs[i + 1] = offs[i] + pow2_at_least(2 * (uint64_t)e + 16);
             }
             CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_cnt.alloc(offs[nbig], false));

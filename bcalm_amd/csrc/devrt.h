@@ -99,6 +99,7 @@ CDBG_DEV uint32_t uni_u32(uint32_t v) { return __shfl(v, 0); }   // (called by a
 #define CDBG_NOINLINE
 #define CDBG_DEV_NOINL inline
 #define CDBG_LDS_BARRIER() __syncthreads()
+#define CDBG_LDS_FENCE() do { } while (0)
 #else
 CDBG_DEV uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 #define CDBG_NOINLINE __attribute__((noinline))
@@ -109,6 +110,10 @@ CDBG_DEV uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfi
 // acknowledgements.  The "local" fences order LDS traffic only (s_waitcnt lgkmcnt(0)); global accesses stay in flight.
 #define CDBG_LDS_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
                                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
+// Release fence for a slot-claim protocol that lives in LDS ONLY (write the key words, then publish the claim word).
+// __threadfence_block() orders every address space: it waits for the wave's global loads too (vmcnt(0)) -- in the
+// counting kernels that is the prefetch of the NEXT partition's records, issued a moment earlier.
+#define CDBG_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 #endif
 CDBG_DEV uint64_t uni_u64(uint64_t v) { return ((uint64_t)uni_u32((uint32_t)(v >> 32)) << 32) | uni_u32((uint32_t)v); }
 CDBG_DEV uint64_t wave_sum_u64(uint64_t v) {        // all lanes -> the wave total (kernel epilogues only)

@@ -115,7 +115,7 @@ CDBG_DEV uint32_t ktable_insert(const KTable<W>& t, const Kmer<W>& key, bool& is
             bool advance = true;
             if (old == KEY_EMPTY) {                          // claimed: write the lower words, then publish the top word
                 for (int i = 0; i < W - 1; ++i) t.keys[(uint64_t)s * W + i] = key.w[i];
-                if (GLOBAL) __threadfence(); else __threadfence_block();
+                if (GLOBAL) __threadfence(); else CDBG_LDS_FENCE();
                 atomic_exch_u64(claim, top);
                 is_new = true; res = s; done = true; advance = false;
             } else if ((old & ~KEY_PENDING) == top) {

@@ -26,12 +26,16 @@
 
 namespace cdbg {
 
-constexpr int COUNT_CB = 16;                            // records per wave batch
+#ifndef CDBG_CB_WIDE
+#define CDBG_CB_WIDE 8
+#endif
+// records per wave batch (W >= 3: CDBG_CB_WIDE -- records of up to 122-153 members fill the 64-lane steps with far fewer of them)
+template <int W> struct CountCb { static constexpr int V = W >= 3 ? CDBG_CB_WIDE : 16; };
 template <int W> struct CountGeom {
     // member positions of one batch: COUNT_CB records of at most CAPB - k + 1 members, k >= 3 (W = 1), 32, 64, 96
     static constexpr int KMIN = W == 1 ? 3 : 32 * (W - 1);
     static constexpr int NMAX = RecFmt<W>::CAPB - KMIN + 1;
-    static constexpr int MASKW = (COUNT_CB * NMAX + 63) / 64;
+    static constexpr int MASKW = (CountCb<W>::V * NMAX + 63) / 64;
 };
 // LDS of one workgroup:
 //   keys / cnt   the open-address table (claim word EMPTY <=> slot free)
@@ -43,10 +47,10 @@ template <int W, int TS, int NT>
 struct CountFastLds {
     uint64_t keys[TS * W];
     uint32_t cnt[TS];
-    uint64_t stage[(NT / 64) * COUNT_CB * RecFmt<W>::RW + 2];   // + 2: the dword window of the last record may over-read (up to 4 dwords)
+    uint64_t stage[(NT / 64) * CountCb<W>::V * RecFmt<W>::RW + 2];   // + 2: the dword window of the last record may over-read (up to 4 dwords)
     uint64_t smask[(NT / 64) * CountGeom<W>::MASKW];
     uint64_t tmask[(NT / 64) * CountGeom<W>::MASKW];
-    uint16_t rbase[(NT / 64) * COUNT_CB];
+    uint16_t rbase[(NT / 64) * CountCb<W>::V];
     uint32_t fill[2], wr[2];                             // per partition parity: new keys / solid entries written
     uint32_t over;
     uint64_t cbase;                                      // chunk hand-out broadcast
@@ -160,6 +164,7 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
     static_assert(LOG_TS > 0, "table size");
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)uni_u32((uint32_t)tid >> 6);
     const int k = P.k;
+    constexpr int COUNT_CB = CountCb<W>::V;
     uint64_t* const stage = L.stage + (size_t)wave * COUNT_CB * RW;
     uint64_t* const smask = L.smask + (size_t)wave * MASKW;
     uint64_t* const tmask = L.tmask + (size_t)wave * MASKW;
@@ -260,7 +265,7 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
                             bool advance = true;
                             if (old == KEY_EMPTY) {
                                 for (int i = 0; i < W - 1; ++i) L.keys[(uint64_t)s * W + i] = can.w[i];
-                                __threadfence_block();
+                                CDBG_LDS_FENCE();
                                 atomic_exch_u64(claim, top);
                                 is_new = true; hit = true; advance = false;
                             } else if ((old & ~KEY_PENDING) == top) {

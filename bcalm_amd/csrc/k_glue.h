@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(JB_THREADS) k_join_bucket(JoinBucketParams P) 
                 if (old == KEY_EMPTY) {
                     if (W > 1) {
                         for (int j = 0; j < W - 1; ++j) L.keys[(uint64_t)s * W + j] = jc.w[j];
-                        __threadfence_block();
+                        CDBG_LDS_FENCE();
                         atomic_exch_u64(claim, top);
                     }
                     done = true; advance = false;

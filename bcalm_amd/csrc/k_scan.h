@@ -358,6 +358,13 @@ __global__ void __launch_bounds__(EXSCAN_THREADS) k_exscan_apply(const uint32_t*
     uint64_t acc = bsum[blockIdx.x] + incl - v;
     for (int j = 0; j < EXSCAN_ITEMS; ++j) { if (i0 + j < n) off[i0 + j] = acc; acc += c[j]; }
 }
+__global__ void k_max_u32(const uint32_t* a, uint64_t n, uint64_t* out) {        // *out = max(*out, max a[i]) (out zeroed by the host)
+    uint32_t m = 0; const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = a[i] > m ? a[i] : m;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(m, d); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomic_max_u32(reinterpret_cast<uint32_t*>(out), m);
+}
 __global__ void k_copy_u64(const uint64_t* src, uint64_t* dst, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];

@@ -32,30 +32,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_TRAFFIC_CSV = os.path.join(ROOT, "profiles", "r02c_pmc_hbm_traffic_per_kernel.csv")
+def pmc_csv(cfg):
+    return os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic_per_kernel_cfg%d.csv" % cfg)
 
 
 GLUE_LABEL = "glue(k_join_bucket+k_rank8_*+k_unitig_heads+k_emit)"
 
 
-def pmc_traffic(kernel_key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (bench_micro/pmc_bench.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench;
-    bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 FETCH_SIZE halving corrected as
-    MI355X_MICROARCH.md section HBM prescribes).  None when the profile is absent."""
+def pmc_traffic(kernel_key, cfg):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same bench
+    (bench_micro/pmc_bench.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs; bytes = (f * FETCH_SIZE + WRITE_SIZE) * 1024 with
+    the per-access-pattern factor f calibrated in profiles/r03_counter_calibration.csv: 2 for wide coalesced reads -- the
+    gfx950 FETCH_SIZE halving of MI355X_MICROARCH.md section HBM -- 1 for kernels whose reads are random gathers).
+    -> (bytes or None, first line of the CSV: the commit it was taken at)"""
     keys = kernel_key if isinstance(kernel_key, (list, tuple)) else [kernel_key]
-    tot, found = 0.0, False
+    tot, found, stamp = 0.0, False, None
     try:
-        for line in open(PMC_TRAFFIC_CSV):
-            row = line.rstrip("\n").rsplit(",", 4)          # kernel names contain commas
-            if len(row) == 5 and any(x in row[0] for x in keys):
-                tot += float(row[4]) * float(row[1]) / 2 * 1e9 if len(keys) > 1 else float(row[4]) * 1e9   # (a stage: all launches of its kernels in one of the 2 profiled steps)
+        for line in open(pmc_csv(cfg)):
+            if line.startswith("#"):
+                stamp = line[1:].strip(); continue
+            row = line.rstrip("\n").rsplit(",", 5)          # kernel names contain commas
+            if len(row) == 6 and row[1].isdigit() and any(x in row[0] for x in keys):
+                tot += float(row[5]) * float(row[1]) / 2 * 1e9 if len(keys) > 1 else float(row[5]) * 1e9   # (a stage: all launches of its kernels in one of the 2 profiled steps)
                 found = True
                 if len(keys) == 1:
                     break
     except Exception:
-        return None
-    return tot if found else None
+        return None, None
+    return (tot if found else None), stamp
+
+
+def W_OF(k):
+    return 1 if k <= 31 else 2 if k <= 63 else 3 if k <= 95 else 4
 
 
 def alg_bytes(k, st, n_reads, read_len):
@@ -166,7 +174,7 @@ def cpu_baseline(k, amin, read_len, cfg, sample_reads):
     res = []
     if cores > 1:                                            # one child process per core (never a Pool: a bench must not hang)
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--k", str(k), "--abundance-min", str(amin),
-                                   "--read-len", str(read_len), "--cfg", str(cfg + 16 * i), "--cpu-sample-reads", str(sample_reads)],
+                                   "--read-len", str(read_len), "--cfg", str(cfg & 0xF), "--gen-cfg", str(cfg + 16 * i), "--cpu-sample-reads", str(sample_reads)],
                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(cores)]
         for p in procs:
             try:
@@ -205,9 +213,14 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=None, help="reads of the CPU baseline's sample (default: 10 M for k <= 31, 400 K per process otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)   # child of cpu_baseline: one scalar run, prints 'distinct seconds'
+    ap.add_argument("--gen-cfg", type=int, default=None, help=argparse.SUPPRESS)   # (child only: generator seed of its own sample)
     ap.add_argument("--mode", choices=["sharded", "independent"], default="sharded",
                     help="N>1: sharded = ONE graph over --reads reads: reads and minimizer partitions split over the ranks, records and glue "
                          "data exchanged over RCCL inside libcdbg (strong scaling); independent = one read set per rank, no collective (weak scaling)")
+    ap.add_argument("--skewed", action="store_true",
+                    help="the HOSTILE generator (cfg | 0x100, include/cdbg.h): two-letter low-complexity blocks, up to 1000 copies of a 5 kbp repeat, "
+                         "50 homopolymer runs, ~20x coverage skew -- what the overflow tiers (spill repair, second count tier, multi-pass, HBM tables) cost; "
+                         "a robustness line, not the metric")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded (collective) code path even with one rank (testing)")
     ap.add_argument("--read-placement", dest="read_placement", choices=["auto", "replicated", "sharded"], default="auto",
                     help="N>1, --mode sharded: replicated = every rank generates ALL reads and scans them for its own partitions, no record "
@@ -220,8 +233,9 @@ def main():
     a.k = a.k or CFG["k"]; a.read_len = a.read_len or CFG["read_len"]
     a.reads = a.reads or int(os.environ.get("CDBG_BENCH_READS", CFG["reads"]))
     a.cpu_sample_reads = a.cpu_sample_reads or (10_000_000 if a.k <= 31 else 400_000)
+    gen_cfg = a.cfg | (0x100 if a.skewed else 0)           # generator seed / mode (cdbg_generate_reads)
     if a.cpu_worker:
-        d, dt = _cpu_worker((a.k, a.abundance_min, a.read_len, a.cfg, a.cpu_sample_reads))
+        d, dt = _cpu_worker((a.k, a.abundance_min, a.read_len, a.gen_cfg if a.gen_cfg is not None else a.cfg, a.cpu_sample_reads))
         print(d, dt)
         return
 
@@ -263,11 +277,11 @@ def main():
         g = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank, world_size=world, rank=rank, reads_replicated=replicated)
         cdist.init_rccl(g, dist, device=torch.device("cuda", local_rank))
         if replicated:
-            g.generate_reads(a.reads, a.read_len, a.cfg, first_read=0, total_reads=a.reads)
+            g.generate_reads(a.reads, a.read_len, gen_cfg, first_read=0, total_reads=a.reads)
         else:
             share = (a.reads + world - 1) // world
             first = rank * share
-            g.generate_reads(max(0, min(share, a.reads - first)), a.read_len, a.cfg, first_read=first, total_reads=a.reads)
+            g.generate_reads(max(0, min(share, a.reads - first)), a.read_len, gen_cfg, first_read=first, total_reads=a.reads)
 
         def step():
             g.run()
@@ -279,7 +293,7 @@ def main():
     else:
         # N == 1, or --mode independent: every rank runs the full path on its own read set
         g = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank)
-        g.generate_reads(a.reads, a.read_len, a.cfg + 16 * rank)
+        g.generate_reads(a.reads, a.read_len, gen_cfg + 16 * rank)
 
         def step():
             g.run()
@@ -350,6 +364,10 @@ def main():
         dom_ms = ms[dom] / a.steps
         achieved = per_kernel[dom] / (dom_ms * 1e-3) / 1e9
         gpu_ms = acc["ms_total"] / a.steps
+        traffic, stamp = pmc_traffic({"k_count_fast": "k_count_fast<%d, %d, " % (W_OF(a.k), {1: 4096}.get(W_OF(a.k), 2048)), "k_compact_wave": "k_compact_wave<",
+                                      "k_scan<emit>": "k_scan_fast<%d, 2" % W_OF(a.k) if a.k <= 63 else "k_scan<%d, 2" % W_OF(a.k),
+                                      "k_scan<hist>": "k_scan_fast<%d, 0" % W_OF(a.k) if a.k <= 63 else "k_scan<%d, 0" % W_OF(a.k)}.get(dom, ["k_join_bucket", "k_rank8", "k_unitig_heads", "k_emit"]), a.cfg)
+        traffic_src = "profiles/%s (separate rocprofv3 --pmc passes of this bench; %s)" % (os.path.basename(pmc_csv(a.cfg)), stamp or "absent")
         out = {
             "metric": "distinct k-mers/s reads->unitigs k=%d" % a.k,
             "value": total_distinct * a.steps / dt,
@@ -358,37 +376,36 @@ def main():
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s: synthetic %d x %d bp reads %s, k=%d, abundance-min %d, 1%% substitutions, 30x coverage"
-                                   % (CFG["name"], a.reads, a.read_len, "in total (one graph)" if sharded else "per GPU", a.k, a.abundance_min),
+            "config": {"workload": "%s: synthetic %d x %d bp reads %s, k=%d, abundance-min %d, 1%% substitutions, 30x coverage%s"
+                                   % (CFG["name"], a.reads, a.read_len, "in total (one graph)" if sharded else "per GPU", a.k, a.abundance_min,
+                                      " -- HOSTILE genome (--skewed: low-complexity blocks, 1000 x 5 kbp repeat, homopolymer runs, 20x coverage skew): a robustness line, not the metric" if a.skewed else ""),
                        "timing_boundary": "reads resident in HBM (ASCII) -> unitigs + KC resident in HBM; includes the stages' host syncs",
                        "multi_gpu": ("single GPU" if world == 1 else
                                      "sharded: minimizer partitions p mod N; reads replicated (2-4 GPUs) or split with an all-to-all-v of super-k-mer records (8 GPUs); glue sharded by owner -- junction records, joined pairs, ranking queries and pieces each travel once over RCCL all-to-all-v (one graph; set_digest comparable with the N=1 line)"
                                      if sharded else "independent read sets per rank (no collective)"),
                        "exchange": xinfo,
                        "minimizer_size": st["minimizer_size"], "log2_partitions": st["log2_partitions"]},
-            "counts": {x: st[x] for x in ("n_occurrences", "n_distinct", "n_solid", "n_pieces", "n_unitigs", "n_records", "n_big_partitions", "n_multipass_partitions")},
+            "counts": {x: st[x] for x in ("n_occurrences", "n_distinct", "n_solid", "n_pieces", "n_unitigs", "n_records", "n_big_partitions", "n_multipass_partitions", "n_cycles")},
             "checks": checks, "checks_passed": all(checks.values()),
             "digest": {"set_digest": "%016x" % dig_last["set_digest"], "kc_sum": dig_last["kc_sum"], "kmers_in_unitigs": dig_last["kmers_in_unitigs"]},
             "stage_ms": {x: acc[x] / a.steps for x in acc},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic({"k_count_fast": "k_count_fast<", "k_compact_wave": "k_compact_wave<", "k_scan<emit>": "k_scan_fast<1, 2",
-                                                 "k_scan<hist>": "k_scan_fast<1, 0"}.get(dom, ["k_join_bucket", "k_rank8", "k_unitig_heads", "k_emit"])) if a.cfg == 3 else None,
-                         "traffic_source": "profiles/r02c_pmc_hbm_traffic_per_kernel.csv (separate rocprofv3 --pmc passes of this bench at config 3)",
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "alg_bytes_per_launch": per_kernel[dom], "avg_launch_ms": dom_ms,
                          "pipeline": {"alg_bytes": alg_total, "gpu_ms": gpu_ms,
                                       "achieved": alg_total / (gpu_ms * 1e-3) / 1e9,
                                       "frac": alg_total / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cb = cpu_baseline(a.k, a.abundance_min, a.read_len, a.cfg, a.cpu_sample_reads)
+            out["cpu_baseline"] = cb = cpu_baseline(a.k, a.abundance_min, a.read_len, gen_cfg, a.cpu_sample_reads)
             if "unitig_sets_equal" in cb:
                 out["checks"]["reference binary and GPU agree on the baseline sample (canonical unitig sets)"] = cb["unitig_sets_equal"]
                 out["checks_passed"] = all(out["checks"].values())
             if "set_digest" in cb:
                 # the same sample through the GPU path: CPU restatement and HIP kernels must agree on the whole unitig set
                 g2 = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank)
-                g2.generate_reads(a.cpu_sample_reads, a.read_len, a.cfg)
+                g2.generate_reads(a.cpu_sample_reads, a.read_len, gen_cfg)
                 g2.run()
                 d2 = g2.digest(); s2 = g2.stats(); g2.close()
                 cb["gpu_same_sample"] = {"set_digest": "%016x" % d2["set_digest"], "distinct": s2["n_distinct"], "unitigs": s2["n_unitigs"], "gpu_ms": s2["ms_total"]}
