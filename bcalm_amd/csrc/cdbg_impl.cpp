@@ -568,7 +568,9 @@ int count_impl(cdbg_ctx* c) {
             const double mean = (double)sample_records * (double)tiles / (double)ns / (double)NPS;
             capped_capacities(mean, NPS, part_cap, spill_cap);
             if ((double)part_cap * (double)NPS * RW * 8.0 > 200e9) fits = false;       // would not fit: use the exact layout
-            if ((double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && getenv("CDBG_SCAN_MODE") == nullptr) fits = false;
+            // (at least 32 sampled records in that partition: with a mean of a few records per partition -- long reads, k = 127 --
+            //  the sampled maximum is Poisson noise, and scaling it up sent the config-5 share through two passes: 598 -> 662 ms)
+            if (sample_max >= 32 && (double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && getenv("CDBG_SCAN_MODE") == nullptr) fits = false;
             else {
                 if (c->xrecs.cap > c->records.cap) c->records.swap(c->xrecs);   // (sharded reads: the previous step left the region buffer there)
                 CK(c->records.alloc((uint64_t)part_cap * NPS * RW, false));

@@ -123,8 +123,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     CDBG_SHARED uint32_t kb[SCAN_NKEY];
     CDBG_SHARED uint64_t brk[SCAN_TILE / 64 + 2];
     CDBG_SHARED uint64_t stt[SCAN_TILE / 64 + 2];
-    CDBG_SHARED uint32_t s_members, s_trav, s_nrec;
-    constexpr uint32_t LIST_CAP = SCAN_NKEY / 2;
+    CDBG_SHARED uint32_t s_members, s_trav, s_nrec, s_nstart;
+    constexpr uint32_t LIST_CAP = (SCAN_NKEY - SCAN_TILE / 2) / 2;     // staged records (two words each) behind the run-start list
 
     const int tid = threadIdx.x;
     const int k = P.k, m = P.m;
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
         uint32_t* t = cur; cur = oth; oth = t;
     }
     const uint32_t* g = cur;                           // g[jq], jq in [0, TILE+1]; junction jq <-> q = 15 + jq
-    uint32_t* lst = oth;                               // the idle ping-pong buffer stages this tile's records
+    uint32_t* lst = oth + SCAN_TILE / 2;               // the idle ping-pong buffer: run-start list (u16 x TILE), then this tile's staged records
     CDBG_SPH(2);
 
     // ---- 4. run structure: brk bit (jq-1) = junction jq does NOT continue the previous run ----
@@ -211,7 +211,11 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
         const int jq = 1 + it * SCAN_THREADS + tid;
         const int q = 15 + jq;
         const bool v = scan_all_valid(vm, q, k - 1);
-        const bool cont = v && jq != 1 && scan_all_valid(vm, q - 1, k - 1) && g[jq] == g[jq - 1];
+        // validity of the junction before: the neighbouring lane's v (one 126-bit window test per junction instead of two: this
+        // phase was 29 % of the kernel at k = 127); lane 0 of a wave asks for itself
+        const unsigned long long vmask = __ballot(v);
+        const bool vprev = (tid & 63) ? ((vmask >> ((tid & 63) - 1)) & 1ULL) : scan_all_valid(vm, q - 1, k - 1);
+        const bool cont = v && jq != 1 && vprev && g[jq] == g[jq - 1];
         const unsigned long long bm = __ballot(!cont);
         const unsigned long long sm = __ballot(v && !cont);
         if ((tid & 63) == 0) { brk[(jq - 1) >> 6] = bm; stt[(jq - 1) >> 6] = sm; }
@@ -219,14 +223,27 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     if (tid == 0) { brk[SCAN_TILE / 64] = ~0ULL; brk[SCAN_TILE / 64 + 1] = ~0ULL; }
     __syncthreads();
     CDBG_SPH(3);
+    // ---- 4b. compact the run starts (the idle ping-pong buffer holds the list): with long minimizer windows a tile of 4096
+    // junctions has ~70 runs, and walking all junctions for them kept 98 % of the lanes idle through 16 divergent iterations
+    // (35 % of the kernel at k = 127).  One wave: lane w takes the 64 junctions of stt[w].
+    uint16_t* const sl = reinterpret_cast<uint16_t*>(oth);                       // [SCAN_TILE] run starts (jq - 1), ascending
+    if (tid < 64) {
+        const unsigned long long bits0 = stt[tid];
+        const uint32_t cnt = (uint32_t)__popcll(bits0);
+        uint32_t off = wave_incl_sum_u32(cnt) - cnt;
+        unsigned long long bits = bits0;
+        while (bits) { const int j = __ffsll((long long)bits) - 1; bits &= bits - 1; sl[off++] = (uint16_t)(tid * 64 + j); }
+        if (tid == 63) s_nstart = off;
+    }
+    __syncthreads();
 
     // ---- 5. one lane per run start: find the run end, apply the boundary rules, emit ----
     const int NMAX = CAPB - k + 1;                     // member k-mers per record
     const uint32_t rank_mask = (1u << P.rank_bits) - 1u;
-    for (int it = 0; it < SCAN_TILE / SCAN_THREADS; ++it) {
-        const int jq = 1 + it * SCAN_THREADS + tid;
-        const int bit = jq - 1;
-        if (!((stt[bit >> 6] >> (bit & 63)) & 1ULL)) continue;
+    const int nstart = (int)s_nstart;
+    for (int si = tid; si < nstart; si += SCAN_THREADS) {                       // one lane per run
+        const int bit = sl[si];
+        const int jq = bit + 1;
         const uint32_t gq = g[jq];
         const uint32_t part = part_of(gq, P.log_np);
         // own partitions only (every rank scans the same text), or -- reads sharded over the ranks -- all partitions, laid
