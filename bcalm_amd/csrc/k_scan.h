@@ -206,36 +206,55 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     uint32_t* lst = oth + SCAN_TILE / 2;               // the idle ping-pong buffer: run-start list (u16 x TILE), then this tile's staged records
     CDBG_SPH(2);
 
-    // ---- 4. run structure: brk bit (jq-1) = junction jq does NOT continue the previous run ----
+    // ---- 4. run structure, bit-parallel: brk bit (jq-1) = junction jq does NOT continue the previous run ----
+    // (a) every lane: is g equal to the junction before?  One compare per junction, gathered into 64-bit words by ballot.
     for (int it = 0; it < SCAN_TILE / SCAN_THREADS; ++it) {
         const int jq = 1 + it * SCAN_THREADS + tid;
-        const int q = 15 + jq;
-        const bool v = scan_all_valid(vm, q, k - 1);
-        // validity of the junction before: the neighbouring lane's v (one 126-bit window test per junction instead of two: this
-        // phase was 29 % of the kernel at k = 127); lane 0 of a wave asks for itself
-        const unsigned long long vmask = __ballot(v);
-        const bool vprev = (tid & 63) ? ((vmask >> ((tid & 63) - 1)) & 1ULL) : scan_all_valid(vm, q - 1, k - 1);
-        const bool cont = v && jq != 1 && vprev && g[jq] == g[jq - 1];
-        const unsigned long long bm = __ballot(!cont);
-        const unsigned long long sm = __ballot(v && !cont);
-        if ((tid & 63) == 0) { brk[(jq - 1) >> 6] = bm; stt[(jq - 1) >> 6] = sm; }
+        const unsigned long long em = __ballot(g[jq] == g[jq - 1]);
+        if ((tid & 63) == 0) brk[(jq - 1) >> 6] = em;
     }
-    if (tid == 0) { brk[SCAN_TILE / 64] = ~0ULL; brk[SCAN_TILE / 64 + 1] = ~0ULL; }
     __syncthreads();
-    CDBG_SPH(3);
-    // ---- 4b. compact the run starts (the idle ping-pong buffer holds the list): with long minimizer windows a tile of 4096
-    // junctions has ~70 runs, and walking all junctions for them kept 98 % of the lanes idle through 16 divergent iterations
-    // (35 % of the kernel at k = 127).  One wave: lane w takes the 64 junctions of stt[w].
+    // (b) one wave, lane w = the 64 junctions jq = 64 w + 1 .. 64 w + 64: validity of a junction = its k-1 bases all valid, for 64
+    // junctions at once by AND-doubling over a 256-bit window of the validity bits (a 126-bit window test per junction and lane was
+    // 29 % of the kernel at k = 127); then continue / break / start words, and the run starts compacted into a list (walking all
+    // junctions for the ~70 runs of a tile kept 98 % of the lanes idle through 16 divergent iterations: another 35 %).
     uint16_t* const sl = reinterpret_cast<uint16_t*>(oth);                       // [SCAN_TILE] run starts (jq - 1), ascending
     if (tid < 64) {
-        const unsigned long long bits0 = stt[tid];
-        const uint32_t cnt = (uint32_t)__popcll(bits0);
+        const int K1 = k - 1, q0 = 16 + 64 * tid;                               // junction jq <-> tile base index q = 15 + jq
+        uint64_t X[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int bit = q0 + 64 * j, w = bit >> 5, sh = bit & 31;
+            const uint64_t lo = ((uint64_t)vm[w + 1] << 32) | vm[w];
+            X[j] = sh ? ((lo >> sh) | ((uint64_t)vm[w + 2] << (64 - sh))) : lo;
+        }
+        auto shr_and = [&](int sft) {                                           // X &= X >> sft (256-bit, zero fill), sft wave-uniform, 1 .. 127
+            const int ws = sft >> 6, bs = sft & 63;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint64_t a0 = i + ws < 4 ? X[(i + ws) & 3] : 0ULL, a1 = i + ws + 1 < 4 ? X[(i + ws + 1) & 3] : 0ULL;
+                X[i] &= bs ? ((a0 >> bs) | (a1 << (64 - bs))) : a0;
+            }
+        };
+        { int len = 1; while (2 * len <= K1) { shr_and(len); len *= 2; } if (K1 > len) shr_and(K1 - len); }
+        const uint64_t v = X[0];
+        // validity of the junction before each of mine: my word shifted up, with the top bit of the previous lane's word
+        const uint32_t top = (uint32_t)(v >> 63);
+        const uint32_t below = __shfl_up(top, 1u);
+        const uint64_t vp = (v << 1) | (tid ? (uint64_t)below : 0ULL);
+        uint64_t cont = v & vp & brk[tid];
+        if (tid == 0) cont &= ~1ULL;                                            // the tile's first junction never continues a run
+        const uint64_t starts = v & ~cont;
+        brk[tid] = ~cont; stt[tid] = starts;
+        const uint32_t cnt = (uint32_t)__popcll(starts);
         uint32_t off = wave_incl_sum_u32(cnt) - cnt;
-        unsigned long long bits = bits0;
+        unsigned long long bits = starts;
         while (bits) { const int j = __ffsll((long long)bits) - 1; bits &= bits - 1; sl[off++] = (uint16_t)(tid * 64 + j); }
         if (tid == 63) s_nstart = off;
     }
+    if (tid == 64) { brk[SCAN_TILE / 64] = ~0ULL; brk[SCAN_TILE / 64 + 1] = ~0ULL; }
     __syncthreads();
+    CDBG_SPH(3);
 
     // ---- 5. one lane per run start: find the run end, apply the boundary rules, emit ----
     const int NMAX = CAPB - k + 1;                     // member k-mers per record
