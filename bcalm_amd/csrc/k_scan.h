@@ -182,6 +182,19 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     // ---- 3. sliding-window minimum of width WN by doubling (ping-pong in LDS) ----
     uint32_t* cur = ka; uint32_t* oth = kb;
     int width = 1;
+    // (radix 4 first: a window of 111 keys is 3 passes of four reads + the final combine instead of 6 doubling passes + combine --
+    //  the same reads, half the writes and barriers; this phase is half of the kernel at k = 127 since the run structure went bit-parallel)
+    while (4 * width <= WN) {
+        for (int i = tid; i < SCAN_NKEY; i += SCAN_THREADS) {
+            uint32_t a = cur[i];
+#pragma unroll
+            for (int j = 1; j < 4; ++j) { const uint32_t b = (i + j * width < SCAN_NKEY) ? cur[i + j * width] : 0xFFFFFFFFu; a = a < b ? a : b; }
+            oth[i] = a;
+        }
+        __syncthreads();
+        uint32_t* t = cur; cur = oth; oth = t;
+        width *= 4;
+    }
     while (2 * width <= WN) {
         for (int i = tid; i < SCAN_NKEY; i += SCAN_THREADS) {
             const uint32_t a = cur[i];
