@@ -115,15 +115,21 @@ int cdbg_reset(cdbg_ctx* ctx);
 
 /* ---- Multi-GPU: one context per GPU (one process per GPU, or one host thread per GPU in one process) ----
  * The reference has nothing here (GraphUnitigsTemplate<span>::create is one shared-memory call, src/bcalm_1.cpp:57);
- * the design is SURVEY.md section 8(e) X1.  Every rank holds a SHARD of the reads.  cdbg_run / cdbg_count /
- * cdbg_compact / cdbg_glue of a context with world_size > 1 perform, through the context's transport:
- *   count   scan the own reads into super-k-mer records of ALL minimizer partitions, all-to-all-v the records to the
- *           partition owners (partition p belongs to rank p % world_size), count the own partitions
+ * the design is SURVEY.md section 8(e).  Rank r owns the minimizer partitions p with p % world_size == r.  cdbg_run /
+ * cdbg_count / cdbg_compact / cdbg_glue of a context with world_size > 1 perform, through the context's transport:
+ *   count   reads_replicated = 0 (X1): scan the own SHARD of the reads into super-k-mer records of ALL partitions (one capped
+ *           pass, regions squeezed into the owner-major layout), all-to-all-v the records to the partition owners, count the
+ *           own partitions.  reads_replicated = 1 (X0): scan ALL reads for the own partitions only; nothing travels.
  *   compact the own buckets (no exchange: the owner of a junction holds every solid k-mer adjacent to it)
- *   glue    all-gather the pieces (lengths, abundance sums, bases 2 bit packed) and the junction log; hash-join of the
- *           junctions sharded by key hash, partner ids combined with one MAX all-reduce; chains ranked on every rank;
- *           every rank emits the unitigs whose first piece it owns (emit_replicated = 0)
- * The transport moves bytes between DEVICE buffers of the ranks.  Built in: RCCL (ncclSend/ncclRecv all-to-all-v,
+ *   glue    emit_replicated = 0: sharded by owner (bcalm_amd/csrc/k_dglue.h) -- every junction record travels once to the rank
+ *           its key hashes to, every joined pair once to the owner of the end, list ranking runs on the owners of the pieces
+ *           with one query / reply exchange per round, every piece travels once to the owner of its unitig's head; each rank
+ *           ends with the unitigs it owns (their union is the graph).  emit_replicated = 1, or closed chains that cross ranks:
+ *           the replicated exchange -- pieces + junction log all-gathered, join sharded by key hash with one MAX all-reduce,
+ *           chains ranked on every rank; every rank ends with the complete set.
+ * A rank that received no reads still takes part in every collective; a rank-local failure is agreed on before the next
+ * collective stage, so that every rank returns an error together instead of leaving its peers inside the transport.
+ * The transport moves bytes between DEVICE buffers of the ranks.  Built in: RCCL (grouped ncclSend/ncclRecv all-to-all-v,
  * ncclAllGather, ncclAllReduce over xGMI), bound at run time from librccl.so.1:
  *   cdbg_comm_unique_id   rank 0 creates the 128-byte id; the caller distributes it (MPI, torch.distributed, a file)
  *   cdbg_comm_init_rccl   every rank, after cdbg_create on its device
@@ -131,8 +137,8 @@ int cdbg_reset(cdbg_ctx* ctx);
  * All four functions are collective: every rank calls them in the same order; they return 0 on success.
  *   all_gather_u64  host buffers: n words from every rank, rank order
  *   all_to_all_v    device buffers: send_cnt[r] bytes at send_off[r] go to rank r; recv_cnt[s] bytes from rank s land at recv_off[s]
- *   all_gather_v    device buffers: nbytes of every rank (recv_cnt[s], known from an all_gather_u64) at recv_off[s]
- *   all_reduce_max_i32  in place on a device buffer of n int32 */
+ *   all_gather_v    device buffers: nbytes of every rank (recv_cnt[s], known from an all_gather_u64) at recv_off[s]   (replicated exchange only)
+ *   all_reduce_max_i32  in place on a device buffer of n int32                                                        (replicated exchange only) */
 typedef struct cdbg_transport {
     void* user;
     int (*all_gather_u64)(void* user, const uint64_t* send, uint64_t* recv, int n);
@@ -190,7 +196,8 @@ int cdbg_fetch_links(cdbg_ctx* ctx, uint64_t* end_off, uint32_t* link_to);
  *   CDBG_REPAIR_MAX_PASSES=<n>    LDS pass limit of the spill-repair launch   CDBG_NO_COUNT_TIER2=1     skip the second one-pass count tier
  *   CDBG_GLUE_LOG=1               junction records through the sequential log CDBG_GLUE_TABLE=1         global-table junction join
  *   CDBG_JOIN_LOG_JB=<n>          log2 of the join buckets (0 forces the overflow fallback)
- *   CDBG_FORCE_MULTI=1            run the multi-GPU data path with one rank   CDBG_STAGE_BYTES, CDBG_STREAM_MIN_BYTES, CDBG_STREAM_BATCH_TILES: ingest staging sizes */
+ *   CDBG_FORCE_MULTI=1            run the multi-GPU data path with one rank   CDBG_STAGE_BYTES, CDBG_STREAM_MIN_BYTES, CDBG_STREAM_BATCH_TILES: ingest staging sizes
+ *   CDBG_GLUE_REPLICATED=1        the replicated glue exchange for emit_replicated = 0 as well       CDBG_HOST_MARKS=1  wall-clock marks between host-side phases (stderr) */
 
 #ifdef __cplusplus
 }
