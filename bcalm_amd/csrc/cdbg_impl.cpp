@@ -103,11 +103,11 @@ constexpr int TS_COUNT_1 = CDBG_TSC1, TS_COUNT_2 = CDBG_TSC2, TS_COUNT_4 = CDBG_
 constexpr int TS_COMPACT_1 = CDBG_TSK1, TS_COMPACT_2 = 512, TS_COMPACT_4 = 512;
 template <int W> struct Cfg;
 // TSW: slots of the wave-per-bucket compaction tier (buckets of at most TSW / 2 entries; k_compact_wave.h)
-template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1, TSK2 = 2 * TS_COMPACT_1, NTC = CDBG_NTC1, TSW = 512; };
+template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1, TSK2 = 2 * TS_COMPACT_1, NTC = CDBG_NTC1, TSW = 512, TSW2 = 512; };   // (TSW2 == TSW: no second wave tier)
 #ifndef CDBG_TSW2
 #define CDBG_TSW2 256
 #endif
-template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, TSK2 = 2 * TS_COMPACT_2, NTC = 512, TSW = CDBG_TSW2; };
+template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, TSK2 = 2 * TS_COMPACT_2, NTC = 512, TSW = CDBG_TSW2, TSW2 = 2 * CDBG_TSW2; };
 // (W >= 3: 512 threads with member-balanced wave shares and 8-record batches: 2 x 8 waves per CU instead of 2 x 4;
 //  config-5 share: count tier 1 257 -> 214 ms, tier 2 87 -> 62 ms.  Before the balanced shares 512 threads LOST: 341 -> 464 ms)
 #ifndef CDBG_NTC4
@@ -116,10 +116,10 @@ template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMP
 #ifndef CDBG_TSW4
 #define CDBG_TSW4 256
 #endif
-template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, TSK2 = 2 * TS_COMPACT_4, NTC = CDBG_NTC4, TSW = CDBG_TSW4; };
+template <> struct Cfg<4> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, TSK2 = 2 * TS_COMPACT_4, NTC = CDBG_NTC4, TSW = CDBG_TSW4, TSW2 = 2 * CDBG_TSW4; };
 // three-word k-mers (64 <= k <= 95, the span-96 entry of the reference's KSIZE_LIST, README.md:93-99): the four-word geometry
 // with 3/4 of the key bytes (count table 56 KB instead of 72)
-template <> struct Cfg<3> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, TSK2 = 2 * TS_COMPACT_4, NTC = CDBG_NTC4, TSW = CDBG_TSW4; };
+template <> struct Cfg<3> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMPACT_4, TSK2 = 2 * TS_COMPACT_4, NTC = CDBG_NTC4, TSW = CDBG_TSW4, TSW2 = 2 * CDBG_TSW4; };
 
 #ifndef CDBG_PGRID
 #define CDBG_PGRID (256 * 12)
@@ -313,7 +313,7 @@ int read_u32(const uint32_t* dptr, uint32_t* out, size_t n = 1) {
 }
 int check_device_error(cdbg_ctx* c, const char* where) {
     uint32_t e = 0; CK(read_u32(c->derr.p, &e));
-    if (e) return fail(CDBG_E_INTERNAL, "%s: device reported error %u (1 solid overflow, 2 scratch sizing, 3 piece overflow, 4 unitig overflow, 5 glue log overflow)", where, e);
+    if (e) return fail(CDBG_E_INTERNAL, "%s: device reported error %u (1 solid overflow, 2 scratch sizing, 3 piece overflow, 4 unitig overflow, 5 glue log overflow, 9 junction-ownership flag of a k-mer wrong [simulator build only])", where, e);
     HIPCK(hipGetLastError());
     return CDBG_OK;
 }
@@ -879,6 +879,21 @@ int compact_impl(cdbg_ctx* c) {
             HIPCK(hipStreamSynchronize(s));
             hm.mark("compact: buffers + wave tier");
             CK(read_u32(c->big_count.p, &nbig));
+        }
+        if (nbig && Cfg<W>::TSW2 > Cfg<W>::TSW) {
+            // tier 0b: the deferred buckets again one wave each, with a table twice the size (fewer waves per CU, but no
+            // workgroup barriers: at the config-4 share the workgroup tier below spent 44 ms on the 129..256-entry buckets)
+            CK(c->big_list2.alloc(nbig, false)); CK(c->big_count2.alloc(4, true));
+            CompactParams k0 = kp;
+            k0.part_list = c->big_list.p; k0.n_items = nbig; k0.big_list = c->big_list2.p; k0.big_count = c->big_count2.p;
+            HIPCK(hipMemsetAsync(c->cursors.p + 5, 0, sizeof(uint64_t), s));       // the bucket queue restarts
+            CompactWaveParams wp{ k0, nbig, reinterpret_cast<uint32_t*>(c->cursors.p + 5) };
+            const uint64_t wgrid = resident_grid(k_compact_wave<W, Cfg<W>::TSW2>, CW_THREADS, 256 * 2);
+            CDBG_LAUNCH((k_compact_wave<W, Cfg<W>::TSW2>), std::min<uint64_t>((nbig + CW_THREADS / 64 - 1) / (CW_THREADS / 64), wgrid), CW_THREADS, s, wp);
+            HIPCK(hipStreamSynchronize(s));
+            CK(read_u32(c->big_count2.p, &nbig));
+            // (the survivors are the input of the workgroup tiers)
+            if (nbig) HIPCK(hipMemcpyAsync(c->big_list.p, c->big_list2.p, (size_t)nbig * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
         }
         if (nbig) {                                          // tier 1: a workgroup per bucket, LDS table of TS slots
             CK(c->big_list2.alloc(nbig, false)); CK(c->big_count2.alloc(4, true));

@@ -116,6 +116,17 @@ CDBG_DEV uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfi
 #define CDBG_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 #endif
 CDBG_DEV uint64_t uni_u64(uint64_t v) { return ((uint64_t)uni_u32((uint32_t)(v >> 32)) << 32) | uni_u32((uint32_t)v); }
+// v in the lanes whose bit of a wave-uniform 64-bit mask (from uni_u64) is set, 0 in the others.  A mask in a scalar
+// register pair IS a lane predicate on CDNA: one v_cndmask, where (mask >> lane) & 1 costs a 64-bit shift per lane.
+#ifdef CDBG_HOSTSIM
+CDBG_DEV uint32_t lane_pick_u32(uint64_t mask, uint32_t v, int lane) { return ((mask >> lane) & 1ULL) ? v : 0u; }
+#else
+CDBG_DEV uint32_t lane_pick_u32(uint64_t mask, uint32_t v, int) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(mask));
+    return r;
+}
+#endif
 CDBG_DEV uint64_t wave_sum_u64(uint64_t v) {        // all lanes -> the wave total (kernel epilogues only)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);

@@ -143,7 +143,6 @@ CDBG_DEV Kmer<W> canon_junction(const Kmer<W>& u_out, int k) {
     Kmer<W> r = j.rc(k - 1);
     return (r < j) ? r : j;
 }
-
 // successors of oriented k-mer u present in the table; returns count, last hit in (slot, enter_end)
 template <int W>
 CDBG_DEV int probe_succ(const KTable<W>& T, const Kmer<W>& u, int k, uint32_t& slot, uint32_t& enter_end) {
@@ -212,13 +211,20 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
     for (uint32_t e = tid; e < E; e += COMPACT_THREADS) {
         Kmer<W> x;
         for (int i = 0; i < W; ++i) x.w[i] = P.solid_keys[(so + e) * W + i];
+        const uint64_t fl = x.w[W - 1] & KEY_FLAGS;           // (KEY_FOREIGN_*, k_count.h: the junctions this bucket does NOT own)
+        x.w[W - 1] &= ~KEY_FLAGS;
         bool nw; const uint32_t s = ktable_insert<W, GLOBAL>(T, x, nw);
         const uint32_t cv = P.solid_cnt[so + e];
         cnt[s] = cv;
         // vis byte: bit 0 visited (walk 1), bit 1 traveller (cnt[] is recycled for byte offsets later),
         // bit 2 / 3: the junction at the LEFT / RIGHT end of the label is owned by this bucket
-        uint32_t gl, gr; kmer_junction_mins<W>(x, k, P.m, gl, gr);
-        vis[s] = (uint8_t)(((cv & TRAV_FLAG) ? 2u : 0u) | (part_of(gl, P.log_np) == pg ? 4u : 0u) | (part_of(gr, P.log_np) == pg ? 8u : 0u));
+        vis[s] = (uint8_t)(((cv & TRAV_FLAG) ? 2u : 0u) | ((fl & KEY_FOREIGN_L) ? 0u : 4u) | ((fl & KEY_FOREIGN_R) ? 0u : 8u));
+#ifdef CDBG_HOSTSIM
+        {   // (the simulator build checks every flag against the definition)
+            uint32_t gl, gr; kmer_junction_mins<W>(x, k, P.m, gl, gr);
+            if ((part_of(gl, P.log_np) == pg) != !(fl & KEY_FOREIGN_L) || (part_of(gr, P.log_np) == pg) != !(fl & KEY_FOREIGN_R)) *P.error = 9;
+        }
+#endif
         slots[e] = s;
     }
     block_sync<GLOBAL>();

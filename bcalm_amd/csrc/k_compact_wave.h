@@ -198,11 +198,20 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
             Kmer<W> x;
 #pragma unroll
             for (int i = 0; i < W; ++i) x.w[i] = X.key[j * W + i];
+            // which of the two junctions this bucket owns came along in the top bits of the key (KEY_FOREIGN_*, k_count.h:
+            // the scan knows; recomputing both junction minimizers here took a quarter of this kernel at k = 55)
+            const uint64_t fl = x.w[W - 1] & KEY_FLAGS;
+            x.w[W - 1] &= ~KEY_FLAGS;
             const uint32_t cv = X.cnt[j];
             const uint32_t s = cw_insert<W, TSW>(L.keys, x);
             L.ent[s] = (uint16_t)e; L.slot_of[e] = (uint16_t)s; L.cnt[e] = cv;
-            uint32_t gl, gr; kmer_junction_mins<W>(x, k, P.m, gl, gr);
-            L.vis[e] = (uint8_t)(((cv & TRAV_FLAG) ? 2u : 0u) | (part_of(gl, P.log_np) == pg ? 4u : 0u) | (part_of(gr, P.log_np) == pg ? 8u : 0u));
+            L.vis[e] = (uint8_t)(((cv & TRAV_FLAG) ? 2u : 0u) | ((fl & KEY_FOREIGN_L) ? 0u : 4u) | ((fl & KEY_FOREIGN_R) ? 0u : 8u));
+#ifdef CDBG_HOSTSIM
+            {   // (the simulator build checks every flag against the definition)
+                uint32_t gl, gr; kmer_junction_mins<W>(x, k, P.m, gl, gr);
+                if ((part_of(gl, P.log_np) == pg) != !(fl & KEY_FOREIGN_L) || (part_of(gr, P.log_np) == pg) != !(fl & KEY_FOREIGN_R)) *P.error = 9;
+            }
+#endif
             if (!(cv & TRAV_FLAG)) ++n_home;
         }
     }
@@ -439,7 +448,7 @@ template <int W, int TSW>
 #ifndef CDBG_CW_WAVES4
 #define CDBG_CW_WAVES4 3
 #endif
-__global__ void __launch_bounds__(CW_THREADS, W == 1 ? CDBG_CW_WAVES1 : W == 2 ? CDBG_CW_WAVES2 : CDBG_CW_WAVES4) k_compact_wave(CompactWaveParams WP) {
+__global__ void __launch_bounds__(CW_THREADS, W == 1 ? CDBG_CW_WAVES1 : W == 2 ? (TSW > 256 ? 2 : CDBG_CW_WAVES2) : (TSW > 256 ? 2 : CDBG_CW_WAVES4)) k_compact_wave(CompactWaveParams WP) {
     CDBG_SHARED CompactWaveLds<W, TSW> Ls[CW_THREADS / 64];
     const CompactParams& P = WP.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)uni_u32((uint32_t)tid >> 6);
@@ -463,26 +472,28 @@ __global__ void __launch_bounds__(CW_THREADS, W == 1 ? CDBG_CW_WAVES1 : W == 2 ?
     uint32_t q_batch, q_j = 0, q_next_raw;              // id stream: current batch, position in it, next batch (raw: lane 0 only)
 #define CW_TICKET(dst) do { uint32_t t_ = 0; if (lane == 0) t_ = atomic_add_u32(queue, 1u); (dst) = t_; } while (0)
 #define CW_NEXT_ID(dst) do { if (q_j == CW_BATCH) { q_batch = uni_u32(q_next_raw); CW_TICKET(q_next_raw); q_j = 0; } (dst) = q_batch * CW_BATCH + q_j; ++q_j; } while (0)
-#define CW_SEG_LOAD(p_, n_, off_) do { const uint32_t q_ = (p_) < nb ? (p_) : nb - 1u; (n_) = seg_n[q_]; (off_) = seg_off[q_]; } while (0)
+    // (second wave tier: the items are entries of part_list -- the buckets the first tier deferred; one more dependent load)
+    const uint32_t* const plist = P.part_list;
+#define CW_SEG_LOAD(p_, n_, off_, id_) do { uint32_t q_ = (p_) < nb ? (p_) : nb - 1u; if (plist) q_ = plist[q_]; (id_) = q_; (n_) = seg_n[q_]; (off_) = seg_off[q_]; } while (0)
     CwEntries<W, TSW> X0, X1;
     uint32_t p_cur, p_nxt, p_nn;                        // buckets: being compacted, entries requested, descriptor requested
     { uint32_t t; CW_TICKET(t); q_batch = uni_u32(t); CW_TICKET(q_next_raw); }
     CW_NEXT_ID(p_cur); CW_NEXT_ID(p_nxt); CW_NEXT_ID(p_nn);
-    uint32_t E_cur, segn_nxt; uint64_t sego_nxt;
+    uint32_t E_cur, segn_nxt, id_cur, id_nxt; uint64_t sego_nxt;
     {
-        uint32_t n0; uint64_t o0; CW_SEG_LOAD(p_cur, n0, o0);
-        E_cur = p_cur < nb ? uni_u32(n0) : 0u;
+        uint32_t n0; uint64_t o0; CW_SEG_LOAD(p_cur, n0, o0, id_cur);
+        E_cur = p_cur < nb ? uni_u32(n0) : 0u; id_cur = uni_u32(id_cur);
         cw_load_entries<W, TSW>(P, uni_u64(o0), E_cur, lane, X0);
     }
-    CW_SEG_LOAD(p_nxt, segn_nxt, sego_nxt);
+    CW_SEG_LOAD(p_nxt, segn_nxt, sego_nxt, id_nxt);
 #define CW_ONE_BUCKET(Xc, Xn) do {                                                                                         \
-        uint32_t segn_nn; uint64_t sego_nn; CW_SEG_LOAD(p_nn, segn_nn, sego_nn);            /* descriptor two buckets ahead */ \
+        uint32_t segn_nn, id_nn; uint64_t sego_nn; CW_SEG_LOAD(p_nn, segn_nn, sego_nn, id_nn);  /* descriptor two buckets ahead */ \
         const uint32_t E_nxt = p_nxt < nb ? uni_u32(segn_nxt) : 0u;                                                         \
         cw_load_entries<W, TSW>(P, uni_u64(sego_nxt), E_nxt, lane, Xn);                     /* entries one bucket ahead */     \
-        if (E_cur > (uint32_t)(TSW / 2)) {                  /* more entries than the wave tier holds: workgroup tiers */        \
-            if (lane == 0) { const uint32_t i_ = atomic_add_u32(P.big_count, 1u); P.big_list[i_] = p_cur; }                 \
-        } else if (E_cur) compact_bucket_wave<W, TSW>(P, L, p_cur, E_cur, lane, Xc, pc, bc, lc, acc);                       \
-        p_cur = p_nxt; E_cur = E_nxt; p_nxt = p_nn; segn_nxt = segn_nn; sego_nxt = sego_nn;                                 \
+        if (E_cur > (uint32_t)(TSW / 2)) {                  /* more entries than this wave tier holds: the next tier */         \
+            if (lane == 0) { const uint32_t i_ = atomic_add_u32(P.big_count, 1u); P.big_list[i_] = id_cur; }                \
+        } else if (E_cur) compact_bucket_wave<W, TSW>(P, L, id_cur, E_cur, lane, Xc, pc, bc, lc, acc);                      \
+        p_cur = p_nxt; E_cur = E_nxt; id_cur = uni_u32(id_nxt); p_nxt = p_nn; segn_nxt = segn_nn; sego_nxt = sego_nn; id_nxt = id_nn; \
         CW_NEXT_ID(p_nn);                                                                                                   \
     } while (0)
     while (p_cur < nb) {

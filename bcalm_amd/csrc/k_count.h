@@ -42,9 +42,30 @@ CDBG_DEV void count_add_sat(uint32_t* p) {
 CDBG_HD uint32_t count_value(uint32_t word) { const uint32_t n = word & COUNT_MAX; return n >= COUNT_SAT ? COUNT_MAX : n; }   // abundance of a count word
 CDBG_HD uint32_t count_word_out(uint32_t word) { return (word & TRAV_FLAG) | count_value(word); }                            // what the solid array holds
 // Multi-word keys (W > 1) are claimed through their TOP word: a k-mer or (k-1)-mer of k < 32 W (the span rule) leaves
-// the two top bits of that word clear, so all-ones can mean "empty" and bit 63 "claimed, lower words not written
-// yet".  One 64-bit compare-and-swap per probe, no separate state array.
+// the two top bits of that word clear.  The join tables of the glue (k_glue.h) use all-ones for "empty" and bit 63 for
+// "claimed, lower words not written yet".  The k-mer tables of this stage put two facts about the k-mer into those
+// bits (KEY_FOREIGN_*: never both), so there BOTH bits set mean a state: all-ones = empty, anything else = "claimed,
+// lower words not written yet" with the low 62 bits of the claimer's top word beside it (key_pending): a lane that meets
+// the claim of ANOTHER key moves on at once, only a lane with the same 62 bits looks again.
+// One 64-bit compare-and-swap per probe, no separate state array.
 constexpr uint64_t KEY_EMPTY = ~0ULL, KEY_PENDING = 1ULL << 63;
+// A solid k-mer travels from the count tables to the compaction with two flags in the top bits of its top word: the
+// junction at the LEFT / RIGHT end of its canonical label belongs to ANOTHER bucket.  The scan knows (record meta bits
+// 10 / 11, k_scan.h); the flags are a function of the k-mer and of the bucket, so every occurrence of a k-mer in a
+// bucket forms the same 64 W-bit key and the tables need no extra operation for them.  A home k-mer has at least one
+// junction in its bucket, a traveller exactly one: both flags together do not occur.
+constexpr uint64_t KEY_FOREIGN_L = 1ULL << 62, KEY_FOREIGN_R = 1ULL << 63, KEY_FLAGS = KEY_FOREIGN_L | KEY_FOREIGN_R;
+// the claim word of a key while its lower words are being written (62 ones would read as EMPTY: one less -- a lane whose
+// own 62 bits are that value then waits for a key that is not its own, which ends when that key is published)
+CDBG_HD uint64_t key_pending(uint64_t top) {
+    const uint64_t low = top & ~KEY_FLAGS;
+    return KEY_FLAGS | (low == ~KEY_FLAGS ? low - 1ULL : low);
+}
+// flags of a member k-mer: it is the first / last member of its record, it was stored in read orientation or reversed
+CDBG_HD uint64_t key_flags(bool left_foreign_in_read, bool right_foreign_in_read, bool reversed) {
+    const bool l = reversed ? right_foreign_in_read : left_foreign_in_read, r = reversed ? left_foreign_in_read : right_foreign_in_read;
+    return (l ? KEY_FOREIGN_L : 0ULL) | (r ? KEY_FOREIGN_R : 0ULL);
+}
 
 // ---------------------------------------------------------------------------
 // Open-address table of W-word keys.  W == 1: the key word itself is claimed with
@@ -105,26 +126,24 @@ CDBG_DEV uint32_t ktable_insert(const KTable<W>& t, const Kmer<W>& key, bool& is
     } else {
         // Single-exit loop with the publish INSIDE the iteration that claimed the slot: lanes of one wave that insert
         // the same key must see the claimer finish before the back edge (a wave has no independent thread scheduling,
-        // so a claimer parked behind the loop exit while a sibling lane spins on PENDING would never run again).
-        const uint64_t top = key.w[W - 1];
+        // so a claimer parked behind the loop exit while a sibling lane spins on the pending claim would never run again).
+        const uint64_t top = key.w[W - 1], ptop = key_pending(top);
         uint32_t probes = 0, res = 0xFFFFFFFFu; bool done = false;
 #pragma clang loop unroll(disable)
         do {
             uint64_t* const claim = &t.keys[(uint64_t)s * W + (W - 1)];
-            const uint64_t old = atomic_cas_u64(claim, KEY_EMPTY, top | KEY_PENDING);
+            const uint64_t old = atomic_cas_u64(claim, KEY_EMPTY, ptop);
             bool advance = true;
             if (old == KEY_EMPTY) {                          // claimed: write the lower words, then publish the top word
                 for (int i = 0; i < W - 1; ++i) t.keys[(uint64_t)s * W + i] = key.w[i];
                 if (GLOBAL) __threadfence(); else CDBG_LDS_FENCE();
                 atomic_exch_u64(claim, top);
                 is_new = true; res = s; done = true; advance = false;
-            } else if ((old & ~KEY_PENDING) == top) {
-                if (old & KEY_PENDING) { CDBG_SPIN_YIELD(); advance = false; }   // being written by another lane: look again
-                else {
-                    bool eq = true;
-                    for (int i = 0; i < W - 1; ++i) eq &= ((GLOBAL ? ld_agent_u64(&t.keys[(uint64_t)s * W + i]) : t.keys[(uint64_t)s * W + i]) == key.w[i]);
-                    if (eq) { res = s; done = true; advance = false; }
-                }
+            } else if (old == ptop) { CDBG_SPIN_YIELD(); advance = false; }   // being written by another lane (this key, as far as one can tell): look again
+            else if (old == top) {
+                bool eq = true;
+                for (int i = 0; i < W - 1; ++i) eq &= ((GLOBAL ? ld_agent_u64(&t.keys[(uint64_t)s * W + i]) : t.keys[(uint64_t)s * W + i]) == key.w[i]);
+                if (eq) { res = s; done = true; advance = false; }
             }
             if (advance) { s = (s + 1) & t.mask; ++probes; }
         } while (!done && probes < max_probe);
@@ -200,6 +219,8 @@ struct RecView {
     CDBG_DEV int n() const { return (int)(r[0] & 0xFFu); }
     CDBG_DEV bool first_trav() const { return (r[0] >> 8) & 1u; }
     CDBG_DEV bool last_trav() const { return (r[0] >> 9) & 1u; }
+    CDBG_DEV bool first_foreign() const { return (r[0] >> 10) & 1u; }
+    CDBG_DEV bool last_foreign() const { return (r[0] >> 11) & 1u; }
     CDBG_DEV uint32_t base(int i) const {
         const int pos = 64 * RecFmt<W>::RW - 2 * (i + 1);
         const int wi = pos >> 6;
@@ -374,10 +395,13 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                             const int t = g - ex, qn = Q.n();
                             const Kmer<W> fw = Q.kmer(t, k);
                             const Kmer<W> rc = fw.rc(k);
-                            const Kmer<W>& can = (rc < fw) ? rc : fw;
+                            const bool rev = rc < fw;
+                            const Kmer<W>& can = rev ? rc : fw;
                             if (npass == 1 || ((can.hash() >> 20) & (npass - 1)) == pass) {
                                 bool is_new;
-                                const uint32_t s = ktable_insert<W, GLOBAL>(T, can, is_new, 64u);
+                                Kmer<W> ck = can;                     // (the key carries the foreign-junction flags: KEY_FOREIGN_*)
+                                ck.w[W - 1] |= key_flags(t == 0 && Q.first_foreign(), t == qn - 1 && Q.last_foreign(), rev);
+                                const uint32_t s = ktable_insert<W, GLOBAL>(T, ck, is_new, 64u);
                                 if (s == 0xFFFFFFFFu) s_over = 1;   // table (nearly) full: this pass is void
                                 else {
                                     if (is_new) {

@@ -40,17 +40,18 @@ template <int W> struct CountGeom {
 // LDS of one workgroup:
 //   keys / cnt   the open-address table (claim word EMPTY <=> slot free)
 //   stage        per wave: the COUNT_CB records of the batch being expanded
-//   rbase        per wave: 128 - 2k + 2 * (first member position) of each staged record (bit offset of member g = rbase - 2g)
+//   rinfo        per wave: 128 - 2k + 2 * (first member position) of each staged record (bit offset of member g = rinfo - 2g),
+//                plus the record's four boundary facts in the top bits (see where it is written)
 //   smask        per wave: bit g set <=> a record of the batch starts at member position g
-//   tmask        per wave: bit g set <=> the member at position g is a traveller copy
+//   emask        per wave: bit g set <=> the member at position g is the last of a record that has something to say about it
 template <int W, int TS, int NT>
 struct CountFastLds {
     uint64_t keys[TS * W];
     uint32_t cnt[TS];
     uint64_t stage[(NT / 64) * CountCb<W>::V * RecFmt<W>::RW + 2];   // + 2: the dword window of the last record may over-read (up to 4 dwords)
     uint64_t smask[(NT / 64) * CountGeom<W>::MASKW];
-    uint64_t tmask[(NT / 64) * CountGeom<W>::MASKW];
-    uint16_t rbase[(NT / 64) * CountCb<W>::V];
+    uint64_t emask[(NT / 64) * CountGeom<W>::MASKW];
+    uint32_t rinfo[(NT / 64) * CountCb<W>::V];
     uint32_t fill[2], wr[2];                             // per partition parity: new keys / solid entries written
     uint32_t over;
     uint64_t cbase;                                      // chunk hand-out broadcast
@@ -167,10 +168,9 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
     constexpr int COUNT_CB = CountCb<W>::V;
     uint64_t* const stage = L.stage + (size_t)wave * COUNT_CB * RW;
     uint64_t* const smask = L.smask + (size_t)wave * MASKW;
-    uint64_t* const tmask = L.tmask + (size_t)wave * MASKW;
-    uint16_t* const rbase = L.rbase + (size_t)wave * COUNT_CB;
+    uint64_t* const emask = L.emask + (size_t)wave * MASKW;
+    uint32_t* const rinfo = L.rinfo + (size_t)wave * COUNT_CB;
     const uint64_t lane_le = lane == 63 ? ~0ULL : ((2ULL << lane) - 1ULL);      // bits 0 .. lane
-    const uint64_t lane_bit = 1ULL << lane;
     const uint32_t RBITS = 64u * RW;                                            // bits of a record
     const uint64_t kmask1 = ~0ULL >> (64 - 2 * (k < 32 ? k : 31));             // (W == 1 only)
 
@@ -201,24 +201,36 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
                 const int si = lane - (fa > lo ? fa : lo);
 #pragma unroll
                 for (int i = 0; i < RW; ++i) stage[si * RW + i] = R.r[i];
-                rbase[si] = (uint16_t)(RBITS - 2u * (uint32_t)k - 2u * first + 2u * excl);
+                // Bit base of the record's members (even, < 2^13) and, in the bits above, the record's four boundary facts (meta
+                // bits 8..11, k_scan.h) laid out for the member loop: a bit-field merge of the word as seen by the FIRST member
+                // and as seen by the LAST one leaves each fact in the lanes it applies to, and the two foreign-junction facts
+                // land where the key wants them (bits 31 / 30 = bits 63 / 62 of the top word) -- twice, so that a reversed
+                // member shifts the swapped pair in.  A wave that holds only a part of the record keeps the facts of its ends.
+                const uint32_t meta = (uint32_t)R.r[0];
+                const uint32_t head = first == 0u ? meta : 0u, tail = first + n == nfull ? meta : 0u;
+                const uint32_t f0 = (head >> 10) & 1u, f1 = (tail >> 11) & 1u, ft = (head >> 8) & 1u, lt = (tail >> 9) & 1u;
+                rinfo[si] = (RBITS - 2u * (uint32_t)k - 2u * first + 2u * excl) | (f1 << 31) | (f0 << 30) | (f0 << 29) | (f1 << 28) | (ft << 27) | (lt << 26);
                 atomic_or_u64(&smask[excl >> 6], 1ULL << (excl & 63u));
-                const uint32_t meta = (uint32_t)R.r[0], last = excl + n - 1u;
-                if ((meta & 0x100u) && first == 0u) atomic_or_u64(&tmask[excl >> 6], 1ULL << (excl & 63u));
-                if ((meta & 0x200u) && first + n == nfull) atomic_or_u64(&tmask[last >> 6], 1ULL << (last & 63u));
+                const uint32_t last = excl + n - 1u;
+                if (f1 | lt) atomic_or_u64(&emask[last >> 6], 1ULL << (last & 63u));
             }
             CDBG_WAVE_SYNC();
             if (!A.issued) { CDBG_FPH(1); count_issue_ahead<W, NW, CAPPED>(P, A, wave, lane); }        // behind the wait for this partition's own records
             uint32_t started = 0;                                             // records of the batch that start before the step's window
             for (uint32_t g0 = 0; g0 < total; g0 += 64) {                     // wave-uniform trip count
-                const uint64_t M = smask[g0 >> 6], T = tmask[g0 >> 6];
+                const uint64_t M = uni_u64(smask[g0 >> 6]), E = uni_u64(emask[g0 >> 6]);   // (scalar: used as lane predicates below)
                 const uint32_t g = g0 + (uint32_t)lane;
                 const bool active = g < total;
                 const uint32_t slot = started + (uint32_t)__popcll(M & lane_le) - 1u;   // active lanes: >= 0 (member 0 starts record 0)
                 started += (uint32_t)__popcll(M);
                 bool is_new = false;
                 if (active) {
-                    const uint32_t sh = (uint32_t)rbase[slot] - 2u * g;       // the member's k-mer = record bits [sh, sh + 2k)
+                    const uint32_t ri = rinfo[slot];
+                    const uint32_t sh = (ri & 0x1FFFu) - 2u * g;              // the member's k-mer = record bits [sh, sh + 2k)
+                    // the record's facts about its first / last member, in the lanes that hold that member
+                    const uint32_t as_first = lane_pick_u32(M, ri, lane), as_last = lane_pick_u32(E, ri, lane);
+                    const uint32_t facts = (as_first & 0x68000000u) | (as_last & ~0x68000000u);   // (v_bfi_b32)
+                    const bool trav = (facts & 0x0C000000u) != 0u;
                     Kmer<W> fw;
                     if (W == 1) {
                         // 128-bit record, sh >= 16: the three dwords from bit sh on, two funnel shifts
@@ -239,7 +251,11 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
                         fw.mask(k);
                     }
                     const Kmer<W> rc = fw.rc(k);
-                    const Kmer<W>& can = (rc < fw) ? rc : fw;
+                    const bool rev = rc < fw;
+                    const Kmer<W>& can = rev ? rc : fw;
+                    // the key carries the foreign-junction flags (KEY_FOREIGN_*, k_count.h): the same for every occurrence
+                    // (bits 31 / 30 of `facts`: right / left junction foreign in read orientation; bits 29 / 28: the same two swapped)
+                    const uint64_t ktop = can.w[W - 1] | ((uint64_t)((rev ? facts << 2 : facts) & 0xC0000000u) << 32);
                     uint32_t s = can.hash_lds() >> (32 - LOG_TS);
                     bool hit;
                     if (W == 1) {
@@ -248,33 +264,31 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
                         uint32_t probes = 0; uint64_t old;
 #pragma clang loop unroll(disable)
                         for (;;) {
-                            old = atomic_cas_u64(&L.keys[s], ~0ULL, can.w[0]);
-                            if ((old == ~0ULL) | (old == can.w[0]) | (++probes == 64u)) break;
+                            old = atomic_cas_u64(&L.keys[s], ~0ULL, ktop);
+                            if ((old == ~0ULL) | (old == ktop) | (++probes == 64u)) break;
                             s = (s + 1) & (TS - 1);
                         }
                         is_new = old == ~0ULL;
-                        hit = is_new | (old == can.w[0]);
+                        hit = is_new | (old == ktop);
                     } else {
-                        const uint64_t top = can.w[W - 1];
+                        const uint64_t top = ktop, ptop = key_pending(ktop);
                         uint32_t probes = 0;
                         hit = false;
 #pragma clang loop unroll(disable)
                         do {                                                   // (single exit, publish inside the iteration: see ktable_insert)
                             uint64_t* const claim = &L.keys[(uint64_t)s * W + (W - 1)];
-                            const uint64_t old = atomic_cas_u64(claim, KEY_EMPTY, top | KEY_PENDING);
+                            const uint64_t old = atomic_cas_u64(claim, KEY_EMPTY, ptop);
                             bool advance = true;
                             if (old == KEY_EMPTY) {
                                 for (int i = 0; i < W - 1; ++i) L.keys[(uint64_t)s * W + i] = can.w[i];
                                 CDBG_LDS_FENCE();
                                 atomic_exch_u64(claim, top);
                                 is_new = true; hit = true; advance = false;
-                            } else if ((old & ~KEY_PENDING) == top) {
-                                if (old & KEY_PENDING) { CDBG_SPIN_YIELD(); advance = false; }
-                                else {
-                                    bool eq = true;
-                                    for (int i = 0; i < W - 1; ++i) eq &= (L.keys[(uint64_t)s * W + i] == can.w[i]);
-                                    if (eq) { hit = true; advance = false; }
-                                }
+                            } else if (old == ptop) { CDBG_SPIN_YIELD(); advance = false; }
+                            else if (old == top) {
+                                bool eq = true;
+                                for (int i = 0; i < W - 1; ++i) eq &= (L.keys[(uint64_t)s * W + i] == can.w[i]);
+                                if (eq) { hit = true; advance = false; }
                             }
                             if (advance) { s = (s + 1) & (TS - 1); ++probes; }
                         } while (!hit && probes < 64u);
@@ -282,13 +296,13 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
                     if (!hit) L.over = 1;                                      // table (nearly) full: not a one-pass partition
                     else {
                         atomic_add_u32(&L.cnt[s], 1u);
-                        if (T & lane_bit) atomic_or_u32(&L.cnt[s], TRAV_FLAG);
+                        if (trav) atomic_or_u32(&L.cnt[s], TRAV_FLAG);
                     }
                 }
                 n_new += (uint32_t)__popcll(__ballot(is_new));
             }
             CDBG_WAVE_SYNC();                                                  // every lane has read the stage and the mask
-            if (lane < MASKW && lane <= (int)((total + 63) >> 6)) { smask[lane] = 0; tmask[lane] = 0; }   // hand the masks back clean
+            if (lane < MASKW && lane <= (int)((total + 63) >> 6)) { smask[lane] = 0; emask[lane] = 0; }   // hand the masks back clean
             CDBG_WAVE_SYNC();
         }
     }
@@ -360,7 +374,7 @@ template <int W, int TS, int NT>
 CDBG_NOINLINE CDBG_DEV_NOINL void count_fast_clear(CountFastLds<W, TS, NT>& L) {
     const int tid = threadIdx.x;
     for (uint32_t i = tid; i < (uint32_t)TS; i += NT) { L.keys[(uint64_t)i * W + (W - 1)] = KEY_EMPTY; L.cnt[i] = 0; }
-    for (uint32_t i = tid; i < (uint32_t)((NT / 64) * CountGeom<W>::MASKW); i += NT) { L.smask[i] = 0; L.tmask[i] = 0; }
+    for (uint32_t i = tid; i < (uint32_t)((NT / 64) * CountGeom<W>::MASKW); i += NT) { L.smask[i] = 0; L.emask[i] = 0; }
     if (tid == 0) { L.fill[0] = L.fill[1] = 0; L.wr[0] = L.wr[1] = 0; L.over = 0; }
 }
 

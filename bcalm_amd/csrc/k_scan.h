@@ -25,6 +25,11 @@
 //   bits [0,8)  n = number of member k-mers       bit 8  member 0 is a traveller
 //   bit 9  member n-1 is a traveller               bits [16, 64*RW): bases, 2 bit each,
 //   base i at bits [64*RW-2(i+1), 64*RW-2i)  (first base on top), n+k-1 bases.
+//   bit 10 the junction member 0 shares with the run BEFORE belongs to another bucket ("foreign"; implied by bit 8)
+//   bit 11 the junction member n-1 shares with the run AFTER is foreign (implied by bit 9)
+//   Every other junction of a record lies in the run, i.e. is owned by the record's bucket.  The count stage carries the
+//   two bits with the k-mer (k_count.h, KEY_FOREIGN_*) so that the compaction does not have to recompute the minimizers
+//   of both junctions of every solid k-mer (k - m + 1 hashed windows each: a quarter of k_compact_wave<2> at k = 55).
 #pragma once
 #include "kmer.h"
 
@@ -298,16 +303,18 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
         }
         const int s = jq;                              // run = junctions [s, e]
         // boundary members
-        bool first_incl = false, first_trav = false, last_incl = false, last_trav = false;
+        bool first_incl = false, first_trav = false, last_incl = false, last_trav = false, first_foreign = false, last_foreign = false;
         if (scan_all_valid(vm, 15 + s - 1, k)) {       // k-mer s-1 (its right junction is s)
             const uint32_t g2 = g[s - 1];
+            first_foreign = part_of(g2, P.log_np) != part;   // the junction this k-mer shares with the run before belongs to another bucket
             if (gq < g2) first_incl = true;
-            else if (part_of(g2, P.log_np) != part) { first_incl = true; first_trav = true; }
+            else if (first_foreign) { first_incl = true; first_trav = true; }
         }
         if (scan_all_valid(vm, 15 + e, k)) {           // k-mer e (its left junction is e)
             const uint32_t g2 = g[e + 1];
+            last_foreign = part_of(g2, P.log_np) != part;
             if (gq < g2) last_incl = true;
-            else if (part_of(g2, P.log_np) != part) { last_incl = true; last_trav = true; }
+            else if (last_foreign) { last_incl = true; last_trav = true; }
             else if (gq == g2) last_incl = true;       // artificial split (tile edge): keep it here
         }
         // chunk the run into records of at most NMAX members
@@ -323,6 +330,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
                 const bool lt = (ce == e) && last_incl && last_trav;
                 if (ft) meta |= 0x100u;
                 if (lt) meta |= 0x200u;
+                if (firstchunk && first_incl && first_foreign) meta |= 0x400u;
+                if ((ce == e) && last_incl && last_foreign) meta |= 0x800u;
                 // stage the record in LDS; all lanes emit together afterwards, so a tile costs two
                 // rounds of device-atomic latency instead of one per loop iteration
                 const uint32_t li = atomic_add_u32(&s_nrec, 1u);

@@ -228,16 +228,18 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : WN
             if (e > 15 + SCANF_TILE) e = 15 + SCANF_TILE;
         }
         // validity of the boundary k-mers: k-mer at q-1 (right junction s) and k-mer at e (left junction e)
-        bool first_incl = false, first_trav = false, last_incl = false, last_trav = false;
+        bool first_incl = false, first_trav = false, last_incl = false, last_trav = false, first_foreign = false, last_foreign = false;
         if (scan_all_valid(vm, s - 1, k)) {
             const uint32_t g2 = kg[scanf_pad(s - 1)];
+            first_foreign = part_of(g2, P.log_np) != part;   // the junction this k-mer shares with the run before belongs to another bucket
             if (g0 < g2) first_incl = true;
-            else if (part_of(g2, P.log_np) != part) { first_incl = true; first_trav = true; }
+            else if (first_foreign) { first_incl = true; first_trav = true; }
         }
         if (scan_all_valid(vm, e, k)) {
             const uint32_t g2 = kg[scanf_pad(e + 1)];
+            last_foreign = part_of(g2, P.log_np) != part;
             if (g0 < g2) last_incl = true;
-            else if (part_of(g2, P.log_np) != part) { last_incl = true; last_trav = true; }
+            else if (last_foreign) { last_incl = true; last_trav = true; }
             else if (g0 == g2) last_incl = true;
         }
         int c = s; bool firstchunk = true;
@@ -252,6 +254,8 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : WN
                 const bool lt = (ce == e) && last_incl && last_trav;
                 if (ft) meta |= 0x100u;
                 if (lt) meta |= 0x200u;
+                if (firstchunk && first_incl && first_foreign) meta |= 0x400u;
+                if ((ce == e) && last_incl && last_foreign) meta |= 0x800u;
                 scan_emit_record<W, MODE>(P, pk, 2 * ms, meta, lpart);
                 n_members += (uint32_t)n;
                 n_trav += (ft ? 1u : 0u) + (lt ? 1u : 0u);
