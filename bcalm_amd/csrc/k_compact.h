@@ -143,6 +143,23 @@ CDBG_DEV Kmer<W> canon_junction(const Kmer<W>& u_out, int k) {
     Kmer<W> r = j.rc(k - 1);
     return (r < j) ? r : j;
 }
+// A stored (canonical) k-mer x seen from one of its ends: u reads out of that end, ur = rc(u).  One reverse complement
+// serves both (x.rc for the left end IS u, for the right end it is rc(u)); orient_out followed by u.rc(k) took two.
+template <int W>
+CDBG_DEV void orient_pair(const Kmer<W>& x, uint32_t end, int k, Kmer<W>& u, Kmer<W>& ur) {
+    const Kmer<W> xr = x.rc(k);
+    const bool right = end == END_RIGHT;
+#pragma unroll
+    for (int i = 0; i < W; ++i) { u.w[i] = right ? x.w[i] : xr.w[i]; ur.w[i] = right ? xr.w[i] : x.w[i]; }
+}
+// canonical junction (k-1)-mer at that end: the suffix of u, or its reverse complement = rc(u) without its last base
+template <int W>
+CDBG_DEV Kmer<W> canon_junction_at(const Kmer<W>& x, uint32_t end, int k) {
+    Kmer<W> u, ur; orient_pair<W>(x, end, k, u, ur);
+    const Kmer<W> j = suffix_km1<W>(u, k), r = ur.shr(2);
+    return (r < j) ? r : j;
+}
+
 // successors of oriented k-mer u present in the table; returns count, last hit in (slot, enter_end)
 template <int W>
 CDBG_DEV int probe_succ(const KTable<W>& T, const Kmer<W>& u, int k, uint32_t& slot, uint32_t& enter_end) {
@@ -346,7 +363,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
             const uint32_t l = lnk[s * 2 + end];
             if (!(l & LNK_CONF) || (l & 3u) == LNK_OPEN) continue;   // open home ends carry their confirmation themselves
             const uint64_t o = s_lbase + atomic_add_u32(&s_lw, 1u);
-            const Kmer<W> jc = canon_junction<W>(orient_out<W>(ktable_key<W>(T, s), end, k), k);
+            const Kmer<W> jc = canon_junction_at<W>(ktable_key<W>(T, s), end, k);
             glue_record_put<W>(P, o, jc, GTAG_CONFIRM);
         }
     }
@@ -412,7 +429,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
             const uint32_t l = lnk[s * 2 + end];
             if (!(l & LNK_POSTED)) continue;
             const uint64_t o = s_lbase + atomic_add_u32(&s_lw, 1u);
-            const Kmer<W> jc = canon_junction<W>(orient_out<W>(ktable_key<W>(T, s), end, k), k);
+            const Kmer<W> jc = canon_junction_at<W>(ktable_key<W>(T, s), end, k);
             glue_record_put<W>(P, o, jc, (uint32_t)(s_pbase * 2 + (l & 0x3FFFFFFFu)) | ((l & LNK_CONF) ? GTAG_CONFBIT : 0u));
             ++my_open;
         }

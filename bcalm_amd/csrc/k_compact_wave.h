@@ -225,11 +225,11 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
         const uint32_t e = it >> 1, end = it & 1u;
         uint32_t note = CWN_FOREIGN;                     // junction owned elsewhere: glue decides
         if ((L.vis[e] >> (2 + end)) & 1u) {
-            const Kmer<W> u = orient_out<W>(cw_key<W, TSW>(L, e), end, k);
+            Kmer<W> u, ur; orient_pair<W>(cw_key<W, TSW>(L, e), end, k, u, ur);
             // the four successors u[1:]+c share everything but one base: v = (u << 2) | c, and its reverse complement is
             // comp(c) in front of rc(u) without its last base.  Their home slots are read together (one LDS round trip).
             Kmer<W> vb = u; vb.push_right(k, 0);
-            const Kmer<W> rb = u.rc(k).shr(2);
+            const Kmer<W> rb = ur.shr(2);
             const int pos = 2 * (k - 1);
             // (even k: a successor that is its own reverse complement is reached by TWO edges -- the rows (s,+) and (s,-) of
             //  the overlap table, .md:41-46 -- so it counts twice and the junction is never 1-in/1-out)
@@ -357,7 +357,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
             const uint32_t l = L.lnk[it];
             if (!(l & CWL_CONF) || (l & 3u) == LNK_OPEN) continue;   // open home ends carry their confirmation themselves
             const uint64_t o = lbase + atomic_add_u32(&L.lw, 1u);
-            const Kmer<W> jc = canon_junction<W>(orient_out<W>(cw_key<W, TSW>(L, it >> 1), it & 1u, k), k);
+            const Kmer<W> jc = canon_junction_at<W>(cw_key<W, TSW>(L, it >> 1), it & 1u, k);
             glue_record_put<W>(P, o, jc, GTAG_CONFIRM);
         }
     }
@@ -412,7 +412,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
             const uint32_t l = L.lnk[it];
             if (!(l & CWL_POSTED)) continue;
             const uint64_t o = lbase + atomic_add_u32(&L.lw, 1u);
-            const Kmer<W> jc = canon_junction<W>(orient_out<W>(cw_key<W, TSW>(L, it >> 1), it & 1u, k), k);
+            const Kmer<W> jc = canon_junction_at<W>(cw_key<W, TSW>(L, it >> 1), it & 1u, k);
             glue_record_put<W>(P, o, jc, (uint32_t)(pbase * 2 + (l & 0x3FFu)) | ((l & CWL_CONF) ? GTAG_CONFBIT : 0u));
         }
     }
