@@ -107,7 +107,10 @@ template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMP
 #ifndef CDBG_TSW2
 #define CDBG_TSW2 256
 #endif
-template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, TSK2 = 2 * TS_COMPACT_2, NTC = 512, TSW = CDBG_TSW2, TSW2 = 2 * CDBG_TSW2; };
+#ifndef CDBG_NTC2
+#define CDBG_NTC2 512
+#endif
+template <> struct Cfg<2> { static constexpr int TSC = TS_COUNT_2, TSK = TS_COMPACT_2, TSK2 = 2 * TS_COMPACT_2, NTC = CDBG_NTC2, TSW = CDBG_TSW2, TSW2 = 2 * CDBG_TSW2; };
 // (W >= 3: 512 threads with member-balanced wave shares and 8-record batches: 2 x 8 waves per CU instead of 2 x 4;
 //  config-5 share: count tier 1 257 -> 214 ms, tier 2 87 -> 62 ms.  Before the balanced shares 512 threads LOST: 341 -> 464 ms)
 #ifndef CDBG_NTC4

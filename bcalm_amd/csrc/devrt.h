@@ -46,6 +46,8 @@ CDBG_DEV uint64_t atomic_cas_u64(uint64_t* p, uint64_t cmp, uint64_t v) {
 CDBG_DEV uint64_t atomic_exch_u64(uint64_t* p, uint64_t v) {
     return (uint64_t)atomicExch((unsigned long long*)p, (unsigned long long)v);
 }
+// the compiler may not move memory operations across this point (the hardware executes a wave's LDS operations in order)
+#define CDBG_COMPILER_BARRIER() asm volatile("" ::: "memory")
 // L1-bypassing (agent-scope) load / volatile LDS flag read
 CDBG_DEV uint64_t ld_agent_u64(const uint64_t* p) {
 #ifdef CDBG_HOSTSIM

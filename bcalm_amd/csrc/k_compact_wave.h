@@ -61,6 +61,9 @@ CDBG_DEV uint32_t cw_insert(uint64_t* keys, const Kmer<W>& key) {
     } while (!done);
     return s;
 }
+// (two-word keys: both words of a slot are requested together -- the lower word of a slot whose top word does not match is
+//  wasted LDS bandwidth, a second dependent round trip for the one that does is latency, and this kernel waits on LDS round
+//  trips: compact 68.4 -> 66.4 ms at k = 55.  One-word keys have nothing to fetch, with three lower words it gained nothing.)
 template <int W, int TSW>
 CDBG_DEV uint32_t cw_find(const uint64_t* keys, const Kmer<W>& key) {
     uint32_t s = cw_home<W, TSW>(key);
@@ -69,7 +72,8 @@ CDBG_DEV uint32_t cw_find(const uint64_t* keys, const Kmer<W>& key) {
 #pragma clang loop unroll(disable)
     do {
         const uint64_t v = keys[(uint64_t)s * W + (W - 1)];
-        if (v == top) {
+        if (W == 2) found = (v == top) & (keys[(uint64_t)s * W] == key.w[0]);
+        else if (v == top) {
             bool eq = true;
             for (int i = 0; i < W - 1; ++i) eq &= (keys[(uint64_t)s * W + i] == key.w[i]);
             found = eq;
@@ -148,12 +152,14 @@ CDBG_DEV void cw_load_entries(const CompactParams& P, uint64_t so, uint32_t E, i
     }
 }
 // first probe of one key from a value read earlier (the four successor probes of an end read their home slots together)
+// first: the words of the home slot s as read earlier: its top word, and (two-word keys) its lower word
 template <int W, int TSW>
-CDBG_DEV uint32_t cw_find_after_first(const uint64_t* keys, const Kmer<W>& key, uint32_t s, uint64_t first_top) {
-    if (first_top == KEY_EMPTY) return NONE32;
-    if (first_top == key.w[W - 1]) {
+CDBG_DEV uint32_t cw_find_after_first(const uint64_t* keys, const Kmer<W>& key, uint32_t s, const uint64_t (&first)[W == 2 ? 2 : 1]) {
+    if (first[0] == KEY_EMPTY) return NONE32;
+    if (first[0] == key.w[W - 1]) {
         bool eq = true;
-        for (int i = 0; i < W - 1; ++i) eq &= (keys[(uint64_t)s * W + i] == key.w[i]);
+        if (W == 2) eq = first[W == 2 ? 1 : 0] == key.w[0];
+        else for (int i = 0; i < W - 1; ++i) eq &= (keys[(uint64_t)s * W + i] == key.w[i]);
         if (eq) return s;
     }
     // occupied by another key: keep probing
@@ -163,7 +169,8 @@ CDBG_DEV uint32_t cw_find_after_first(const uint64_t* keys, const Kmer<W>& key, 
 #pragma clang loop unroll(disable)
     do {
         const uint64_t v = keys[(uint64_t)s * W + (W - 1)];
-        if (v == top) {
+        if (W == 2) found = (v == top) & (keys[(uint64_t)s * W] == key.w[0]);
+        else if (v == top) {
             bool eq = true;
             for (int i = 0; i < W - 1; ++i) eq &= (keys[(uint64_t)s * W + i] == key.w[i]);
             found = eq;
@@ -233,7 +240,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
             const int pos = 2 * (k - 1);
             // (even k: a successor that is its own reverse complement is reached by TWO edges -- the rows (s,+) and (s,-) of
             //  the overlap table, .md:41-46 -- so it counts twice and the junction is never 1-in/1-out)
-            Kmer<W> lab[4]; uint32_t hs[4]; uint64_t first[4]; bool fwd[4], pal[4];
+            Kmer<W> lab[4]; uint32_t hs[4]; uint64_t first[4][W == 2 ? 2 : 1]; bool fwd[4], pal[4];
 #pragma unroll
             for (uint32_t c = 0; c < 4; ++c) {
                 Kmer<W> v = vb; v.w[0] |= (uint64_t)c;
@@ -241,7 +248,8 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
                 fwd[c] = !(r < v); pal[c] = even_k && r == v;
                 lab[c] = fwd[c] ? v : r;
                 hs[c] = cw_home<W, TSW>(lab[c]);
-                first[c] = L.keys[(uint64_t)hs[c] * W + (W - 1)];
+                first[c][0] = L.keys[(uint64_t)hs[c] * W + (W - 1)];
+                if (W == 2) first[c][W == 2 ? 1 : 0] = L.keys[(uint64_t)hs[c] * W];
             }
             uint32_t nsucc = 0, y = 0, ye = 0;
 #pragma unroll

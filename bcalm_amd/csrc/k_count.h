@@ -133,19 +133,35 @@ CDBG_DEV uint32_t ktable_insert(const KTable<W>& t, const Kmer<W>& key, bool& is
         do {
             uint64_t* const claim = &t.keys[(uint64_t)s * W + (W - 1)];
             const uint64_t old = atomic_cas_u64(claim, KEY_EMPTY, ptop);
-            bool advance = true;
-            if (old == KEY_EMPTY) {                          // claimed: write the lower words, then publish the top word
+            // LDS tables: the lower words are requested right behind the claim, whatever it returns -- one round trip for a
+            // hit instead of two (a wave's LDS operations execute in order: a published top word seen by the compare-and-swap
+            // means that the lower words read after it are the published ones).  HBM tables read them only when the top matches.
+            // (two-word keys only: measured at k = 55, count 169 -> 154 ms; with three lower words to fetch per probe it lost, k = 127: 352 -> 355 ms)
+            uint64_t low[W > 1 ? W - 1 : 1];
+            constexpr bool SPEC = !GLOBAL && W == 2;
+            if (SPEC) {
+                CDBG_COMPILER_BARRIER();
+#pragma unroll
+                for (int i = 0; i < W - 1; ++i) low[i] = t.keys[(uint64_t)s * W + i];
+            }
+            // (selects instead of an if / else chain: the structurised chain cost a dozen scalar mask operations per probe)
+            const bool mine = old == KEY_EMPTY, wait = old == ptop;
+            bool same = old == top;
+            if (SPEC) same &= (low[0] == key.w[0]);
+            else if (same) {
+#pragma unroll
+                for (int i = 0; i < W - 1; ++i) same &= ((GLOBAL ? ld_agent_u64(&t.keys[(uint64_t)s * W + i]) : t.keys[(uint64_t)s * W + i]) == key.w[i]);
+            }
+            if (mine) {                                      // claimed: write the lower words, then publish the top word
+#pragma unroll
                 for (int i = 0; i < W - 1; ++i) t.keys[(uint64_t)s * W + i] = key.w[i];
                 if (GLOBAL) __threadfence(); else CDBG_LDS_FENCE();
                 atomic_exch_u64(claim, top);
-                is_new = true; res = s; done = true; advance = false;
-            } else if (old == ptop) { CDBG_SPIN_YIELD(); advance = false; }   // being written by another lane (this key, as far as one can tell): look again
-            else if (old == top) {
-                bool eq = true;
-                for (int i = 0; i < W - 1; ++i) eq &= ((GLOBAL ? ld_agent_u64(&t.keys[(uint64_t)s * W + i]) : t.keys[(uint64_t)s * W + i]) == key.w[i]);
-                if (eq) { res = s; done = true; advance = false; }
             }
-            if (advance) { s = (s + 1) & t.mask; ++probes; }
+            if (wait) CDBG_SPIN_YIELD();                     // being written by another lane (this key, as far as one can tell): look again
+            is_new = is_new | mine; done = mine | same; res = done ? s : res;
+            const bool advance = !(done | wait);
+            s = advance ? ((s + 1) & t.mask) : s; probes += advance ? 1u : 0u;
         } while (!done && probes < max_probe);
         return res;
     }

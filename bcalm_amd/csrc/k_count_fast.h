@@ -276,21 +276,31 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
                         hit = false;
 #pragma clang loop unroll(disable)
                         do {                                                   // (single exit, publish inside the iteration: see ktable_insert)
-                            uint64_t* const claim = &L.keys[(uint64_t)s * W + (W - 1)];
-                            const uint64_t old = atomic_cas_u64(claim, KEY_EMPTY, ptop);
-                            bool advance = true;
-                            if (old == KEY_EMPTY) {
-                                for (int i = 0; i < W - 1; ++i) L.keys[(uint64_t)s * W + i] = can.w[i];
-                                CDBG_LDS_FENCE();
-                                atomic_exch_u64(claim, top);
-                                is_new = true; hit = true; advance = false;
-                            } else if (old == ptop) { CDBG_SPIN_YIELD(); advance = false; }
-                            else if (old == top) {
-                                bool eq = true;
-                                for (int i = 0; i < W - 1; ++i) eq &= (L.keys[(uint64_t)s * W + i] == can.w[i]);
-                                if (eq) { hit = true; advance = false; }
+                            uint64_t* const slotp = &L.keys[(uint64_t)s * W];
+                            const uint64_t old = atomic_cas_u64(slotp + (W - 1), KEY_EMPTY, ptop);
+                            // the lower words are requested right behind the claim, whatever it returns: one LDS round trip for a
+                            // hit instead of two (LDS operations of a wave execute in order: a published top word seen by the
+                            // compare-and-swap means the lower words read after it are the published ones)
+                            // (two-word keys; with more lower words to fetch per probe the speculation gains nothing: k = 127, 352 -> 350 ms)
+                            bool eq = true;
+                            if (W == 2) {
+                                CDBG_COMPILER_BARRIER();                        // (the reads must be issued AFTER the compare-and-swap)
+                                eq = slotp[0] == can.w[0];
+                            } else if (old == top) {
+#pragma unroll
+                                for (int i = 0; i < W - 1; ++i) eq &= (slotp[i] == can.w[i]);
                             }
-                            if (advance) { s = (s + 1) & (TS - 1); ++probes; }
+                            const bool mine = old == KEY_EMPTY, same = (old == top) & eq, wait = old == ptop;
+                            if (wait) CDBG_SPIN_YIELD();
+                            if (mine) {
+#pragma unroll
+                                for (int i = 0; i < W - 1; ++i) slotp[i] = can.w[i];
+                                CDBG_LDS_FENCE();
+                                atomic_exch_u64(slotp + (W - 1), top);
+                            }
+                            is_new = is_new | mine; hit = mine | same;
+                            const bool advance = !(hit | wait);
+                            s = advance ? ((s + 1) & (TS - 1)) : s; probes += advance ? 1u : 0u;
                         } while (!hit && probes < 64u);
                     }
                     if (!hit) L.over = 1;                                      // table (nearly) full: not a one-pass partition

@@ -184,6 +184,9 @@ struct Kmer {
     // the GOOD bits are the high ones (slot = hash_lds() >> (32 - log2 slots)).  The 64-bit product of hash() below costs
     // four 32-bit multiplies (bench_micro/micro_r02: 18 cycles per wave against 4.5 for one v_mul_lo_u32).
     CDBG_HD uint32_t hash_lds() const {
+        // (measured and discarded in round 3: a fold of the dwords by rotations + two 24-bit multiplies -- full-rate operations
+        //  only -- probed as well as this on random k-mers but sent 50 % more partitions of real read sets to the multi-pass
+        //  kernel: count 169 -> 175 ms at k = 55, 352 -> 362 ms at k = 127)
         uint32_t t = (uint32_t)(w[0] >> 32);
         t = (uint32_t)w[0] * 0x9E3779B1u + t;
         for (int i = 1; i < W; ++i) { t = t * 0x85EBCA77u + (uint32_t)w[i]; t = t * 0xC2B2AE3Du + (uint32_t)(w[i] >> 32); }
