@@ -130,6 +130,10 @@ CDBG_DEV uint64_t cw_reserve(CwChunk& ch, uint64_t* cursor, uint32_t need, uint3
 }
 
 // the solid entries of one bucket as loaded, NPER per lane (entry e = lane + 64 j)
+// (measured and discarded in round 3: unconditional loads from a clamped index, so that the waits for the current bucket's
+//  entries become s_waitcnt vmcnt(N) instead of vmcnt(0) and the request for the next bucket stays in flight through the
+//  load and classify phases -- the ISA showed exactly that, the times did not move: 40.0 / 67.3 / 50.1 -> 40.5 / 67.5 / 49.0 ms
+//  at k = 31 / 55 / 127.  16 - 20 waves per CU cover a bucket's exposed memory latency; the waves wait on LDS round trips.)
 template <int W, int TSW>
 struct CwEntries {
     static constexpr int NPER = TSW / 2 / 64 > 0 ? TSW / 2 / 64 : 1;
