@@ -239,6 +239,22 @@ def test_hostile_four_million_reads(oracle, hip):
     assert st["n_multipass_partitions"] + st["n_big_partitions"] > 0          # the hostile input did reach the fallback tiers
 
 
+@pytest.mark.parametrize("k,cfg,n_reads,read_len", [(55, 4 | 0x100, 150_000, 150), (32, 3 | 0x100, 150_000, 150), (64, 4 | 0x100, 100_000, 150),
+                                                    (96, 5 | 0x100, 20_000, 1000), (127, 5 | 0x100, 20_000, 1000)])
+def test_hostile_multiword_parity(oracle, hip, k, cfg, n_reads, read_len):
+    """the hostile generator with two-, three- and four-word k-mers, odd and even k (k = 32, 64, 96 sit on the word-count
+    boundaries of the span rule): homopolymer runs and low-complexity blocks put k-mers whose top word is all T -- the value next to
+    the table's EMPTY / claimed encodings -- and hundreds of duplicates of one key into the same step of the multi-word slot-claim
+    protocol, and the repeat copies overfill partitions (second count tier, multi-pass, workgroup compaction tiers).  Against the
+    scalar oracle: occurrences, distinct, solid and the canonical unitig set with KC."""
+    text = oracle.synth_reads(n_reads, read_len, cfg)
+    exp = oracle.run(text, k, 2)
+    st, canon = _run_stats(hip, text, k, 2)
+    assert st["n_occurrences"] == exp["stats"]["occurrences"]
+    assert st["n_distinct"] == exp["stats"]["distinct"] and st["n_solid"] == exp["stats"]["solid"]
+    assert canon == exp["unitigs"]
+
+
 @pytest.mark.parametrize("log_np", [-1, 0])
 def test_abundance_saturates_at_31_bits(hip, log_np):
     """one k-mer seen more than 2^31 times (2.3 M reads of 1000 x 'A', k = 31): the count must clamp at 2^31 - 1 -- not carry

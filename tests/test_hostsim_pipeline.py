@@ -95,6 +95,15 @@ def test_hostile_reads_parity(oracle, sim):
     assert_parity(oracle, sim, text, 21, 1, log2_partitions=7, minimizer_size=8)
 
 
+@pytest.mark.parametrize("k,cfg,n_reads,read_len,log_np", [(55, 4 | 0x100, 600, 150, 3), (32, 3 | 0x100, 600, 150, 3), (64, 4 | 0x100, 500, 150, 2), (127, 5 | 0x100, 80, 1000, 2)])
+def test_hostile_reads_parity_multiword(oracle, sim, k, cfg, n_reads, read_len, log_np):
+    """the hostile generator with multi-word k-mers (two, three, four words; even k on the word-count boundaries): duplicates of one
+    key and top words of all T in the slot-claim protocol of the multi-word tables, through the simulator build -- which also
+    re-derives the junction-ownership flag of every solid k-mer from its minimizers (device error 9 on a mismatch)"""
+    text = oracle.synth_reads(n_reads, read_len, cfg, first=0, total=n_reads).decode()
+    assert_parity(oracle, sim, text, k, 2, log2_partitions=log_np)
+
+
 def test_synthetic_reads_parity(oracle, sim):
     text = oracle.synth_reads(300, 150, 3).decode()
     assert_parity(oracle, sim, text, 31, 2, log2_partitions=5)
