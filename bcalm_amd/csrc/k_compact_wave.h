@@ -25,9 +25,8 @@ constexpr uint16_t CWN_NONE = 0xFFFFu, CWN_FOREIGN = 0xFFFEu;
 template <int W, int TSW>
 struct CompactWaveLds {                                 // one per wave
     static constexpr int EMAX = TSW / 2;
-    uint64_t keys[TSW * W];
-    uint16_t ent[TSW];                                  // slot -> entry
-    uint16_t slot_of[EMAX];                             // entry -> slot
+    uint64_t ekeys[EMAX * W];                           // the bucket's k-mers in entry order: word i of entry e at [i * EMAX + e]
+    uint64_t jt[TSW];                                   // junction table: one slot per junction that an end of the bucket registers at (cw_jt_*)
     uint32_t cnt[EMAX];                                 // count | TRAV_FLAG; after walk 2: (byte offset << 1) | strand
     uint16_t lnk[2 * EMAX];                             // per end (2 * entry + end): note, then link word
     uint16_t fin[2 * EMAX];
@@ -38,73 +37,63 @@ struct CompactWaveLds {                                 // one per wave
 };
 
 template <int W, int TSW>
-CDBG_DEV uint32_t cw_home(const Kmer<W>& key) {
-    constexpr int LOG = TSW == 1024 ? 10 : TSW == 512 ? 9 : TSW == 256 ? 8 : TSW == 128 ? 7 : -1;
-    static_assert(LOG > 0, "wave table size");
-    return key.hash_lds() >> (32 - LOG);
-}
-// distinct keys only (a bucket's solid entries), so no PENDING protocol: the claimer's lower words are written
-// before any sibling lane of the same iteration compares them (program order inside the iteration)
-template <int W, int TSW>
-CDBG_DEV uint32_t cw_insert(uint64_t* keys, const Kmer<W>& key) {
-    uint32_t s = cw_home<W, TSW>(key);
-    const uint64_t top = key.w[W - 1];
-    bool done = false;
-#pragma clang loop unroll(disable)
-    do {
-        const uint64_t old = atomic_cas_u64(&keys[(uint64_t)s * W + (W - 1)], KEY_EMPTY, top);
-        if (old == KEY_EMPTY) {
-            for (int i = 0; i < W - 1; ++i) keys[(uint64_t)s * W + i] = key.w[i];
-            done = true;
-        }
-        if (!done) s = (s + 1) & (TSW - 1);
-    } while (!done);
-    return s;
-}
-// (two-word keys: both words of a slot are requested together -- the lower word of a slot whose top word does not match is
-//  wasted LDS bandwidth, a second dependent round trip for the one that does is latency, and this kernel waits on LDS round
-//  trips: compact 68.4 -> 66.4 ms at k = 55.  One-word keys have nothing to fetch, with three lower words it gained nothing.)
-template <int W, int TSW>
-CDBG_DEV uint32_t cw_find(const uint64_t* keys, const Kmer<W>& key) {
-    uint32_t s = cw_home<W, TSW>(key);
-    const uint64_t top = key.w[W - 1];
-    bool found = false, stop;
-#pragma clang loop unroll(disable)
-    do {
-        const uint64_t v = keys[(uint64_t)s * W + (W - 1)];
-        if (W == 2) found = (v == top) & (keys[(uint64_t)s * W] == key.w[0]);
-        else if (v == top) {
-            bool eq = true;
-            for (int i = 0; i < W - 1; ++i) eq &= (keys[(uint64_t)s * W + i] == key.w[i]);
-            found = eq;
-        }
-        stop = found | (v == KEY_EMPTY);
-        s = stop ? s : ((s + 1) & (TSW - 1));
-    } while (!stop);
-    return found ? s : NONE32;
-}
-template <int W, int TSW>
 CDBG_DEV Kmer<W> cw_key(const CompactWaveLds<W, TSW>& L, uint32_t e) {
-    const uint32_t s = L.slot_of[e];
     Kmer<W> r;
-    for (int i = 0; i < W; ++i) r.w[i] = L.keys[(uint64_t)s * W + i];
+#pragma unroll
+    for (int i = 0; i < W; ++i) r.w[i] = L.ekeys[i * (TSW / 2) + e];
     return r;
 }
-// successors of oriented k-mer u present in the table; returns count, last hit in (entry, enter_end)
+// ---- the junction table -------------------------------------------------------------------------------------------
+// Whether a junction is 1-in/1-out is a fact about the JUNCTION: it holds exactly when one end of the bucket's k-mers
+// reaches it from each side.  Every end whose junction the bucket owns registers there once (one hash insert of the
+// canonical (k-1)-mer) instead of probing the k-mer table for its four possible successors (four canonical k-mers, four
+// hashes, four probe sequences per end: a third of this kernel's time).  A slot does not hold the (k-1)-mer: it holds a
+// 24-bit tag of its hash and the end that claimed the slot, and a later end with the same tag recomputes the claimer's
+// junction from the entry-ordered k-mers and compares all of it -- exact, at 8 bytes per slot for any k.
+//   bits [0,3) / [3,6)   ends registered on side 0 / 1 (side 0: the end's outgoing (k-1)-suffix IS the canonical junction)
+//   bits [6,16) / [16,26) the first end registered on side 0 / 1      bit 26  the side of the end that claimed the slot
+//   bits [40,64)          tag (bit 63 set: a claimed slot is never 0)
+// Even k: a k-mer that is its own reverse complement reaches the junction with both of its ends from the same side, so
+// that side counts 2 and the junction is never 1-in/1-out (the two edges (s,+) / (s,-) of the overlap table, .md:41-46).
+// Odd k: a junction that is its own reverse complement has one side only -- never 1-in/1-out either (every end there
+// sees its own node's reverse complement among its successors).
+template <int W>
+CDBG_DEV Kmer<W> cw_junction_of(const Kmer<W>& x, uint32_t end, int k, uint32_t& side) {
+    Kmer<W> u, ur; orient_pair<W>(x, end, k, u, ur);
+    const Kmer<W> j = suffix_km1<W>(u, k), r = ur.shr(2);      // the junction as the end leaves through it, and its reverse complement
+    const bool rev = r < j;
+    side = rev ? 1u : 0u;
+    return rev ? r : j;
+}
+// registers end `it` (side known) at junction jc; returns the slot, or NONE32 when the table is too full (the caller defers the bucket)
 template <int W, int TSW>
-CDBG_DEV int cw_probe_succ(const CompactWaveLds<W, TSW>& L, const Kmer<W>& u, int k, uint32_t& ent, uint32_t& enter_end) {
-    int n = 0;
-    Kmer<W> vb = u; vb.push_right(k, 0);
-    const Kmer<W> rb = u.rc(k).shr(2);
-    const int pos = 2 * (k - 1);
-    for (uint32_t c = 0; c < 4; ++c) {
-        Kmer<W> v = vb; v.w[0] |= (uint64_t)c;
-        Kmer<W> r = rb; r.or_word(pos >> 6, (uint64_t)(3u - c) << (pos & 63));
-        const bool fwd = !(r < v);
-        const uint32_t f = cw_find<W, TSW>(L.keys, fwd ? v : r);
-        if (f != NONE32) { n += (r == v) ? 2 : 1; ent = L.ent[f]; enter_end = fwd ? END_LEFT : END_RIGHT; }   // (even k: see compact_bucket_wave)
-    }
-    return n;
+CDBG_DEV uint32_t cw_jt_register(CompactWaveLds<W, TSW>& L, const Kmer<W>& jc, uint32_t side, uint32_t it, int k) {
+    constexpr int LOG = TSW == 1024 ? 10 : TSW == 512 ? 9 : TSW == 256 ? 8 : TSW == 128 ? 7 : -1;
+    static_assert(LOG > 0, "wave table size");
+    const uint32_t h = jc.hash_lds();
+    uint32_t s = h >> (32 - LOG);
+    const uint64_t tag = (uint64_t)((h & 0x7FFFFFu) | 0x800000u) << 40;
+    const uint64_t mine = tag | ((uint64_t)side << 26) | ((uint64_t)it << (6u + 10u * side)) | (1ULL << (3u * side));
+    uint32_t probes = 0, res = NONE32; bool done = false;
+#pragma clang loop unroll(disable)
+    do {
+        const uint64_t old = atomic_cas_u64(&L.jt[s], 0ULL, mine);
+        bool same = false;
+        if (old != 0ULL && (old >> 40) == (tag >> 40)) {          // same tag: is it the same junction?  ask the end that claimed the slot
+            const uint32_t cs = (uint32_t)(old >> 26) & 1u, rid = (uint32_t)(old >> (6u + 10u * cs)) & 0x3FFu;
+            uint32_t rside;
+            const Kmer<W> rj = cw_junction_of<W>(cw_key<W, TSW>(L, rid >> 1), rid & 1u, k, rside);
+            same = rj == jc;
+        }
+        if (same) {
+            const uint64_t before = atomic_add_u64(&L.jt[s], 1ULL << (3u * side));
+            if (((before >> (3u * side)) & 7ULL) == 0ULL) atomic_or_u64(&L.jt[s], (uint64_t)it << (6u + 10u * side));   // the first end on this side
+        }
+        done = (old == 0ULL) | same;
+        res = done ? s : res;
+        s = done ? s : ((s + 1) & (TSW - 1)); probes += done ? 0u : 1u;
+    } while (!done && probes < 48u);
+    return res;
 }
 
 struct CompactWaveParams {
@@ -155,36 +144,6 @@ CDBG_DEV void cw_load_entries(const CompactParams& P, uint64_t so, uint32_t E, i
         }
     }
 }
-// first probe of one key from a value read earlier (the four successor probes of an end read their home slots together)
-// first: the words of the home slot s as read earlier: its top word, and (two-word keys) its lower word
-template <int W, int TSW>
-CDBG_DEV uint32_t cw_find_after_first(const uint64_t* keys, const Kmer<W>& key, uint32_t s, const uint64_t (&first)[W == 2 ? 2 : 1]) {
-    if (first[0] == KEY_EMPTY) return NONE32;
-    if (first[0] == key.w[W - 1]) {
-        bool eq = true;
-        if (W == 2) eq = first[W == 2 ? 1 : 0] == key.w[0];
-        else for (int i = 0; i < W - 1; ++i) eq &= (keys[(uint64_t)s * W + i] == key.w[i]);
-        if (eq) return s;
-    }
-    // occupied by another key: keep probing
-    const uint64_t top = key.w[W - 1];
-    bool found = false, stop;
-    s = (s + 1) & (TSW - 1);
-#pragma clang loop unroll(disable)
-    do {
-        const uint64_t v = keys[(uint64_t)s * W + (W - 1)];
-        if (W == 2) found = (v == top) & (keys[(uint64_t)s * W] == key.w[0]);
-        else if (v == top) {
-            bool eq = true;
-            for (int i = 0; i < W - 1; ++i) eq &= (keys[(uint64_t)s * W + i] == key.w[i]);
-            found = eq;
-        }
-        stop = found | (v == KEY_EMPTY);
-        s = stop ? s : ((s + 1) & (TSW - 1));
-    } while (!stop);
-    return found ? s : NONE32;
-}
-
 // One bucket.  X: its entries (requested one bucket ago); E, so: its segment.
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
 #define CDBG_WPH(i) do { const uint64_t t_ = clock64(); acc[4 + (i)] += t_ - acc[15]; acc[15] = t_; } while (0)
@@ -214,8 +173,9 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
             const uint64_t fl = x.w[W - 1] & KEY_FLAGS;
             x.w[W - 1] &= ~KEY_FLAGS;
             const uint32_t cv = X.cnt[j];
-            const uint32_t s = cw_insert<W, TSW>(L.keys, x);
-            L.ent[s] = (uint16_t)e; L.slot_of[e] = (uint16_t)s; L.cnt[e] = cv;
+#pragma unroll
+            for (int i = 0; i < W; ++i) L.ekeys[i * (TSW / 2) + e] = x.w[i];
+            L.cnt[e] = cv;
             L.vis[e] = (uint8_t)(((cv & TRAV_FLAG) ? 2u : 0u) | ((fl & KEY_FOREIGN_L) ? 0u : 4u) | ((fl & KEY_FOREIGN_R) ? 0u : 8u));
 #ifdef CDBG_HOSTSIM
             {   // (the simulator build checks every flag against the definition)
@@ -230,40 +190,42 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
     CDBG_WAVE_SYNC();
     CDBG_WPH(1);
 
-    // ---- classify: every end whose junction this bucket owns notes its unique successor end (or none) ----
-    const bool even_k = (k & 1) == 0;
+    // ---- classify: every end whose junction this bucket owns registers at the junction (cw_jt_*) ... ----
     for (uint32_t it = lane; it < 2 * E; it += 64) {
         const uint32_t e = it >> 1, end = it & 1u;
-        uint32_t note = CWN_FOREIGN;                     // junction owned elsewhere: glue decides
+        uint32_t where = 0xFFFFu;                        // junction owned elsewhere: glue decides
         if ((L.vis[e] >> (2 + end)) & 1u) {
-            Kmer<W> u, ur; orient_pair<W>(cw_key<W, TSW>(L, e), end, k, u, ur);
-            // the four successors u[1:]+c share everything but one base: v = (u << 2) | c, and its reverse complement is
-            // comp(c) in front of rc(u) without its last base.  Their home slots are read together (one LDS round trip).
-            Kmer<W> vb = u; vb.push_right(k, 0);
-            const Kmer<W> rb = ur.shr(2);
-            const int pos = 2 * (k - 1);
-            // (even k: a successor that is its own reverse complement is reached by TWO edges -- the rows (s,+) and (s,-) of
-            //  the overlap table, .md:41-46 -- so it counts twice and the junction is never 1-in/1-out)
-            Kmer<W> lab[4]; uint32_t hs[4]; uint64_t first[4][W == 2 ? 2 : 1]; bool fwd[4], pal[4];
-#pragma unroll
-            for (uint32_t c = 0; c < 4; ++c) {
-                Kmer<W> v = vb; v.w[0] |= (uint64_t)c;
-                Kmer<W> r = rb; r.or_word(pos >> 6, (uint64_t)(3u - c) << (pos & 63));
-                fwd[c] = !(r < v); pal[c] = even_k && r == v;
-                lab[c] = fwd[c] ? v : r;
-                hs[c] = cw_home<W, TSW>(lab[c]);
-                first[c][0] = L.keys[(uint64_t)hs[c] * W + (W - 1)];
-                if (W == 2) first[c][W == 2 ? 1 : 0] = L.keys[(uint64_t)hs[c] * W];
-            }
-            uint32_t nsucc = 0, y = 0, ye = 0;
-#pragma unroll
-            for (uint32_t c = 0; c < 4; ++c) {
-                const uint32_t f = cw_find_after_first<W, TSW>(L.keys, lab[c], hs[c], first[c]);
-                if (f != NONE32) { nsucc += pal[c] ? 2u : 1u; y = L.ent[f]; ye = fwd[c] ? END_LEFT : END_RIGHT; }
-            }
-            note = (nsucc == 1 && y != e) ? (y * 2 + ye) : CWN_NONE;
+            uint32_t side;
+            const Kmer<W> jc = cw_junction_of<W>(cw_key<W, TSW>(L, e), end, k, side);
+            const uint32_t s = cw_jt_register<W, TSW>(L, jc, side, it, k);
+            if (s == NONE32) L.pad = 1u;                 // (table too full: the bucket goes to the next tier; pad is reset below)
+            where = s == NONE32 ? 0xFFFFu : (s | (side << 15));
+        }
+        L.fin[it] = (uint16_t)where;
+    }
+    CDBG_WAVE_SYNC();
+    const bool jt_full = uni_u32(L.pad) != 0u;
+    // ---- ... and reads there whether it is the only end on its side and which end is the only one on the other side ----
+    for (uint32_t it = lane; it < 2 * E; it += 64) {
+        const uint32_t w = L.fin[it];
+        uint32_t note = CWN_FOREIGN;
+        if (w != 0xFFFFu) {
+            const uint32_t side = w >> 15;
+            const uint64_t v = L.jt[w & 0x7FFFu];
+            const uint32_t own = (uint32_t)(v >> (3u * side)) & 7u, opp = (uint32_t)(v >> (3u * (1u - side))) & 7u;
+            const uint32_t y = (uint32_t)(v >> (6u + 10u * (1u - side))) & 0x3FFu;
+            note = (own == 1u && opp == 1u && (y >> 1) != (it >> 1)) ? y : CWN_NONE;   // (never through the node's own other end)
         }
         L.lnk[it] = (uint16_t)note;
+    }
+    CDBG_WAVE_SYNC();
+    // the table goes back empty (every registered end clears its slot)
+    for (uint32_t it = lane; it < 2 * E; it += 64) { const uint32_t w = L.fin[it]; if (w != 0xFFFFu) L.jt[w & 0x7FFFu] = 0ULL; }
+    if (jt_full) {                                       // (uniform) some end found no slot within the probe bound: nothing was written yet
+        for (uint32_t i = lane; i < (uint32_t)TSW; i += 64) L.jt[i] = 0ULL;
+        if (lane == 0) { L.pad = 0; const uint32_t i_ = atomic_add_u32(P.big_count, 1u); P.big_list[i_] = p; }
+        CDBG_WAVE_SYNC();
+        return;
     }
     CDBG_WAVE_SYNC();
     CDBG_WPH(2);
@@ -435,9 +397,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
 #endif
     const uint32_t nopen_posted = np ? uni_u32(L.lw) - (log_ok ? nconf : 0u) : 0u;
     acc[0] += nopen_posted; acc[1] += log_ok ? nconf : 0u; acc[2] += uni_u32(L.ncyc); acc[3] += np;
-    // hand the table back empty (E slots instead of all TSW) and clear the visited marks
     CDBG_WPH(7);
-    for (uint32_t e = lane; e < E; e += 64) L.keys[(uint64_t)L.slot_of[e] * W + (W - 1)] = KEY_EMPTY;
     CDBG_WAVE_SYNC();
     CDBG_WPH(8);
 }
@@ -465,7 +425,7 @@ __global__ void __launch_bounds__(CW_THREADS, W == 1 ? CDBG_CW_WAVES1 : W == 2 ?
     const CompactParams& P = WP.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)uni_u32((uint32_t)tid >> 6);
     CompactWaveLds<W, TSW>& L = Ls[wave];
-    for (uint32_t i = lane; i < (uint32_t)TSW; i += 64) L.keys[(uint64_t)i * W + (W - 1)] = KEY_EMPTY;
+    for (uint32_t i = lane; i < (uint32_t)TSW; i += 64) L.jt[i] = 0ULL;
     CDBG_WAVE_SYNC();
     uint64_t acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
