@@ -26,10 +26,9 @@ template <int W, int TSW>
 struct CompactWaveLds {                                 // one per wave
     static constexpr int EMAX = TSW / 2;
     uint64_t ekeys[EMAX * W];                           // the bucket's k-mers in entry order: word i of entry e at [i * EMAX + e]
-    uint64_t jt[TSW];                                   // junction table: one slot per junction that an end of the bucket registers at (cw_jt_*)
+    uint32_t jt[TSW];                                   // junction table: one slot per junction that an end of the bucket registers at (cw_jt_*)
     uint32_t cnt[EMAX];                                 // count | TRAV_FLAG; after walk 2: (byte offset << 1) | strand
     uint16_t lnk[2 * EMAX];                             // per end (2 * entry + end): note, then link word
-    uint16_t fin[2 * EMAX];
     uint16_t pdesc[EMAX], pn[EMAX], pb[EMAX];           // pieces: start end (bit 15: cyclic), k-mers, relative base offset
     uint8_t vis[EMAX];                                  // bit 0 visited, bit 1 traveller, bit 2 / 3 owns the junction at the left / right end
     uint16_t term[2 * EMAX];                            // terminal ends of home entries (walk 1 work list)
@@ -48,11 +47,11 @@ CDBG_DEV Kmer<W> cw_key(const CompactWaveLds<W, TSW>& L, uint32_t e) {
 // reaches it from each side.  Every end whose junction the bucket owns registers there once (one hash insert of the
 // canonical (k-1)-mer) instead of probing the k-mer table for its four possible successors (four canonical k-mers, four
 // hashes, four probe sequences per end: a third of this kernel's time).  A slot does not hold the (k-1)-mer: it holds a
-// 24-bit tag of its hash and the end that claimed the slot, and a later end with the same tag recomputes the claimer's
-// junction from the entry-ordered k-mers and compares all of it -- exact, at 8 bytes per slot for any k.
+// 7-bit tag of its hash and the end that claimed the slot, and a later end with the same tag recomputes the claimer's
+// junction from the entry-ordered k-mers and compares all of it -- exact, at 4 bytes per slot for any k.
 //   bits [0,3) / [3,6)   ends registered on side 0 / 1 (side 0: the end's outgoing (k-1)-suffix IS the canonical junction)
-//   bits [6,16) / [16,26) the first end registered on side 0 / 1      bit 26  the side of the end that claimed the slot
-//   bits [40,64)          tag (bit 63 set: a claimed slot is never 0)
+//   bits [6,15) / [15,24) the first end registered on side 0 / 1      bit 24  the side of the end that claimed the slot
+//   bits [25,32)          tag            (a claimed slot is never 0: the claimer's side counts 1)
 // Even k: a k-mer that is its own reverse complement reaches the junction with both of its ends from the same side, so
 // that side counts 2 and the junction is never 1-in/1-out (the two edges (s,+) / (s,-) of the overlap table, .md:41-46).
 // Odd k: a junction that is its own reverse complement has one side only -- never 1-in/1-out either (every end there
@@ -68,28 +67,28 @@ CDBG_DEV Kmer<W> cw_junction_of(const Kmer<W>& x, uint32_t end, int k, uint32_t&
 // registers end `it` (side known) at junction jc; returns the slot, or NONE32 when the table is too full (the caller defers the bucket)
 template <int W, int TSW>
 CDBG_DEV uint32_t cw_jt_register(CompactWaveLds<W, TSW>& L, const Kmer<W>& jc, uint32_t side, uint32_t it, int k) {
-    constexpr int LOG = TSW == 1024 ? 10 : TSW == 512 ? 9 : TSW == 256 ? 8 : TSW == 128 ? 7 : -1;
-    static_assert(LOG > 0, "wave table size");
+    constexpr int LOG = TSW == 512 ? 9 : TSW == 256 ? 8 : TSW == 128 ? 7 : -1;
+    static_assert(LOG > 0, "wave table size (end ids are 9-bit fields of a slot)");
     const uint32_t h = jc.hash_lds();
     uint32_t s = h >> (32 - LOG);
-    const uint64_t tag = (uint64_t)((h & 0x7FFFFFu) | 0x800000u) << 40;
-    const uint64_t mine = tag | ((uint64_t)side << 26) | ((uint64_t)it << (6u + 10u * side)) | (1ULL << (3u * side));
+    const uint32_t tag = (h << LOG) & 0xFE000000u;               // the 7 hash bits below the slot index
+    const uint32_t mine = tag | (side << 24) | (it << (6u + 9u * side)) | (1u << (3u * side));
     uint32_t probes = 0, res = NONE32; bool done = false;
 #pragma clang loop unroll(disable)
     do {
-        const uint64_t old = atomic_cas_u64(&L.jt[s], 0ULL, mine);
+        const uint32_t old = atomic_cas_u32(&L.jt[s], 0u, mine);
         bool same = false;
-        if (old != 0ULL && (old >> 40) == (tag >> 40)) {          // same tag: is it the same junction?  ask the end that claimed the slot
-            const uint32_t cs = (uint32_t)(old >> 26) & 1u, rid = (uint32_t)(old >> (6u + 10u * cs)) & 0x3FFu;
+        if (old != 0u && (old & 0xFE000000u) == tag) {            // same tag: is it the same junction?  ask the end that claimed the slot
+            const uint32_t cs = (old >> 24) & 1u, rid = (old >> (6u + 9u * cs)) & 0x1FFu;
             uint32_t rside;
             const Kmer<W> rj = cw_junction_of<W>(cw_key<W, TSW>(L, rid >> 1), rid & 1u, k, rside);
             same = rj == jc;
         }
         if (same) {
-            const uint64_t before = atomic_add_u64(&L.jt[s], 1ULL << (3u * side));
-            if (((before >> (3u * side)) & 7ULL) == 0ULL) atomic_or_u64(&L.jt[s], (uint64_t)it << (6u + 10u * side));   // the first end on this side
+            const uint32_t before = atomic_add_u32(&L.jt[s], 1u << (3u * side));
+            if (((before >> (3u * side)) & 7u) == 0u) atomic_or_u32(&L.jt[s], it << (6u + 9u * side));   // the first end on this side
         }
-        done = (old == 0ULL) | same;
+        done = (old == 0u) | same;
         res = done ? s : res;
         s = done ? s : ((s + 1) & (TSW - 1)); probes += done ? 0u : 1u;
     } while (!done && probes < 48u);
@@ -198,66 +197,53 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
             uint32_t side;
             const Kmer<W> jc = cw_junction_of<W>(cw_key<W, TSW>(L, e), end, k, side);
             const uint32_t s = cw_jt_register<W, TSW>(L, jc, side, it, k);
-            if (s == NONE32) L.pad = 1u;                 // (table too full: the bucket goes to the next tier; pad is reset below)
+            if (s == NONE32) L.pad = 1u;                 // (table too full: the bucket goes to the next tier)
             where = s == NONE32 ? 0xFFFFu : (s | (side << 15));
         }
-        L.fin[it] = (uint16_t)where;
+        L.lnk[it] = (uint16_t)where;
     }
     CDBG_WAVE_SYNC();
-    const bool jt_full = uni_u32(L.pad) != 0u;
-    // ---- ... and reads there whether it is the only end on its side and which end is the only one on the other side ----
-    for (uint32_t it = lane; it < 2 * E; it += 64) {
-        const uint32_t w = L.fin[it];
-        uint32_t note = CWN_FOREIGN;
-        if (w != 0xFFFFu) {
-            const uint32_t side = w >> 15;
-            const uint64_t v = L.jt[w & 0x7FFFu];
-            const uint32_t own = (uint32_t)(v >> (3u * side)) & 7u, opp = (uint32_t)(v >> (3u * (1u - side))) & 7u;
-            const uint32_t y = (uint32_t)(v >> (6u + 10u * (1u - side))) & 0x3FFu;
-            note = (own == 1u && opp == 1u && (y >> 1) != (it >> 1)) ? y : CWN_NONE;   // (never through the node's own other end)
-        }
-        L.lnk[it] = (uint16_t)note;
-    }
-    CDBG_WAVE_SYNC();
-    // the table goes back empty (every registered end clears its slot)
-    for (uint32_t it = lane; it < 2 * E; it += 64) { const uint32_t w = L.fin[it]; if (w != 0xFFFFu) L.jt[w & 0x7FFFu] = 0ULL; }
-    if (jt_full) {                                       // (uniform) some end found no slot within the probe bound: nothing was written yet
-        for (uint32_t i = lane; i < (uint32_t)TSW; i += 64) L.jt[i] = 0ULL;
-        if (lane == 0) { L.pad = 0; const uint32_t i_ = atomic_add_u32(P.big_count, 1u); P.big_list[i_] = p; }
+    if (uni_u32(L.pad) != 0u) {                          // (uniform) some end found no slot within the probe bound: nothing was written yet
+        for (uint32_t i = lane; i < (uint32_t)TSW; i += 64) L.jt[i] = 0u;
+        if (lane == 0) { const uint32_t i_ = atomic_add_u32(P.big_count, 1u); P.big_list[i_] = p; }
         CDBG_WAVE_SYNC();
         return;
     }
-    CDBG_WAVE_SYNC();
     CDBG_WPH(2);
-    // a junction is 1-in/1-out exactly when two ends name each other; terminal ends of home entries go on a list
+    // ---- ... and reads there whether it is the only end on its side and which end is the only one on the other side: a
+    // junction is 1-in/1-out exactly then (both ends read the same counts, so the partnership is mutual by construction).
+    // Terminal ends of home entries go on a list. ----
     for (uint32_t it = lane; it < 2 * E; it += 64) {
         const uint32_t e = it >> 1;
+        const uint32_t w = L.lnk[it];
         const bool home = !(L.cnt[e] & TRAV_FLAG);
-        const uint32_t note = L.lnk[it];
         uint32_t link = LNK_DEAD; bool conf = false;
-        if (note == CWN_FOREIGN) link = LNK_OPEN;
-        else if (note != CWN_NONE && L.lnk[note] == it) {
-            const uint32_t y = note >> 1, ye = note & 1u;
-            const bool yhome = !(L.cnt[y] & TRAV_FLAG);
-            if (home && yhome) link = LNK_INTERNAL | (ye << 2) | (y << 3);
-            else {
-                // 1-1 junction with a traveller on at least one side: confirm it for glue, once (a home end is open and
-                // posted anyway: its confirmation rides on that record)
-                if (home || (!yhome && e < y)) { conf = true; if (!home) atomic_add_u32(&L.nconf, 1u); }
-                if (home) link = LNK_OPEN;
+        if (w == 0xFFFFu) link = LNK_OPEN;
+        else {
+            const uint32_t side = w >> 15;
+            const uint32_t v = L.jt[w & 0x7FFFu];
+            const uint32_t own = (v >> (3u * side)) & 7u, opp = (v >> (3u * (1u - side))) & 7u;
+            const uint32_t yy = (v >> (6u + 9u * (1u - side))) & 0x1FFu, y = yy >> 1, ye = yy & 1u;
+            if (own == 1u && opp == 1u && y != e) {      // (never through the node's own other end)
+                const bool yhome = !(L.cnt[y] & TRAV_FLAG);
+                if (home && yhome) link = LNK_INTERNAL | (ye << 2) | (y << 3);
+                else {
+                    // 1-1 junction with a traveller on at least one side: confirm it for glue, once (a home end is open and
+                    // posted anyway: its confirmation rides on that record)
+                    if (home || (!yhome && e < y)) { conf = true; if (!home) atomic_add_u32(&L.nconf, 1u); }
+                    if (home) link = LNK_OPEN;
+                }
             }
         }
-        L.fin[it] = (uint16_t)((home ? link : LNK_DEAD) | (conf ? CWL_CONF : 0u));
-    }
-    CDBG_WAVE_SYNC();
-    for (uint32_t it = lane; it < 2 * E; it += 64) {
-        const uint32_t l = L.fin[it];
+        const uint32_t l = (home ? link : LNK_DEAD) | (conf ? CWL_CONF : 0u);
         L.lnk[it] = (uint16_t)l;
-        if (!(L.cnt[it >> 1] & TRAV_FLAG) && (l & 3u) != LNK_INTERNAL) {   // terminal end of a home entry
+        if (home && (l & 3u) != LNK_INTERNAL) {          // terminal end of a home entry
             const uint32_t ti = atomic_add_u32(&L.pad, 1u);
             L.term[ti] = (uint16_t)it;
         }
     }
+    CDBG_WAVE_SYNC();
+    for (uint32_t i = lane; i < (uint32_t)TSW; i += 64) L.jt[i] = 0u;   // the table goes back empty
     CDBG_WAVE_SYNC();
 
     CDBG_WPH(3);
@@ -392,7 +378,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
     }
     CDBG_WAVE_SYNC();
 #ifdef CDBG_WAVE_DEBUG
-    if (lane == 0) { for (uint32_t it = 0; it < 2 * E; ++it) fprintf(stderr, " [%u cnt %x vis %x lnk %04x fin %04x]", it, L.cnt[it >> 1], L.vis[it >> 1], L.lnk[it], L.fin[it]); fprintf(stderr, "\n"); }
+    if (lane == 0) { for (uint32_t it = 0; it < 2 * E; ++it) fprintf(stderr, " [%u cnt %x vis %x lnk %04x]", it, L.cnt[it >> 1], L.vis[it >> 1], L.lnk[it]); fprintf(stderr, "\n"); }
     if (lane == 0) fprintf(stderr, "bucket %u E %u np %u nconf %u nopen %u lw %u pbase %llu lbase %llu nterm %u ncov %u nhome %u\n", p, E, np, nconf, L.nopen, L.lw, (unsigned long long)pbase, (unsigned long long)lbase, nterm, L.ncov, n_home);
 #endif
     const uint32_t nopen_posted = np ? uni_u32(L.lw) - (log_ok ? nconf : 0u) : 0u;
@@ -408,14 +394,16 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
 // wave: queue ticket -> segment descriptor -> entries -> compaction, one bucket apart each; the entries live in two
 // register sets (ping-pong, as in k_count_fast).
 template <int W, int TSW>
-// waves per SIMD promised to the register allocator: left alone it takes 131 / 126 / 179 VGPRs (W = 1 / 2 / 4), which caps
-// the kernel at 12 / 16 / 8 waves per CU below what the LDS allows.  Measured: W = 4 with <= 168 VGPRs 163 -> 131 ms
-// (config-5 share), W = 2 with <= 96 126 -> 122 ms, W = 1 with <= 128 48.5 -> 49.2 ms (left alone)
+// waves per SIMD promised to the register allocator.  With the junction table (4-byte slots, no k-mer hash table) a workgroup of
+// two waves needs 18 / 11 / 15 KB of LDS (W = 1 / 2 / 4), i.e. the LDS has room for 16 / 28 / 20 waves per CU, and the kernel waits
+// on dependent LDS round trips: occupancy is what it is short of.  Left alone the compiler takes 132 / 83 / 110 VGPRs = 12 / 20 / 16
+// waves per CU.  Measured: W = 1 promised 4 (<= 128 VGPRs, 16 waves per CU) 32.2 -> 26.7 ms at config 3; W = 2 promised 6 (<= 80)
+// 49.3 -> 47.7 ms at the config-4 share; W = 4 promised 4 or 5: no change (37.7 ms).
 #ifndef CDBG_CW_WAVES1
-#define CDBG_CW_WAVES1 1
+#define CDBG_CW_WAVES1 4
 #endif
 #ifndef CDBG_CW_WAVES2
-#define CDBG_CW_WAVES2 5
+#define CDBG_CW_WAVES2 6
 #endif
 #ifndef CDBG_CW_WAVES4
 #define CDBG_CW_WAVES4 3
@@ -425,7 +413,7 @@ __global__ void __launch_bounds__(CW_THREADS, W == 1 ? CDBG_CW_WAVES1 : W == 2 ?
     const CompactParams& P = WP.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)uni_u32((uint32_t)tid >> 6);
     CompactWaveLds<W, TSW>& L = Ls[wave];
-    for (uint32_t i = lane; i < (uint32_t)TSW; i += 64) L.jt[i] = 0ULL;
+    for (uint32_t i = lane; i < (uint32_t)TSW; i += 64) L.jt[i] = 0u;
     CDBG_WAVE_SYNC();
     uint64_t acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
