@@ -107,17 +107,30 @@ CDBG_DEV void glue_record_put(const CompactParams& P, uint64_t o, const Kmer<W>&
 // bases [i, i + 8) of a k-mer as 8 ASCII letters in memory order: one 16-bit field (the word index is a select chain once
 // per 8 bases, not per base), 2-bit codes spread to bytes, letters by arithmetic (0 A 0x41, 1 C 0x43, 2 G 0x47, 3 T 0x54)
 template <int W>
-CDBG_DEV uint64_t kmer_ascii8(const Kmer<W>& x, int k, int i) {
+CDBG_DEV uint32_t kmer_bases8(const Kmer<W>& x, int k, int i) {   // bases i .. i + 7 as 16 bits: base i in bits 15:14 ... base i + 7 in bits 1:0
     const int pos = 2 * (k - i - 8);                       // bit of base i + 7; requires 0 <= i, i + 8 <= k
     uint64_t v = x.word_z(pos >> 6) >> (pos & 63);
     if (W > 1 && (pos & 63) > 48) v |= x.word_z((pos >> 6) + 1) << (64 - (pos & 63));
-    const uint32_t f = (uint32_t)v & 0xFFFFu;             // base i in bits 15:14 ... base i + 7 in bits 1:0
+    return (uint32_t)v & 0xFFFFu;
+}
+CDBG_DEV uint64_t ascii8_of_bases(uint32_t f) {
     const uint32_t a = f >> 8, b = f & 0xFFu;
     const uint32_t ta = ((a >> 6) & 3u) | (((a >> 4) & 3u) << 8) | (((a >> 2) & 3u) << 16) | ((a & 3u) << 24);
     const uint32_t tb = ((b >> 6) & 3u) | (((b >> 4) & 3u) << 8) | (((b >> 2) & 3u) << 16) | ((b & 3u) << 24);
     const uint32_t ea = ((ta & 0x01010101u) * 2u) + ((ta & 0x02020202u) * 3u) + 0x41414141u + (((ta >> 1) & ta & 0x01010101u) * 11u);
     const uint32_t eb = ((tb & 0x01010101u) * 2u) + ((tb & 0x02020202u) * 3u) + 0x41414141u + (((tb >> 1) & tb & 0x01010101u) * 11u);
     return (uint64_t)ea | ((uint64_t)eb << 32);
+}
+template <int W>
+CDBG_DEV uint64_t kmer_ascii8(const Kmer<W>& x, int k, int i) { return ascii8_of_bases(kmer_bases8<W>(x, k, i)); }
+// bases i .. i + 7 of rc(x) without forming rc(x): the complement of bases k - 8 - i .. k - 1 - i of x, in reverse order
+template <int W>
+CDBG_DEV uint64_t kmer_rc_ascii8(const Kmer<W>& x, int k, int i) {
+    uint32_t f = kmer_bases8<W>(x, k, k - 8 - i);
+    f = ((f >> 8) | (f << 8)) & 0xFFFFu;                   // reverse the eight 2-bit groups: bytes, nibbles, pairs
+    f = ((f >> 4) & 0x0F0Fu) | ((f & 0x0F0Fu) << 4);
+    f = ((f >> 2) & 0x3333u) | ((f & 0x3333u) << 2);
+    return ascii8_of_bases(f ^ 0xFFFFu);
 }
 // the first n bases of x to dst (any alignment): 8 per store, the last 8 overlapping; bytes when n < 8
 template <int W>

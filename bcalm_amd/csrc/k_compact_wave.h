@@ -56,17 +56,18 @@ CDBG_DEV Kmer<W> cw_key(const CompactWaveLds<W, TSW>& L, uint32_t e) {
 // that side counts 2 and the junction is never 1-in/1-out (the two edges (s,+) / (s,-) of the overlap table, .md:41-46).
 // Odd k: a junction that is its own reverse complement has one side only -- never 1-in/1-out either (every end there
 // sees its own node's reverse complement among its successors).
+// j: the junction as the end leaves through it; r: its reverse complement; returns the canonical one of the two and the side
 template <int W>
-CDBG_DEV Kmer<W> cw_junction_of(const Kmer<W>& x, uint32_t end, int k, uint32_t& side) {
+CDBG_DEV Kmer<W> cw_junction_of(const Kmer<W>& x, uint32_t end, int k, uint32_t& side, Kmer<W>& j, Kmer<W>& r) {
     Kmer<W> u, ur; orient_pair<W>(x, end, k, u, ur);
-    const Kmer<W> j = suffix_km1<W>(u, k), r = ur.shr(2);      // the junction as the end leaves through it, and its reverse complement
+    j = suffix_km1<W>(u, k); r = ur.shr(2);
     const bool rev = r < j;
     side = rev ? 1u : 0u;
     return rev ? r : j;
 }
 // registers end `it` (side known) at junction jc; returns the slot, or NONE32 when the table is too full (the caller defers the bucket)
 template <int W, int TSW>
-CDBG_DEV uint32_t cw_jt_register(CompactWaveLds<W, TSW>& L, const Kmer<W>& jc, uint32_t side, uint32_t it, int k) {
+CDBG_DEV uint32_t cw_jt_register(CompactWaveLds<W, TSW>& L, const Kmer<W>& jc, const Kmer<W>& j, const Kmer<W>& r, uint32_t side, uint32_t it, int k) {
     constexpr int LOG = TSW == 512 ? 9 : TSW == 256 ? 8 : TSW == 128 ? 7 : -1;
     static_assert(LOG > 0, "wave table size (end ids are 9-bit fields of a slot)");
     const uint32_t h = jc.hash_lds();
@@ -79,10 +80,12 @@ CDBG_DEV uint32_t cw_jt_register(CompactWaveLds<W, TSW>& L, const Kmer<W>& jc, u
         const uint32_t old = atomic_cas_u32(&L.jt[s], 0u, mine);
         bool same = false;
         if (old != 0u && (old & 0xFE000000u) == tag) {            // same tag: is it the same junction?  ask the end that claimed the slot
+            // (no reverse complement needed: the stored k-mer x' of that end touches its junction with its (k-1)-suffix -- right
+            //  end -- or its (k-1)-prefix -- left end -- as written, and the junctions are equal exactly when that is j or rc(j))
             const uint32_t cs = (old >> 24) & 1u, rid = (old >> (6u + 9u * cs)) & 0x1FFu;
-            uint32_t rside;
-            const Kmer<W> rj = cw_junction_of<W>(cw_key<W, TSW>(L, rid >> 1), rid & 1u, k, rside);
-            same = rj == jc;
+            const Kmer<W> xr = cw_key<W, TSW>(L, rid >> 1);
+            const Kmer<W> c = (rid & 1u) == END_RIGHT ? suffix_km1<W>(xr, k) : prefix_km1<W>(xr, k);
+            same = (c == j) | (c == r);
         }
         if (same) {
             const uint32_t before = atomic_add_u32(&L.jt[s], 1u << (3u * side));
@@ -194,9 +197,9 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
         const uint32_t e = it >> 1, end = it & 1u;
         uint32_t where = 0xFFFFu;                        // junction owned elsewhere: glue decides
         if ((L.vis[e] >> (2 + end)) & 1u) {
-            uint32_t side;
-            const Kmer<W> jc = cw_junction_of<W>(cw_key<W, TSW>(L, e), end, k, side);
-            const uint32_t s = cw_jt_register<W, TSW>(L, jc, side, it, k);
+            uint32_t side; Kmer<W> j, r;
+            const Kmer<W> jc = cw_junction_of<W>(cw_key<W, TSW>(L, e), end, k, side, j, r);
+            const uint32_t s = cw_jt_register<W, TSW>(L, jc, j, r, side, it, k);
             if (s == NONE32) L.pad = 1u;                 // (table too full: the bucket goes to the next tier)
             where = s == NONE32 ? 0xFFFFu : (s | (side << 15));
         }
@@ -350,12 +353,28 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
             if ((ll & 3u) == LNK_OPEN) L.lnk[il] = (uint16_t)(CWL_POSTED | (ll & CWL_CONF) | (li * 2u + 0u));
             if ((lr & 3u) == LNK_OPEN) L.lnk[ir] = (uint16_t)(CWL_POSTED | (lr & CWL_CONF) | (li * 2u + 1u));
         }
-        // the first k-1 bases of the piece: the start k-mer, read leaving through the far end of the start terminal
-        const Kmer<W> x0 = cw_key<W, TSW>(L, s0);
-        const Kmer<W> xo = ((e0 ^ 1u) == END_RIGHT) ? x0 : x0.rc(k);
-        kmer_prefix_ascii<W>(out + rel, xo, k, k - 1);   // (8 bases per unaligned store: 30 byte stores per piece were 2 G transactions at config 3)
+        L.pb[li] = (uint16_t)rel;                        // (bucket-relative: at most EMAX * k bytes)
+        if (k < 9) {                                     // (fewer than 8 prefix bases: byte stores, here)
+            const Kmer<W> x0 = cw_key<W, TSW>(L, s0);
+            const Kmer<W> xo = ((e0 ^ 1u) == END_RIGHT) ? x0 : x0.rc(k);
+            kmer_prefix_ascii<W>(out + rel, xo, k, k - 1);
+        }
     }
     CDBG_WAVE_SYNC();
+    // the first k-1 bases of every piece -- the start k-mer, read leaving through the far end of the start terminal -- one lane
+    // per 8 bases (an unaligned 8-byte store; the last chunk of a piece overlaps the one before): with one lane per piece the
+    // 16 stores of a 127-mer's prefix were serial work of a few lanes (walk 2: a third of this kernel at k = 127)
+    if (k >= 9) {
+        const uint32_t nchunk = ((uint32_t)k - 1u + 7u) >> 3;
+        for (uint32_t item = lane; item < np * nchunk; item += 64) {
+            const uint32_t li = item / nchunk, c = item - li * nchunk;
+            const uint32_t d = L.pdesc[li], start = d & 0x7FFFu;
+            const Kmer<W> x0 = cw_key<W, TSW>(L, start >> 1);
+            const int i = (int)(8u * c + 8u > (uint32_t)k - 1u ? (uint32_t)k - 9u : 8u * c);
+            const uint64_t v = ((start & 1u) ^ 1u) == END_RIGHT ? kmer_ascii8<W>(x0, k, i) : kmer_rc_ascii8<W>(x0, k, i);
+            st_unaligned_u64(out + L.pb[li] + i, v);
+        }
+    }
     CDBG_WPH(6);
     if (np) {
         // last base of every home k-mer (one lane per k-mer; no reverse complement needed:
