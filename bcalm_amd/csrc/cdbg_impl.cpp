@@ -725,7 +725,10 @@ int count_impl(cdbg_ctx* c) {
     // one-pass kernel over all partitions; the ones whose distinct k-mers do not fit the LDS table at once come back on
     // the retry list and go through the multi-pass kernel
     {
-        CountFastParams fp{ cp, c->retry_list.p, c->big_count.p + 1 };
+        // (admission by predicted fill: k_count_fast.h; one-word k-mers: off -- their second tier runs one workgroup per CU against three)
+        CountFastParams fp{ cp, c->retry_list.p, c->big_count.p + 1, COUNT_FAST_MAX_RECORDS, W == 1 ? 0u : W == 2 ? 177u : 200u };
+        if (const char* e = getenv("CDBG_FAST_SKIP_Q8")) fp.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
+        if (const char* e = getenv("CDBG_FAST_MAX_RECORDS")) fp.fast_max_records = std::min<uint32_t>(COUNT_FAST_MAX_RECORDS, (uint32_t)std::max(1, atoi(e)));   // dev knob
         if (capped) CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, true>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, fp);
         else CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, fp);
     }
@@ -741,7 +744,7 @@ int count_impl(cdbg_ctx* c) {
         CK(c->retry_list2.alloc(nretry, false));
         HIPCK(hipMemsetAsync(c->big_count.p + 2, 0, sizeof(uint32_t), s));
         CountParams c2 = cp; c2.part_list = c->retry_list.p; c2.n_items = nretry;
-        CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2 };
+        CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2, COUNT_FAST_MAX_RECORDS, 0u };
         if (capped) CDBG_LAUNCH((k_count_fast<W, 2 * TS, Cfg<W>::NTC, 3>), std::min<uint64_t>(nretry, 256), Cfg<W>::NTC, s, fp2);
         else CDBG_LAUNCH((k_count_fast<W, 2 * TS, Cfg<W>::NTC, 2>), std::min<uint64_t>(nretry, 256), Cfg<W>::NTC, s, fp2);
         HIPCK(hipStreamSynchronize(s));

@@ -60,6 +60,9 @@ struct CountFastLds {
 struct CountFastParams {
     CountParams c;                                       // item_off / g_* unused here; part_list only by the LISTED tier
     uint32_t* retry_list; uint32_t* retry_count;         // partitions that need the multi-pass kernel
+    uint32_t fast_max_records;                           // partitions with more records are not tried (<= COUNT_FAST_MAX_RECORDS)
+    uint32_t skip_fill_q8;                               // 0: off.  Else a partition whose PREDICTED distinct k-mers (records x the workgroup's
+                                                         // running distinct-per-record average) exceed skip_fill_q8 / 256 of the table goes to the next tier untried
 };
 
 // raw words of a partition's record range as loaded: resolved one partition later, so that no load is waited for
@@ -126,7 +129,7 @@ CDBG_DEV void count_load_chunk(const CountParams& P, uint64_t first, uint64_t en
         for (int i = 0; i < RW; ++i) R.r[i] = P.records[(first + lane) * RW + i];
     }
 }
-struct CountAcc { uint32_t dist, sh, st; uint64_t occ;
+struct CountAcc { uint32_t dist, sh, st, last_fill; uint64_t occ;
 #ifdef CDBG_PROFILE_PHASES
     uint64_t ph[8], t_prev;
 #endif
@@ -322,6 +325,7 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
     CDBG_LDS_BARRIER();                                                           // ---- barrier A: all inserts done ----
     CDBG_FPH(3);
     const uint32_t need = uni_u32(L.fill[par]);
+    if (W > 1) acc.last_fill = need;                                           // (what the admission rule of the caller learns from)
     if (uni_u32(L.over) || need > (uint32_t)(TS - TS / 4)) return false;       // uniform
     if (need > chunk_left) {                                                   // uniform: new chunk (one device atomic per COUNT_CHUNK entries)
         if (tid == 0) L.cbase = atomic_add_u64(P.solid_cursor, (uint64_t)COUNT_CHUNK);
@@ -401,7 +405,7 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, 
     const CountParams& P = FP.c;
     constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)uni_u32((uint32_t)tid >> 6);
-    CountAcc ca; ca.dist = 0; ca.sh = 0; ca.st = 0; ca.occ = 0;
+    CountAcc ca; ca.dist = 0; ca.sh = 0; ca.st = 0; ca.occ = 0; ca.last_fill = 0;
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
     for (int i = 0; i < 8; ++i) ca.ph[i] = 0;
     ca.t_prev = clock64();
@@ -416,6 +420,15 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, 
     S0.raw = count_raw_load<CAPPED>(P, blockIdx.x + stride);
     { uint64_t w0, w1; count_share<W, NW>(rg_cur, wave, w0, w1); count_load_chunk<W>(P, w0, w1, lane, S0.R); }
     uint32_t par = 0, misses = 0, deferred = 0;          // misses: consecutive partitions that did not fit one pass; deferred: partitions sent on untried since
+    // Admission by predicted fill.  A partition that overflows the table costs its whole insert phase for nothing, and well before
+    // that the probe sequences of a table more than half full are long, while the next tier's table is twice the size: measured at the
+    // config-5 share (k = 127: 6 records of 53 members per partition on average, a heavy tail of partitions with two minimizer loci)
+    // count 332 -> 256 ms when partitions of >= 24 records skip this tier, at the config-4 share (k = 55) 154 -> 145 ms at >= 175 records;
+    // both are the same rule in units of the table: predicted distinct k-mers > 0.47 / 0.69 of the slots.  The prediction: the
+    // partition's size -- its member k-mers where every wave sees all records anyway (CountBal, k >= 64: 1 .. 122 members per
+    // record), its records otherwise -- times the distinct k-mers per unit of size that this workgroup has seen so far (running
+    // average over its partitions, 8 fractional bits).
+    uint32_t dpu_q8 = 0;
     auto one_partition = [&](CountSet<W, CAPPED>& cur, CountSet<W, CAPPED>& nxt, const uint32_t item) {
         CountAhead<W, CAPPED> A;
         A.cur = &cur; A.nxt = &nxt; A.item_nxt = item + stride; A.item_nn = item + 2 * stride; A.issued = false;
@@ -425,8 +438,18 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, 
             // 16th partition: one heavy locus must not send the rest of the workgroup's stride to the slower tiers
             bool try_fast = misses < 4;
             if (!try_fast && ++deferred >= 16u) { try_fast = true; deferred = 0; }
-            if (try_fast && rg_cur.n < COUNT_FAST_MAX_RECORDS) {   // (a partition that could carry a count to the 31-bit ceiling goes to the saturating kernels)
+            uint32_t size = rg_cur.n;
+            if (W > 1 && FP.skip_fill_q8) {              // (uniform; one-word k-mers never use the rule)
+                if (CountBal<W>::ON && rg_cur.n <= 64u) size = wave_readlane_u32(wave_incl_sum_u32((uint32_t)cur.R.n()), 63);   // (lanes without a record hold zeros)
+                else if (CountBal<W>::ON) size = rg_cur.n * 64u;   // (more than one chunk of records: big; any large number will do)
+                if ((((uint64_t)size * dpu_q8) >> 8) * 256u > (uint64_t)TS * FP.skip_fill_q8) try_fast = false;
+            }
+            if (try_fast && rg_cur.n < FP.fast_max_records) {   // (a partition that could carry a count to the 31-bit ceiling goes to the saturating kernels)
                 done = count_partition_fast<W, TS, NT, CAPPED>(P, L, rg_cur, A, par, chunk_base, chunk_left, ca);
+                if (W > 1 && FP.skip_fill_q8) {          // (a partition that did not fit still says: at least this many distinct k-mers)
+                    const uint32_t sample = (uint32_t)((float)ca.last_fill * 256.0f / (float)(size ? size : 1u));
+                    dpu_q8 = dpu_q8 ? (uint32_t)((int32_t)dpu_q8 + (((int32_t)sample - (int32_t)dpu_q8) >> 4)) : sample;
+                }
                 if (done) { par ^= 1u; misses = 0; deferred = 0; }
                 else {                                   // leave a clean table and known counters behind
                     CDBG_LDS_BARRIER();
