@@ -150,12 +150,6 @@ CDBG_DEV void kmer_prefix_ascii(uint8_t* dst, const Kmer<W>& x, int k, int n) {
 template <int W>
 CDBG_DEV Kmer<W> orient_out(const Kmer<W>& x, uint32_t end, int k) { return end == END_RIGHT ? x : x.rc(k); }
 
-template <int W>
-CDBG_DEV Kmer<W> canon_junction(const Kmer<W>& u_out, int k) {
-    Kmer<W> j = suffix_km1<W>(u_out, k);
-    Kmer<W> r = j.rc(k - 1);
-    return (r < j) ? r : j;
-}
 // A stored (canonical) k-mer x seen from one of its ends: u reads out of that end, ur = rc(u).  One reverse complement
 // serves both (x.rc for the left end IS u, for the right end it is rc(u)); orient_out followed by u.rc(k) took two.
 template <int W>

@@ -8,9 +8,12 @@
 // 256-thread workgroup and 13 workgroup barriers; its phase profile (profiles/r02_*) is latency, not work:
 // most lanes idle in every phase and every barrier waits for the slowest wave.  Here a bucket belongs to one
 // wavefront: a phase is 3-5 wave iterations, phases are separated by wave-level ordering only (the LDS executes a
-// wave's instructions in order), four buckets are in flight per workgroup and ~16 per CU.  Per-bucket state is
-// entry-indexed 16-bit words (<= TSW/2 entries), ~10 KB of LDS per wave for one-word k-mers.
-// Buckets with more entries than TSW/2 are deferred to the workgroup-per-bucket tiers of k_compact.
+// wave's instructions in order), two buckets are in flight per workgroup and 16-24 per CU.  Per-bucket state is
+// entry-indexed (<= TSW/2 entries): the k-mers in entry order, 16-bit link / piece words and a table of 4-byte
+// slots in which every k-mer end registers at its junction (cw_jt_*: the classification is junction-centric, the
+// workgroup tiers of k_compact.h still probe for successors) -- 9 KB of LDS per wave for one-word k-mers.
+// Buckets with more entries than TSW/2 (or more junctions than the table takes) are deferred: to a second launch of
+// this kernel with a table twice the size (W >= 2), then to the workgroup-per-bucket tiers of k_compact.
 #pragma once
 #include "k_compact.h"
 
