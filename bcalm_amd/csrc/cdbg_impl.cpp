@@ -745,8 +745,14 @@ int count_impl(cdbg_ctx* c) {
         HIPCK(hipMemsetAsync(c->big_count.p + 2, 0, sizeof(uint32_t), s));
         CountParams c2 = cp; c2.part_list = c->retry_list.p; c2.n_items = nretry;
         CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2, COUNT_FAST_MAX_RECORDS, 0u };
-        if (capped) CDBG_LAUNCH((k_count_fast<W, 2 * TS, Cfg<W>::NTC, 3>), std::min<uint64_t>(nretry, 256), Cfg<W>::NTC, s, fp2);
-        else CDBG_LAUNCH((k_count_fast<W, 2 * TS, Cfg<W>::NTC, 2>), std::min<uint64_t>(nretry, 256), Cfg<W>::NTC, s, fp2);
+        // (multi-word k-mers: 1024 threads -- the table fills the CU's LDS either way, so the workgroup size IS the occupancy: 16
+        //  waves per CU instead of 8, second tier 81 -> 67 ms at the config-5 share, 24 -> 18 at the config-4 share)
+#ifndef CDBG_NT_TIER2
+#define CDBG_NT_TIER2 1024
+#endif
+        constexpr int NT2 = W == 1 ? Cfg<W>::NTC : CDBG_NT_TIER2;
+        if (capped) CDBG_LAUNCH((k_count_fast<W, 2 * TS, NT2, 3>), std::min<uint64_t>(nretry, 256), NT2, s, fp2);
+        else CDBG_LAUNCH((k_count_fast<W, 2 * TS, NT2, 2>), std::min<uint64_t>(nretry, 256), NT2, s, fp2);
         HIPCK(hipStreamSynchronize(s));
         CK(read_u32(c->big_count.p + 2, &nretry));
         retry_ptr = c->retry_list2.p;
