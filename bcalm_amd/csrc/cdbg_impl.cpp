@@ -761,14 +761,17 @@ int count_impl(cdbg_ctx* c) {
     if (nretry) {
         CountParams rp1 = cp;
         rp1.part_list = retry_ptr; rp1.n_items = nretry;
-        CDBG_LAUNCH((k_count<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(nretry, PERSISTENT_GRID), Cfg<W>::NTC, s, rp1);
+        // (multi-word k-mers: the table of the second tier and 1024 threads -- half the passes at 16 waves per CU: 45 -> 39 ms at the config-5 share)
+        constexpr int TSG = W == 1 ? TS : 2 * TS, NTG = W == 1 ? Cfg<W>::NTC : 1024;
+        CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(nretry, W == 1 ? PERSISTENT_GRID : 256), NTG, s, rp1);
     }
     if (n_spilled_parts) {                                   // spilled partitions: count their gathered copies
         CountParams rp2 = cp;
         rp2.records = c->repair_recs.p; rp2.item_off = c->repair_off.p; rp2.part_list = c->repair_part.p; rp2.part_stride = 0;
         rp2.n_items = (uint32_t)n_spilled_parts; rp2.max_passes = 4096;
         if (const char* ev = getenv("CDBG_REPAIR_MAX_PASSES")) rp2.max_passes = (uint32_t)std::max(1, atoi(ev));   // (tests: a spilled partition that is deferred as well)
-        CDBG_LAUNCH((k_count<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(rp2.n_items, PERSISTENT_GRID), Cfg<W>::NTC, s, rp2);
+        constexpr int TSG = W == 1 ? TS : 2 * TS, NTG = W == 1 ? Cfg<W>::NTC : 1024;
+        CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(rp2.n_items, W == 1 ? PERSISTENT_GRID : 256), NTG, s, rp2);
     }
     uint32_t nbig = 0;
     HIPCK(hipStreamSynchronize(s));
