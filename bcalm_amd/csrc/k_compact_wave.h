@@ -29,12 +29,12 @@ template <int W, int TSW>
 struct CompactWaveLds {                                 // one per wave
     static constexpr int EMAX = TSW / 2;
     uint64_t ekeys[EMAX * W];                           // the bucket's k-mers in entry order: word i of entry e at [i * EMAX + e]
-    uint32_t jt[TSW];                                   // junction table: one slot per junction that an end of the bucket registers at (cw_jt_*)
+    uint32_t jt[TSW];                                   // junction table: one slot per junction that an end of the bucket registers at (cw_jt_*);
+                                                        // once the links are known, its memory holds the terminal ends of home entries (walk 1 work list)
     uint32_t cnt[EMAX];                                 // count | TRAV_FLAG; after walk 2: (byte offset << 1) | strand
     uint16_t lnk[2 * EMAX];                             // per end (2 * entry + end): note, then link word
     uint16_t pdesc[EMAX], pn[EMAX], pb[EMAX];           // pieces: start end (bit 15: cyclic), k-mers, relative base offset
     uint8_t vis[EMAX];                                  // bit 0 visited, bit 1 traveller, bit 2 / 3 owns the junction at the left / right end
-    uint16_t term[2 * EMAX];                            // terminal ends of home entries (walk 1 work list)
     uint32_t np, nb, nb2, nopen, nconf, lw, ncyc, pad, ncov;   // pad: number of terminals
 };
 
@@ -241,22 +241,25 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
                 }
             }
         }
-        const uint32_t l = (home ? link : LNK_DEAD) | (conf ? CWL_CONF : 0u);
-        L.lnk[it] = (uint16_t)l;
-        if (home && (l & 3u) != LNK_INTERNAL) {          // terminal end of a home entry
-            const uint32_t ti = atomic_add_u32(&L.pad, 1u);
-            L.term[ti] = (uint16_t)it;
-        }
+        L.lnk[it] = (uint16_t)((home ? link : LNK_DEAD) | (conf ? CWL_CONF : 0u));
     }
     CDBG_WAVE_SYNC();
-    for (uint32_t i = lane; i < (uint32_t)TSW; i += 64) L.jt[i] = 0u;   // the table goes back empty
+    // terminal ends of home entries: the walk-1 work list, in the memory of the junction table (dead from here on: 1 KB per wave
+    // less is a fifth more waves per CU for one-word k-mers)
+    uint16_t* const term = reinterpret_cast<uint16_t*>(L.jt);
+    for (uint32_t it = lane; it < 2 * E; it += 64) {
+        if (!(L.cnt[it >> 1] & TRAV_FLAG) && (L.lnk[it] & 3u) != LNK_INTERNAL) {
+            const uint32_t ti = atomic_add_u32(&L.pad, 1u);
+            term[ti] = (uint16_t)it;
+        }
+    }
     CDBG_WAVE_SYNC();
 
     CDBG_WPH(3);
     // ---- walk 1: every terminal end measures its piece; the smaller terminal id registers it ----
     const uint32_t nterm = uni_u32(L.pad);
     for (uint32_t ti = lane; ti < nterm; ti += 64) {
-        const uint32_t it = L.term[ti];
+        const uint32_t it = term[ti];
         uint32_t cur = it >> 1, ex = (it & 1u) ^ 1u, n = 1;
         for (;;) {
             const uint32_t l = L.lnk[cur * 2 + ex];
@@ -274,6 +277,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
         }
     }
     CDBG_WAVE_SYNC();
+    for (uint32_t i = lane; i < (uint32_t)TSW; i += 64) L.jt[i] = 0u;   // the work list is consumed: the table goes back empty, for the next bucket
     // ---- closed chains entirely inside the bucket (isolated cycles): only when the linear pieces do not cover every
     // home entry (rare).  Mark what the pieces cover, then cut each remaining cycle at its smallest entry. ----
     if (uni_u32(L.ncov) != n_home) {
@@ -416,13 +420,14 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
 // wave: queue ticket -> segment descriptor -> entries -> compaction, one bucket apart each; the entries live in two
 // register sets (ping-pong, as in k_count_fast).
 template <int W, int TSW>
-// waves per SIMD promised to the register allocator.  With the junction table (4-byte slots, no k-mer hash table) a workgroup of
-// two waves needs 18 / 11 / 15 KB of LDS (W = 1 / 2 / 4), i.e. the LDS has room for 16 / 28 / 20 waves per CU, and the kernel waits
-// on dependent LDS round trips: occupancy is what it is short of.  Left alone the compiler takes 132 / 83 / 110 VGPRs = 12 / 20 / 16
-// waves per CU.  Measured: W = 1 promised 4 (<= 128 VGPRs, 16 waves per CU) 32.2 -> 26.7 ms at config 3; W = 2 promised 6 (<= 80)
-// 49.3 -> 47.7 ms at the config-4 share; W = 4 promised 4 or 5: no change (37.7 ms).
+// waves per SIMD promised to the register allocator.  With the junction table (4-byte slots, no k-mer hash table; the walk-1
+// work list in its memory once the links are known) a workgroup of two waves needs 16 / 10 / 14 KB of LDS (W = 1 / 2 / 4), i.e. the
+// LDS has room for 20 / 32 / 22 waves per CU, and the kernel waits on dependent LDS round trips: occupancy is what it is short of.
+// Left alone the compiler takes 132 / 83 / 110 VGPRs = 12 / 20 / 16 waves per CU.  Measured: W = 1 promised 4 (16 waves per CU)
+// 32.2 -> 26.7 ms at config 3, promised 5 with the smaller LDS (92 VGPRs, 20 waves per CU) 25.8 -> 24.4 ms; W = 2 promised 6 (80
+// VGPRs, 24 waves per CU) 49.3 -> 47.7 ms at the config-4 share; W = 4 promised 4 or 5: no change (36 ms).
 #ifndef CDBG_CW_WAVES1
-#define CDBG_CW_WAVES1 4
+#define CDBG_CW_WAVES1 5
 #endif
 #ifndef CDBG_CW_WAVES2
 #define CDBG_CW_WAVES2 6
