@@ -346,8 +346,10 @@ void configure(cdbg_ctx* c, uint64_t total_bytes) {
 #define CDBG_OCC_DEN 2
 #endif
     // (four-word k-mers: at k = 127 three quarters of the k-mers of reads with 1 % errors are distinct, so a partition
-    //  must hold fewer occurrences for its distinct k-mers to fit the one-pass table)
-    const uint64_t target_occ = W >= 3 ? (uint64_t)ts * 3 / 10 : (uint64_t)ts * CDBG_OCC_NUM / CDBG_OCC_DEN;
+    //  must hold fewer occurrences for its distinct k-mers to fit the one-pass table.  0.3 tables' worth until the count
+    //  tiers learned to send a partition that will not fit straight to the bigger table; with that, twice the partition size
+    //  halves the per-partition fixed costs for less than it adds to the second tier: 316 -> 307 ms at the config-5 share)
+    const uint64_t target_occ = W >= 3 ? (uint64_t)ts * 6 / 10 : (uint64_t)ts * CDBG_OCC_NUM / CDBG_OCC_DEN;
     int log_np = c->log_np_override >= 0 ? c->log_np_override : c->prm.log2_partitions;
     if (log_np < 0) {
         log_np = 0;
