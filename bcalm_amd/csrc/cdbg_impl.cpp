@@ -746,7 +746,10 @@ int count_impl(cdbg_ctx* c) {
         CK(c->retry_list2.alloc(nretry, false));
         HIPCK(hipMemsetAsync(c->big_count.p + 2, 0, sizeof(uint32_t), s));
         CountParams c2 = cp; c2.part_list = c->retry_list.p; c2.n_items = nretry;
-        CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2, COUNT_FAST_MAX_RECORDS, 0u };
+        // (three- and four-word k-mers: the admission rule here as well -- a partition predicted beyond 0.68 of the 4096 slots goes to
+        //  the multi-pass kernel untried: count 216 -> 201 ms at the config-5 share; two-word k-mers: no difference, off)
+        CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2, COUNT_FAST_MAX_RECORDS, W >= 3 ? 175u : 0u };
+        if (const char* e = getenv("CDBG_FAST_SKIP2_Q8")) fp2.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
         // (multi-word k-mers: 1024 threads -- the table fills the CU's LDS either way, so the workgroup size IS the occupancy: 16
         //  waves per CU instead of 8, second tier 81 -> 67 ms at the config-5 share, 24 -> 18 at the config-4 share)
 #ifndef CDBG_NT_TIER2
