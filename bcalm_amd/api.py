@@ -41,7 +41,7 @@ class Stats(C.Structure):
 
 EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
            "cdbg_generate_reads", "cdbg_expect_input", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
-           "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats", "cdbg_digest",
+           "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats", "cdbg_digest", "cdbg_verify",
            "cdbg_fetch_unitigs_packed", "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", 
            "cdbg_set_transport", "cdbg_comm_unique_id", "cdbg_comm_init_rccl", "cdbg_comm_bytes"]
 
@@ -90,6 +90,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_fetch_unitigs_packed.argtypes = [vp, C.POINTER(C.c_uint8), u64, C.POINTER(u64), C.POINTER(C.c_uint32), C.POINTER(u64)]
     lib.cdbg_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.cdbg_digest.argtypes = [vp, C.POINTER(u64)]
+    lib.cdbg_verify.argtypes = [vp, C.POINTER(u64)]
     lib.cdbg_fetch_unitig_abundances.argtypes = [vp, u64, u64, C.POINTER(C.c_uint32), C.POINTER(u64)]
     lib.cdbg_link.argtypes = [vp]
     lib.cdbg_num_links.argtypes = [vp, C.POINTER(u64)]
@@ -239,6 +240,16 @@ class Graph:
         out = (C.c_uint64 * 4)()
         self._ck(self.lib.cdbg_digest(self._h, out))
         return {"kc_sum": out[0], "solid_count_sum": out[1], "set_digest": out[2], "kmers_in_unitigs": out[3]}
+
+    def verify(self):
+        """the unitig definition checked on the device, without the oracle (cdbg_verify, bcalm_amd/csrc/k_verify.h):
+        k-mer multiset of the unitigs == solid set (counts + two commutative sums), and no pair of unitig ends that are each
+        other's only link (maximality).  mergeable_ends is None on a rank that holds a share of the unitigs."""
+        out = (C.c_uint64 * 8)()
+        self._ck(self.lib.cdbg_verify(self._h, out))
+        none = 0xFFFFFFFFFFFFFFFF
+        return {"unitig_kmers": (out[0], out[1], out[2]), "solid_kmers": (out[3], out[4], out[5]),
+                "mergeable_ends": None if out[6] == none else out[6], "closed_chains": None if out[7] == none else out[7]}
 
     def solid_kmers(self):
         n = C.c_uint64()

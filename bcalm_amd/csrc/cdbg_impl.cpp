@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "k_links.h"
+#include "k_verify.h"
 #include "k_dglue.h"
 #include "comm.h"
 #include "k_count_fast.h"
@@ -211,6 +212,7 @@ struct cdbg_ctx {
     DBuf<uint4> rank_a, rank_b; DBuf<uint32_t> rank_flag;
     // multi-GPU: transport (RCCL or caller-supplied) and the record exchange buffers
     cdbg_transport tr{}; bool have_tr = false; uint64_t comm_bytes = 0;
+    bool tr_ordered = false;                             // the transport enqueues on the context's stream (built-in RCCL): no host sync around a device-buffer collective
     bool force_multi = false;                            // CDBG_FORCE_MULTI: run the multi-rank code path with one rank (tests)
 #ifndef CDBG_HOSTSIM
     RcclComm* rccl = nullptr;
@@ -491,21 +493,23 @@ int count_impl(cdbg_ctx* c) {
     const bool multi_ctx = c->prm.world_size > 1 || c->force_multi;
     const int world = c->prm.world_size;
     if (multi_ctx && !c->have_tr) return fail(CDBG_E_STATE, "world_size %d but no transport: call cdbg_comm_init_rccl or cdbg_set_transport first", world);
-    {
-        int rc = upload_pending(c);
-        if (rc == CDBG_OK && (!c->reads.p || (c->nbytes == 0 && !multi_ctx))) rc = fail(CDBG_E_STATE, "no reads: call cdbg_push_reads/cdbg_push_text/cdbg_generate_reads first");
-        CK(agree(c, rc, "count: input"));
-    }
+    int rc_in = upload_pending(c);
+    if (rc_in == CDBG_OK && (!c->reads.p || (c->nbytes == 0 && !multi_ctx))) rc_in = fail(CDBG_E_STATE, "no reads: call cdbg_push_reads/cdbg_push_text/cdbg_generate_reads first");
+    if (!multi_ctx) CK(rc_in);
     // multi-GPU, reads SHARDED over the ranks (X1): the scan fills the partitions of every rank and the records travel to
     // their owners; every rank must choose the same partitioning, so the input volume that drives configure() is the sum
     // over the ranks.  Reads REPLICATED (X0): every rank scans the whole text for its own partitions, nothing travels.
     const bool multi = multi_ctx && !c->prm.reads_replicated;
     uint64_t total_bytes = c->nbytes;
     if (multi_ctx) {
-        std::vector<uint64_t> all(world); const uint64_t mine = c->nbytes;
-        if (c->tr.all_gather_u64(c->tr.user, &mine, all.data(), 1) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
-        if (multi) { total_bytes = 0; for (uint64_t v : all) total_bytes += v; }
-        else for (uint64_t v : all) if (v != mine) return fail(CDBG_E_PARAM, "reads_replicated: the ranks hold different texts (%llu vs %llu bytes)", (unsigned long long)mine, (unsigned long long)v);
+        // one small all-gather: every rank's input status (a rank-local failure stops all ranks together) and byte count
+        const std::string mine_err = rc_in != CDBG_OK ? g_err : std::string();
+        std::vector<uint64_t> all(2 * (size_t)world); const uint64_t mine[2] = { (uint64_t)(int64_t)rc_in, c->nbytes };
+        if (c->tr.all_gather_u64(c->tr.user, mine, all.data(), 2) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
+        if (rc_in != CDBG_OK) { g_err = mine_err; return rc_in; }
+        for (int r = 0; r < world; ++r) if (all[2 * r]) return fail(CDBG_E_INTERNAL, "count: input: rank %d reported error %lld; all ranks stop", r, (long long)(int64_t)all[2 * r]);
+        if (multi) { total_bytes = 0; for (int r = 0; r < world; ++r) total_bytes += all[2 * r + 1]; }
+        else for (int r = 0; r < world; ++r) if (all[2 * r + 1] != mine[1]) return fail(CDBG_E_PARAM, "reads_replicated: the ranks hold different texts (%llu vs %llu bytes)", (unsigned long long)mine[1], (unsigned long long)all[2 * r + 1]);
         if (total_bytes == 0) return fail(CDBG_E_STATE, "no reads on any rank");
     }
     if (!c->ss_on) configure(c, total_bytes);             // (a streaming scan fixed the partitioning from the announced volume)
@@ -575,8 +579,8 @@ int count_impl(cdbg_ctx* c) {
             if ((double)part_cap * (double)NPS * RW * 8.0 > 200e9) fits = false;       // would not fit: use the exact layout
             // (at least 32 sampled records in that partition: with a mean of a few records per partition -- long reads, k = 127 --
             //  the sampled maximum is Poisson noise, and scaling it up sent the config-5 share through two passes: 598 -> 662 ms)
-            if (sample_max >= 32 && (double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && getenv("CDBG_SCAN_MODE") == nullptr) fits = false;
-            else {
+            else if (sample_max >= 32 && (double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && getenv("CDBG_SCAN_MODE") == nullptr) fits = false;
+            if (fits) {
                 if (c->xrecs.cap > c->records.cap) c->records.swap(c->xrecs);   // (sharded reads: the previous step left the region buffer there)
                 CK(c->records.alloc((uint64_t)part_cap * NPS * RW, false));
                 CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
@@ -660,7 +664,7 @@ int count_impl(cdbg_ctx* c) {
         std::vector<uint64_t> so(world), sc(world), ro(world), rc(world);
         // per-partition counts first (equal blocks of NPL counts)
         for (int r = 0; r < world; ++r) { so[r] = (uint64_t)r * NPL * 4; sc[r] = NPL * 4; ro[r] = so[r]; rc[r] = sc[r]; }
-        HIPCK(hipStreamSynchronize(s));
+        if (!c->tr_ordered) HIPCK(hipStreamSynchronize(s));
         if (c->tr.all_to_all_v(c->tr.user, c->part_count.p, so.data(), sc.data(), c->xcnt.p, ro.data(), rc.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_to_all_v (counts) failed");
         c->comm_bytes += 2 * (uint64_t)(world - 1) * NPL * 4;
         // where the records of sender s start inside its block, per partition; block sizes
@@ -728,9 +732,9 @@ int count_impl(cdbg_ctx* c) {
     // the retry list and go through the multi-pass kernel
     {
         // (admission by predicted fill: k_count_fast.h; one-word k-mers: off -- their second tier runs one workgroup per CU against three)
-        CountFastParams fp{ cp, c->retry_list.p, c->big_count.p + 1, COUNT_FAST_MAX_RECORDS, W == 1 ? 0u : W == 2 ? 177u : 200u };
+        CountFastParams fp{ cp, c->retry_list.p, c->big_count.p + 1, count_fast_record_limit<W>(c->k), W == 1 ? 0u : W == 2 ? 177u : 200u };
         if (const char* e = getenv("CDBG_FAST_SKIP_Q8")) fp.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
-        if (const char* e = getenv("CDBG_FAST_MAX_RECORDS")) fp.fast_max_records = std::min<uint32_t>(COUNT_FAST_MAX_RECORDS, (uint32_t)std::max(1, atoi(e)));   // dev knob
+        if (const char* e = getenv("CDBG_FAST_MAX_RECORDS")) fp.fast_max_records = std::min<uint32_t>(count_fast_record_limit<W>(c->k), (uint32_t)std::max(1, atoi(e)));   // dev knob
         if (capped) CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, true>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, fp);
         else CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, fp);
     }
@@ -748,7 +752,7 @@ int count_impl(cdbg_ctx* c) {
         CountParams c2 = cp; c2.part_list = c->retry_list.p; c2.n_items = nretry;
         // (three- and four-word k-mers: the admission rule here as well -- a partition predicted beyond 0.68 of the 4096 slots goes to
         //  the multi-pass kernel untried: count 216 -> 201 ms at the config-5 share; two-word k-mers: no difference, off)
-        CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2, COUNT_FAST_MAX_RECORDS, W >= 3 ? 175u : 0u };
+        CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2, count_fast_record_limit<W>(c->k), W >= 3 ? 175u : 0u };
         if (const char* e = getenv("CDBG_FAST_SKIP2_Q8")) fp2.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
         // (multi-word k-mers: 1024 threads -- the table fills the CU's LDS either way, so the workgroup size IS the occupancy: 16
         //  waves per CU instead of 8, second tier 81 -> 67 ms at the config-5 share, 24 -> 18 at the config-4 share)
@@ -1304,7 +1308,9 @@ int pack_unitigs(cdbg_ctx* c) {
 constexpr int DG_FALLBACK = 1;
 struct DgRoute { std::vector<uint64_t> scnt, soff, rcnt, roff, all; uint64_t n_send = 0, n_recv = 0, n_all = 0; };
 // positions of the n items whose destinations are in c->dg_dest: send-block counts / offsets, receive counts / offsets
-int dg_route(cdbg_ctx* c, uint64_t n, DgRoute& R) {
+// (extra: n_extra more words of this rank ride in the same small all-gather -- extra_all[r * n_extra + i] = word i of rank r: the
+//  piece counts and the status words that used to cost a host-synchronous collective of their own)
+int dg_route(cdbg_ctx* c, uint64_t n, DgRoute& R, const uint64_t* extra = nullptr, int n_extra = 0, std::vector<uint64_t>* extra_all = nullptr) {
     const int world = c->prm.world_size, me = c->prm.rank; hipStream_t s = c->stream;
     CK(c->dg_cnt.alloc(3 * DG_MAX_WORLD, true)); CK(c->dg_pos.alloc(n, false));
     RouteParams rp{ n, c->dg_dest.p, c->dg_cnt.p, c->dg_cnt.p + DG_MAX_WORLD, c->dg_cnt.p + 2 * DG_MAX_WORLD, c->dg_pos.p, world };
@@ -1315,7 +1321,17 @@ int dg_route(cdbg_ctx* c, uint64_t n, DgRoute& R) {
     R.n_send = R.soff[world];
     HIPCK(hipMemcpy(c->dg_cnt.p + DG_MAX_WORLD, R.soff.data(), world * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (n) CDBG_LAUNCH(k_route_place, std::min<uint64_t>((n + DG_THREADS * DG_ITEMS - 1) / (DG_THREADS * DG_ITEMS), 256 * 8), DG_THREADS, s, rp);
-    if (c->tr.all_gather_u64(c->tr.user, R.scnt.data(), R.all.data(), world) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
+    {
+        const int row = world + n_extra;
+        std::vector<uint64_t> mine(row), got((size_t)row * world);
+        for (int d = 0; d < world; ++d) mine[d] = R.scnt[d];
+        for (int i = 0; i < n_extra; ++i) mine[world + i] = extra[i];
+        if (c->tr.all_gather_u64(c->tr.user, mine.data(), got.data(), row) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
+        for (int r = 0; r < world; ++r) {
+            for (int d = 0; d < world; ++d) R.all[(size_t)r * world + d] = got[(size_t)r * row + d];
+            if (extra_all) for (int i = 0; i < n_extra; ++i) (*extra_all)[(size_t)r * n_extra + i] = got[(size_t)r * row + world + i];
+        }
+    }
     R.n_all = 0;
     for (int r = 0; r < world; ++r) { R.rcnt[r] = R.all[(size_t)r * world + me]; for (int d = 0; d < world; ++d) R.n_all += R.all[(size_t)r * world + d]; }
     for (int r = 0; r < world; ++r) R.roff[r + 1] = R.roff[r] + R.rcnt[r];
@@ -1332,7 +1348,7 @@ int dg_a2a(cdbg_ctx* c, const void* send, void* recv, const DgRoute& R, uint64_t
         so[r] = sof[r] * item; sc[r] = scn[r] * item; ro[r] = rof[r] * item; rc[r] = rcn[r] * item;
         if (r != me) c->comm_bytes += sc[r] + rc[r];
     }
-    HIPCK(hipStreamSynchronize(c->stream));
+    if (!c->tr_ordered) HIPCK(hipStreamSynchronize(c->stream));   // (a caller-supplied transport reads the buffers from the host side)
     if (c->tr.all_to_all_v(c->tr.user, send, so.data(), sc.data(), recv, ro.data(), rc.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_to_all_v failed");
     return CDBG_OK;
 }
@@ -1345,7 +1361,7 @@ int dg_a2a_blocks(cdbg_ctx* c, const void* send, const std::vector<uint64_t>& se
     recv_off.assign(world + 1, 0); recv_bytes.assign(world, 0);
     for (int r = 0; r < world; ++r) { recv_bytes[r] = all[(size_t)r * world + me]; recv_off[r + 1] = recv_off[r] + (recv_bytes[r] + align - 1) / align * align; if (r != me) c->comm_bytes += send_bytes[r] + recv_bytes[r]; }
     CK(recv.alloc(recv_off[world] + align, false));
-    HIPCK(hipStreamSynchronize(c->stream));
+    if (!c->tr_ordered) HIPCK(hipStreamSynchronize(c->stream));   // (a caller-supplied transport reads the buffers from the host side)
     if (c->tr.all_to_all_v(c->tr.user, send, send_off.data(), send_bytes.data(), recv.p, recv_off.data(), recv_bytes.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_to_all_v failed");
     return CDBG_OK;
 }
@@ -1358,33 +1374,31 @@ int glue_sharded(cdbg_ctx* c) {
     Timer t; CK(t.start(s));
     const uint64_t NP = c->n_pieces;
     auto grid = [](uint64_t n) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>((n + 255) / 256, 1), 256 * 16); };
-    // ---- piece id ranges ----
     DgOwners own{}; own.world = world;
-    {
-        std::vector<uint64_t> all(world);
-        if (c->tr.all_gather_u64(c->tr.user, &NP, all.data(), 1) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
-        uint64_t tot = 0; for (int r = 0; r < world; ++r) { own.b[r] = (uint32_t)tot; tot += all[r]; }
-        if (2 * tot >= 0x7FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 31-bit end ids (%llu): use more partitions per GPU or fewer reads", (unsigned long long)tot);
-        own.b[world] = (uint32_t)tot; c->piece_lo = own.b[me]; c->piece_hi = own.b[me + 1];
-    }
-    const uint32_t end_base = 2u * own.b[me]; const uint32_t NSl = (uint32_t)(2 * NP);
+    const uint32_t NSl = (uint32_t)(2 * NP);
+    uint32_t end_base = 0;
     HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
     HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
-    // ---- 1a. junction records to their key owners ----
+    // ---- 1a. junction records to their key owners (the piece id ranges of the ranks ride in the routing's count exchange) ----
     DgRoute R;
     {
         const uint64_t n = c->n_glog;
         CK(c->dg_dest.alloc(std::max<uint64_t>(std::max<uint64_t>(n, NSl), NP) + 1, false));
-        LogRouteParams lp{ c->glog_keys.p, c->glog_tag.p, n, world, end_base, c->dg_dest.p, nullptr, nullptr };
+        LogRouteParams lp{ c->glog_keys.p, c->glog_tag.p, n, world, 0, c->dg_dest.p, nullptr, nullptr };
         if (n) CDBG_LAUNCH((k_log_dest<W>), grid(n), 256, s, lp);
-        CK(dg_route(c, n, R));
+        std::vector<uint64_t> all(world);
+        CK(dg_route(c, n, R, &NP, 1, &all));
+        uint64_t tot = 0; for (int r = 0; r < world; ++r) { own.b[r] = (uint32_t)tot; tot += all[r]; }
+        if (2 * tot >= 0x7FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 31-bit end ids (%llu): use more partitions per GPU or fewer reads", (unsigned long long)tot);   // (every rank sees the same total)
+        own.b[world] = (uint32_t)tot; c->piece_lo = own.b[me]; c->piece_hi = own.b[me + 1];
+        end_base = 2u * own.b[me]; lp.end_base = end_base;
         CK(c->dg_wire_s.alloc(R.n_send * (W + 1) + 1, false)); CK(c->dg_wire_r.alloc(R.n_recv * (W + 1) + 1, false));
         lp.pos = c->dg_pos.p; lp.wire = c->dg_wire_s.p;
         if (n) CDBG_LAUNCH((k_log_write<W>), grid(n), 256, s, lp);
         CK(dg_a2a(c, c->dg_wire_s.p, c->dg_wire_r.p, R, (uint64_t)(W + 1) * 8));
     }
     // ---- join this rank's keys; joined pairs to the end owners ----
-    uint64_t n_pairs = 0;
+    uint64_t n_pairs = 0; uint32_t join_err = 0;
     {
         const uint64_t n = R.n_recv;
         int log_jb = 0; while (((uint64_t)(JB_CAP / 2) << log_jb) < n && log_jb < 26) ++log_jb;
@@ -1395,22 +1409,32 @@ int glue_sharded(cdbg_ctx* c) {
         WireScatterParams wp{ c->dg_wire_r.p, n, log_jb, c->jfill.p, c->jrecs.p, c->derr.p };
         if (n) CDBG_LAUNCH((k_join_scatter_wire<W>), grid(n), 256, s, wp);
         // (pair list: <= n entries used, in per-wave chunks whose tails stay unused -- pre-filled with the 'no pair' marker)
-        const uint64_t pair_cap = n + 2 + (uint64_t)JB_PAIR_CHUNK * std::min<uint64_t>((JB + 3) / 4, 256 * 16) * (JB_THREADS / 64);
+        // (+ n / 8: a wave also abandons the rest of its current chunk whenever a bucket's pairs do not fit into it)
+        const uint64_t pair_cap = n + n / 8 + 2 + (uint64_t)JB_PAIR_CHUNK * std::min<uint64_t>((JB + 3) / 4, 256 * 16) * (JB_THREADS / 64);
         CK(c->dg_pairs.alloc(pair_cap, false));
         HIPCK(hipMemsetAsync(c->dg_pairs.p, 0xFF, pair_cap * sizeof(uint2), s));
         JoinBucketParams bp{ c->jfill.p, c->jrecs.p, (uint32_t)JB, nullptr, c->dstats.p, c->dg_pairs.p, c->cursors.p + 7, pair_cap, c->derr.p };
         CDBG_LAUNCH((k_join_bucket<W>), std::min<uint64_t>((JB + 3) / 4, 256 * 16), JB_THREADS, s, bp);
-        HIPCK(hipStreamSynchronize(s));
-        uint32_t e = 0; CK(read_u32(c->derr.p, &e));
-        CK(agree(c, e ? fail(CDBG_E_INTERNAL, "sharded junction join: device error %u (8 bucket overflow, 9 pair list overflow)", e) : CDBG_OK, "glue: join"));
+        CK(read_u32(c->derr.p, &join_err));
         CK(read_u64(c->cursors.p + 7, &n_pairs));
+        if (join_err || n_pairs > pair_cap) n_pairs = 0;     // (nothing of a failed join travels; the ranks agree on what happens below)
         uint64_t gs = 0; CK(read_u64(c->dstats.p, &gs)); c->n_join_local = gs;
     }
     {
         PairRouteParams pp{ c->dg_pairs.p, n_pairs, own, c->dg_dest.p, nullptr, nullptr };
         CK(c->dg_dest.alloc(std::max<uint64_t>(std::max<uint64_t>(n_pairs, NSl), NP) + 1, false)); pp.dest = c->dg_dest.p;
         if (n_pairs) CDBG_LAUNCH(k_pair_dest, grid(n_pairs), 256, s, pp);
-        CK(dg_route(c, n_pairs, R));
+        // the status of every rank's join rides in the routing's count exchange: a bucket overflow (8) stops all ranks together, a
+        // pair list that did not fit (9: nearly every record joined and the chunk tails ate the headroom) sends all of them to
+        // the replicated exchange
+        const uint64_t stw = join_err; std::vector<uint64_t> sts(world);
+        CK(dg_route(c, n_pairs, R, &stw, 1, &sts));
+        bool any9 = false;
+        for (int r = 0; r < world; ++r) {
+            if (sts[r] == 9) any9 = true;
+            else if (sts[r]) return fail(CDBG_E_INTERNAL, "sharded junction join: rank %d reported device error %llu (8 bucket overflow); all ranks stop", r, (unsigned long long)sts[r]);
+        }
+        if (any9) { HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s)); float ms = 0; CK(t.stop(&ms)); c->st.ms_exchange += ms; return DG_FALLBACK; }
         CK(c->dg_pair_s.alloc(R.n_send + 1, false)); CK(c->dg_pair_r.alloc(R.n_recv + 1, false));
         pp.pos = c->dg_pos.p; pp.wire = c->dg_pair_s.p;
         if (n_pairs) CDBG_LAUNCH(k_pair_write, grid(n_pairs), 256, s, pp);
@@ -1719,6 +1743,25 @@ int link_impl(cdbg_ctx* c) {
     return CDBG_OK;
 }
 
+// the unitig definition checked on the resident result (k_verify.h)
+template <int W>
+int verify_impl(cdbg_ctx* c, uint64_t* out) {
+    if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_verify before cdbg_glue");
+    hipStream_t s = c->stream;
+    const bool sharded_set = (c->prm.world_size > 1 || c->force_multi) && !c->prm.emit_replicated;   // this rank holds a share of the unitigs: no links
+    if (!sharded_set && !c->linked) CK(link_impl<W>(c));
+    DBuf<uint64_t> d; CK(d.alloc(8, true));
+    VerifyParams vp{ c->n_unitigs, c->k, c->unitig_off.p, c->unitig_len.p, c->unitig_bases.p,
+                     c->seg_off.p, c->seg_n.p, c->solid_keys.p, c->solid_cnt.p, c->n_local_parts, c->link_off.p, c->link_to.p, d.p };
+    if (c->n_unitigs) CDBG_LAUNCH((k_verify_unitig_kmers<W>), std::min<uint64_t>((c->n_unitigs + 255) / 256, 1u << 16), 256, s, vp);
+    CDBG_LAUNCH((k_verify_solid<W>), std::min<uint64_t>((c->n_local_parts + 255) / 256, 1u << 16), 256, s, vp);
+    if (!sharded_set && c->n_unitigs) CDBG_LAUNCH(k_verify_maximal, (2 * c->n_unitigs + 255) / 256, 256, s, vp);
+    HIPCK(hipStreamSynchronize(s));
+    CK(read_u64(d.p, out, 8));
+    if (sharded_set) out[6] = out[7] = ~0ull;
+    return CDBG_OK;
+}
+
 }  // namespace
 
 // =======================================================================================
@@ -1982,7 +2025,7 @@ int cdbg_fetch_unitig_abundances(cdbg_ctx* c, uint64_t first, uint64_t n, uint32
 int cdbg_set_transport(cdbg_ctx* c, const cdbg_transport* t) {
     if (!c || !t || !t->all_gather_u64 || !t->all_to_all_v || !t->all_gather_v || !t->all_reduce_max_i32) return fail(CDBG_E_PARAM, "null transport");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    c->tr = *t; c->have_tr = true; c->force_multi = getenv("CDBG_FORCE_MULTI") != nullptr; return CDBG_OK;
+    c->tr = *t; c->have_tr = true; c->tr_ordered = false; c->force_multi = getenv("CDBG_FORCE_MULTI") != nullptr; return CDBG_OK;
 }
 int cdbg_comm_unique_id(void* out) {
     if (!out) return fail(CDBG_E_PARAM, "null argument");
@@ -2005,7 +2048,7 @@ int cdbg_comm_init_rccl(cdbg_ctx* c, const void* uid) {
     if (c->rccl) { c->rccl->destroy(); delete c->rccl; c->rccl = nullptr; }
     c->rccl = new RcclComm();
     if (!c->rccl->init(uid, c->prm.world_size, c->prm.rank, c->stream)) { const std::string e = c->rccl->err; c->rccl->destroy(); delete c->rccl; c->rccl = nullptr; return fail(CDBG_E_NODEVICE, "RCCL: %s", e.c_str()); }
-    c->tr = c->rccl->transport(); c->have_tr = true; c->force_multi = getenv("CDBG_FORCE_MULTI") != nullptr;
+    c->tr = c->rccl->transport(); c->have_tr = true; c->tr_ordered = true; c->force_multi = getenv("CDBG_FORCE_MULTI") != nullptr;
     return CDBG_OK;
 #endif
 }
@@ -2022,6 +2065,11 @@ int cdbg_digest(cdbg_ctx* c, uint64_t out[4]) {
     HIPCK(hipStreamSynchronize(c->stream));
     CK(read_u64(d.p, out, 4));
     return CDBG_OK;
+}
+int cdbg_verify(cdbg_ctx* c, uint64_t out[8]) {
+    if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);
+    switch (c->W) { case 1: return verify_impl<1>(c, out); case 2: return verify_impl<2>(c, out); case 3: return verify_impl<3>(c, out); default: return verify_impl<4>(c, out); }
 }
 int cdbg_stats(cdbg_ctx* c, cdbg_stats_t* out) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");

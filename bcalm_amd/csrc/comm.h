@@ -5,7 +5,9 @@
 // point (a dedicated link per GPU pair), so the all-to-all-v and the variable-size all-gather are one grouped
 // ncclSend / ncclRecv per peer -- link-parallel, no ring.  RCCL is bound at run time (dlopen of librccl.so.1:
 // a process that already carries PyTorch's copy gets that one), so the library has no link-time dependency and
-// the CPU simulator build has none at all.
+// the CPU simulator build has none at all.  The device-buffer collectives are STREAM-ORDERED on the context's stream:
+// no host synchronisation before or after them (the library skips its own as well: cdbg_ctx::tr_ordered); only the small
+// host-side all-gather of counts returns values to the host and waits.
 #pragma once
 #include "../../include/cdbg.h"
 
@@ -84,7 +86,7 @@ struct RcclComm {
         if (!good) { (void)A.GroupEnd(); return -1; }    // never leave the group open
         if (!c->ok(A.GroupEnd(), "ncclGroupEnd")) return -1;
         if (scnt[c->rank] && !c->hip_ok(hipMemcpyAsync((char*)recv + roff[c->rank], (const char*)send + soff[c->rank], scnt[c->rank], hipMemcpyDeviceToDevice, c->stream), "D2D")) return -1;
-        return c->hip_ok(hipStreamSynchronize(c->stream), "sync") ? 0 : -1;
+        return 0;                                        // (stream-ordered: what consumes the bytes is enqueued on the same stream)
     }
     static int all_gather_v(void* u, const void* send, uint64_t nbytes, void* recv, const uint64_t* roff, const uint64_t* rcnt) {
         RcclComm* c = (RcclComm*)u; RcclApi& A = rccl_api();
@@ -98,12 +100,12 @@ struct RcclComm {
         if (!good) { (void)A.GroupEnd(); return -1; }
         if (!c->ok(A.GroupEnd(), "ncclGroupEnd")) return -1;
         if (nbytes && !c->hip_ok(hipMemcpyAsync((char*)recv + roff[c->rank], send, nbytes, hipMemcpyDeviceToDevice, c->stream), "D2D")) return -1;
-        return c->hip_ok(hipStreamSynchronize(c->stream), "sync") ? 0 : -1;
+        return 0;
     }
     static int all_reduce_max_i32(void* u, void* dev, uint64_t n) {
         RcclComm* c = (RcclComm*)u; RcclApi& A = rccl_api();
         if (n && !c->ok(A.AllReduce(dev, dev, n, 2 /* ncclInt32 */, 2 /* ncclMax */, c->comm, c->stream), "ncclAllReduce")) return -1;
-        return c->hip_ok(hipStreamSynchronize(c->stream), "sync") ? 0 : -1;
+        return 0;
     }
     bool init(const void* uid, int world_, int rank_, hipStream_t s) {
         RcclApi& A = rccl_api();

@@ -31,6 +31,23 @@ namespace cdbg {
 #endif
 // records per wave batch (W >= 3: CDBG_CB_WIDE -- records of up to 122-153 members fill the 64-lane steps with far fewer of them)
 template <int W> struct CountCb { static constexpr int V = W >= 3 ? CDBG_CB_WIDE : 16; };
+// Used-slot list (one-word k-mers).  The sweep of a 4096-slot table for the ~960 keys of a config-3 partition was 19 of the
+// kernel's 67 ms.  Every wave now notes the slots its own lanes claimed and sweeps exactly those.  The list costs no LDS: a
+// count word holds the count in its LOWER half (15 bits + the traveller flag; a partition of the one-pass kernel cannot
+// carry a count beyond that: count_fast_record_limit) and, in its UPPER half, one list entry -- the wave's j-th new slot
+// lives in the upper half of word wave * (TS / waves) + j, written and read as 16 bits.  The halves never interfere: the
+// count atomics (ds_add_u32 / ds_or_b32 on the whole word) never carry out of bit 15, and an LDS bank executes a word's
+// atomic and a half-word write one after the other.  Upper halves are never cleared: entries beyond a wave's count are not
+// read.  A wave that claims more than its TS / waves entries flags the partition for the next tier (at three quarters of
+// the slots the partition is refused anyway).  Multi-word k-mers keep the full sweep: 4 slots per thread there.
+template <int W> struct CountList { static constexpr bool ON = W == 1; };
+constexpr uint32_t CF_TRAV16 = 0x8000u;                  // the traveller flag in a 16-bit count
+// (host) partitions of at least this many records are not tried by the one-pass kernel: a k-mer occurs at most once per member
+// position, so below it no count reaches 2^15 (CountList) / the saturation threshold of the 31-bit counts
+template <int W> inline uint32_t count_fast_record_limit(int k) {
+    if (!CountList<W>::ON) return COUNT_FAST_MAX_RECORDS;
+    return 0x7FFFu / (uint32_t)(RecFmt<W>::CAPB - k + 1) + 1u;
+}
 template <int W> struct CountGeom {
     // member positions of one batch: COUNT_CB records of at most CAPB - k + 1 members, k >= 3 (W = 1), 32, 64, 96
     static constexpr int KMIN = W == 1 ? 3 : 32 * (W - 1);
@@ -180,6 +197,8 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
     uint64_t w0, w1; count_share<W, NW>(rg, wave, w0, w1);
     CDBG_FPH(0);
     uint32_t n_new = 0;                                                       // wave-uniform: keys this wave added
+    constexpr uint32_t LCAP = (uint32_t)(TS / NW);                             // list entries of a wave (CountList)
+    const uint32_t lbase = (uint32_t)wave * LCAP;
     RecView<W> R = A.cur->R;
     for (uint64_t c0 = w0; c0 < w1; c0 += 64) {                               // wave-uniform
         if (c0 != w0) count_load_chunk<W>(P, c0, w1, lane, R);                 // (the first 64 records came prefetched)
@@ -224,6 +243,7 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
                 const uint64_t M = uni_u64(smask[g0 >> 6]), E = uni_u64(emask[g0 >> 6]);   // (scalar: used as lane predicates below)
                 const uint32_t g = g0 + (uint32_t)lane;
                 const bool active = g < total;
+                uint32_t slot_new = 0;
                 const uint32_t slot = started + (uint32_t)__popcll(M & lane_le) - 1u;   // active lanes: >= 0 (member 0 starts record 0)
                 started += (uint32_t)__popcll(M);
                 bool is_new = false;
@@ -309,10 +329,17 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
                     if (!hit) L.over = 1;                                      // table (nearly) full: not a one-pass partition
                     else {
                         atomic_add_u32(&L.cnt[s], 1u);
-                        if (trav) atomic_or_u32(&L.cnt[s], TRAV_FLAG);
+                        if (trav) atomic_or_u32(&L.cnt[s], CountList<W>::ON ? CF_TRAV16 : TRAV_FLAG);
                     }
+                    if (CountList<W>::ON) slot_new = s;
                 }
-                n_new += (uint32_t)__popcll(__ballot(is_new));
+                const uint64_t nb = __ballot(is_new);
+                if (CountList<W>::ON) {
+                    // used-slot list: the wave's j-th new key leaves its slot in the upper half of count word wave * LCAP + j
+                    const uint32_t pos = n_new + (uint32_t)__popcll(nb & (lane_le >> 1));
+                    if (is_new && pos < LCAP) reinterpret_cast<uint16_t*>(L.cnt)[2u * (lbase + pos) + 1u] = (uint16_t)slot_new;
+                }
+                n_new += (uint32_t)__popcll(nb);
             }
             CDBG_WAVE_SYNC();                                                  // every lane has read the stage and the mask
             if (lane < MASKW && lane <= (int)((total + 63) >> 6)) { smask[lane] = 0; emask[lane] = 0; }   // hand the masks back clean
@@ -321,6 +348,7 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
     }
     if (!A.issued) count_issue_ahead<W, NW, CAPPED>(P, A, wave, lane);                // (a wave without records of this partition)
     if (lane == 0 && n_new) atomic_add_u32(&L.fill[par], n_new);
+    if (CountList<W>::ON && n_new > LCAP && lane == 0) L.over = 1;             // (more new keys than the wave's list holds: next tier)
     CDBG_FPH(2);
     CDBG_LDS_BARRIER();                                                           // ---- barrier A: all inserts done ----
     CDBG_FPH(3);
@@ -335,6 +363,33 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
     const uint64_t obase = chunk_base;
     const bool wr_ok = obase + need <= P.solid_cap;
     if (!wr_ok && tid == 0) *P.error = 1;
+    if constexpr (CountList<W>::ON) {
+        // sweep of the used slots only: every wave walks the list of the slots it claimed, 64 per round
+        uint16_t* const h16 = reinterpret_cast<uint16_t*>(L.cnt);
+        for (uint32_t j0 = 0; j0 < n_new; j0 += 64u) {                        // wave-uniform
+            const uint32_t j = j0 + (uint32_t)lane;
+            const bool valid = j < n_new;
+            const uint32_t sl = valid ? (uint32_t)h16[2u * (lbase + j) + 1u] : 0u;
+            const uint64_t key = L.keys[sl];
+            const uint32_t cv = h16[2u * sl];
+            const uint32_t cn = cv & ~CF_TRAV16; const bool trav = cv & CF_TRAV16;
+            if (valid && !trav) { ++acc.dist; acc.occ += cn; }
+            const bool solid = valid && cn >= P.amin;
+            if (solid) { if (trav) ++acc.st; else ++acc.sh; }
+            const uint64_t sb = __ballot(solid);
+            uint32_t wbase = 0;
+            if (sb) {                                                          // uniform
+                if (lane == 0) wbase = atomic_add_u32(&L.wr[par], (uint32_t)__popcll(sb));
+                wbase = wave_readlane_u32(wbase, 0);
+            }
+            if (solid && wr_ok) {
+                const uint64_t o = obase + wbase + (uint32_t)__popcll(sb & (lane_le >> 1));
+                P.solid_keys[o] = key;
+                P.solid_cnt[o] = cn | (trav ? TRAV_FLAG : 0u);
+            }
+            if (valid) { L.keys[sl] = KEY_EMPTY; h16[2u * sl] = 0; }
+        }
+    } else
     // sweep: statistics, solid entries out, slots back to EMPTY.  Every thread owns TS / NT slots; all of their LDS reads
     // are issued first (one wait), the wave's solid entries get their places from ONE returning LDS atomic.
     {

@@ -1,9 +1,13 @@
 """Multi-GPU set-up: one process per GPU.
 
-The data path lives in libcdbg.so (include/cdbg.h, "Multi-GPU"): a context with world_size > 1 shards
-the reads over the ranks, all-to-all-v's the super-k-mer records to the partition owners, all-gathers
-the pieces + junction log, joins the junctions sharded by key hash, and every rank emits the unitigs
-whose first piece it owns.  The bytes move through the context's TRANSPORT:
+The data path lives in libcdbg.so (include/cdbg.h, "Multi-GPU"): a context with world_size > 1 owns
+the minimizer partitions p with p % world == rank.  Reads are either replicated (X0: every rank scans all reads for its own
+partitions, nothing travels) or sharded (X1: one all-to-all-v of super-k-mer records to the partition owners).  The glue is
+sharded by owner: junction records travel once to the rank their key hashes to, joined pairs once to the owner of the end,
+list ranking runs where the pieces live with one query / reply all-to-all-v per round, and every piece travels once to the
+owner of its unitig's head -- each rank ends with the unitigs it owns, their union is the graph.  (emit_replicated = 1, or
+closed chains that cross ranks: the replicated exchange -- pieces + junction log all-gathered, every rank ends with the
+complete set.)  The bytes move through the context's TRANSPORT:
 
   * `init_rccl(graph, dist)`      the product path: RCCL inside libcdbg.so (ncclSend/ncclRecv all-to-all-v,
                                   ncclAllGather, ncclAllReduce over xGMI).  torch.distributed is used for ONE thing:

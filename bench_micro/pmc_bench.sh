@@ -28,7 +28,12 @@ try:
     sha = subprocess.run(["git", "-C", os.environ["GRAFT_REPO_ROOT"], "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "snapshot"
 except Exception:
     sha = "snapshot"
-print(f"# bench.py --cfg {cfg} --steps 1, two --pmc passes; source tree: {sha} (gpurun snapshot of the working tree); factors: bench_micro/pmc_bench.sh header")
+try:
+    srchash = open(os.environ["GRAFT_REPO_ROOT"] + "/bcalm_amd/_build/libcdbg.so.srchash").read().strip()
+except Exception:
+    srchash = "unknown"
+# (srchash: the content hash of the kernel sources libcdbg.so was built from -- bench.py quotes this file as roofline.traffic only while it matches)
+print(f"# bench.py --cfg {cfg} --steps 1, two --pmc passes; source tree: {sha} (gpurun snapshot of the working tree); srchash={srchash}; factors: bench_micro/pmc_bench.sh header")
 print("kernel,launches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,fetch_factor,traffic_GB_per_launch")
 for k in sorted(agg, key=lambda x: -(agg[x].get("FETCH_SIZE", 0) + agg[x].get("WRITE_SIZE", 0))):
     n = max(calls[k].values()); f = agg[k].get("FETCH_SIZE", 0) / n; w = agg[k].get("WRITE_SIZE", 0) / n

@@ -179,6 +179,17 @@ int cdbg_stats(cdbg_ctx* ctx, cdbg_stats_t* out);
  * out[2] = order- and orientation-independent digest of the set {(unitig, KC)} (formula: k_links.h k_digest_unitigs;
  * pinned against the oracle's unitigs in tests/), out[3] = sum of (LN - k + 1) (must equal n_solid). */
 int cdbg_digest(cdbg_ctx* ctx, uint64_t out[4]);
+/* The unitig definition (/root/reference/bidirected-graphs-in-bcalm2/bidirected-graphs-in-bcalm2.md:64,83-92) checked on
+ * the resident result at any size, by code that shares nothing with the compaction or the glue (bcalm_amd/csrc/k_verify.h):
+ *   out[0..2]  k-mer positions of all unitigs, and two independent commutative 64-bit sums over their canonical k-mers
+ *   out[3..5]  the same three numbers over the solid k-mers as the count stage left them
+ *              -- equal triples <=> the unitigs spell every solid k-mer exactly once and nothing else
+ *   out[6]     ends e, f of two different unitigs that are each other's ONLY link (counted from both ends): must be 0 --
+ *              every unitig is maximal; builds the links (cdbg_link) when they are not there yet
+ *   out[7]     unitigs whose two ends are each other's only link (closed chains, cut open once: legitimate)
+ * Several ranks: the sums are additive over the ranks; a rank that holds a share of the unitigs (emit_replicated = 0) has
+ * no link table and reports out[6] = out[7] = UINT64_MAX. */
+int cdbg_verify(cdbg_ctx* ctx, uint64_t out[8]);
 
 /* Edges between unitigs (the `L:<+/->:<id>:<+/->` tokens of /root/reference/README.md:62-72; GFA `L`
  * lines of scripts/convertToGFA.py:103-112).  After cdbg_glue: cdbg_link builds them on the GPU.

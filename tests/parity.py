@@ -141,3 +141,28 @@ def set_digest(unitigs):
             hr = (hr * B + (3 - code[s[n - 1 - i]]) + 1) & M64
         tot = (tot + _mix64(((hf + hr) & M64) ^ _mix64(((hf * hr) + kc) & M64))) & M64
     return tot
+
+
+def kmer_set_sums(kmers, k):
+    """the formula of cdbg_verify (bcalm_amd/csrc/k_verify.h verify_mix) over canonical k-mers given as strings:
+    (count, sum of mix A, sum of mix B) -- pins what the device reports to the k-mer SET, not to the device's own code"""
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    W = k // 32 + 1
+    n = sa = sb = 0
+    for s in kmers:
+        v = 0
+        for ch in s:
+            v = (v << 2) | code[ch]
+        h = 0x243F6A8885A308D3
+        for i in range(W):
+            h = _mix64(h ^ ((v >> (64 * i)) & M64))
+        n += 1; sa = (sa + h) & M64; sb = (sb + _mix64(h ^ 0xA4093822299F31D0)) & M64
+    return (n, sa, sb)
+
+
+def assert_verified(g):
+    """the oracle-independent device check of a finished graph: unitig k-mers == solid set, every unitig maximal"""
+    v = g.verify()
+    assert v["unitig_kmers"] == v["solid_kmers"], v
+    assert v["mergeable_ends"] in (0, None), v
+    return v

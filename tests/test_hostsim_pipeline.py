@@ -278,6 +278,38 @@ def test_result_digest_matches_formula(oracle, sim):
         assert d["kmers_in_unitigs"] == st["n_solid"] == exp["stats"]["solid"]
 
 
+@pytest.mark.parametrize("k,amin,n,L,cfg", [(31, 2, 3000, 150, 3), (55, 1, 1500, 150, 4), (30, 1, 1500, 100, 3), (77, 2, 400, 400, 5), (127, 1, 300, 500, 5)])
+def test_verify_matches_the_kmer_set(oracle, sim, k, amin, n, L, cfg):
+    """cdbg_verify (bench.py's full-size check): the sums it reports for the unitigs and for the solid table are the
+    formula evaluated on the ORACLE's solid k-mers; nothing is left mergeable; a set with one k-mer more, less or twice
+    has other sums (the check is sensitive)"""
+    from bcalm_amd import api
+    from parity import kmer_set_sums
+    text = oracle.synth_reads(n, L, cfg)
+    exp = oracle.run(text, k, amin, want_solid=True)
+    g = api.Graph(k, amin, lib=sim, log2_partitions=5)
+    g.push_text(text); g.run()
+    v = g.verify(); g.close()
+    kmers = [s for s, _ in exp["solid"]]
+    want = kmer_set_sums(kmers, k)
+    assert v["unitig_kmers"] == want and v["solid_kmers"] == want
+    assert v["mergeable_ends"] == 0
+    assert kmer_set_sums(kmers[1:], k) != want and kmer_set_sums(kmers + kmers[:1], k) != want
+    assert kmer_set_sums(kmers[1:] + kmers[1:2], k)[0] == want[0] and kmer_set_sums(kmers[1:] + kmers[1:2], k) != want
+
+
+@pytest.mark.parametrize("key", sorted(GOLD))
+def test_verify_on_goldens(sim, key):
+    """every golden input (cycles, hairpins, palindromes, even k): unitig k-mers == solid set, no mergeable pair of ends"""
+    from bcalm_amd import api
+    from parity import assert_verified
+    name, k, amin = _case(key)
+    g = api.Graph(k, amin, lib=sim, log2_partitions=3)
+    g.push_text(oracle_lib.read_input(name)); g.run()
+    v = assert_verified(g); g.close()
+    assert v["unitig_kmers"][0] == GOLD[key]["solid"]["n"]
+
+
 @pytest.mark.parametrize("k,amin,n_reads,cfg", [(31, 2, 3000, 3), (21, 1, 2500, 2), (55, 2, 1500, 4)])
 def test_streaming_scan_while_ingesting(oracle, sim, monkeypatch, k, amin, n_reads, cfg):
     """cdbg_expect_input: the scan runs on the tiles that have landed while the rest is still being pushed (thresholds
