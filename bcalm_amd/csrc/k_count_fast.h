@@ -30,7 +30,17 @@ namespace cdbg {
 #define CDBG_CB_WIDE 8
 #endif
 // records per wave batch (W >= 3: CDBG_CB_WIDE -- records of up to 122-153 members fill the 64-lane steps with far fewer of them)
-template <int W> struct CountCb { static constexpr int V = W >= 3 ? CDBG_CB_WIDE : 16; };
+// Member-capped batches (one-word k-mers).  A batch of 16 records of k = 31 holds 120 +- 20 members: a third of the batches
+// spilled a handful of members into a third 64-lane step, and the wave's steps ran at 80 % of their lanes (the kernel is
+// bound by VALU issue).  A batch is now the longest run of records with at most CF_BATCH_MEMBERS = 128 members (and at most
+// COUNT_CB = 24 records): exactly two steps, the second one nearly full; the position masks shrink from 14 words to 2 per
+// wave, which pays for the larger stage.
+#ifndef CDBG_CB1
+#define CDBG_CB1 24
+#endif
+template <int W> struct CountCap { static constexpr bool ON = W == 1; };
+constexpr uint32_t CF_BATCH_MEMBERS = 128;
+template <int W> struct CountCb { static constexpr int V = W >= 3 ? CDBG_CB_WIDE : W == 1 ? CDBG_CB1 : 16; };
 // Used-slot list (one-word k-mers).  The sweep of a 4096-slot table for the ~960 keys of a config-3 partition was 19 of the
 // kernel's 67 ms.  Every wave now notes the slots its own lanes claimed and sweeps exactly those.  The list costs no LDS: a
 // count word holds the count in its LOWER half (15 bits + the traveller flag; a partition of the one-pass kernel cannot
@@ -52,7 +62,8 @@ template <int W> struct CountGeom {
     // member positions of one batch: COUNT_CB records of at most CAPB - k + 1 members, k >= 3 (W = 1), 32, 64, 96
     static constexpr int KMIN = W == 1 ? 3 : 32 * (W - 1);
     static constexpr int NMAX = RecFmt<W>::CAPB - KMIN + 1;
-    static constexpr int MASKW = (CountCb<W>::V * NMAX + 63) / 64;
+    static constexpr int MASKW = CountCap<W>::ON ? (int)(CF_BATCH_MEMBERS / 64) : (CountCb<W>::V * NMAX + 63) / 64;
+    static_assert(!CountCap<W>::ON || NMAX <= (int)CF_BATCH_MEMBERS, "a record must fit a batch");
 };
 // LDS of one workgroup:
 //   keys / cnt   the open-address table (claim word EMPTY <=> slot free)
@@ -214,12 +225,17 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
         const uint32_t incl = wave_incl_sum_u32(n);
         // (the wave's records with members are consecutive lanes; the stage index of a record is its rank among them)
         const int fa = CountBal<W>::ON ? (int)uni_u32((uint32_t)__builtin_ctzll(__ballot(n != 0u) | (1ULL << 63))) : 0;
-        for (int lo = 0; lo < nrec; lo += COUNT_CB) {                         // batches of COUNT_CB records
+        for (int lo = 0, nb = COUNT_CB; lo < nrec; lo += nb) {                 // batches of at most COUNT_CB records
             const uint32_t before = lo ? wave_readlane_u32(incl, lo - 1) : 0u;
-            const uint32_t total = wave_readlane_u32(incl, lo + COUNT_CB - 1) - before;
+            if (CountCap<W>::ON) {
+                // the records from `lo` on whose members end within CF_BATCH_MEMBERS positions (prefix sums are monotone: a run; >= 1 record)
+                const uint64_t fit = __ballot(lane >= lo && lane < lo + COUNT_CB && lane < nrec && incl - before <= CF_BATCH_MEMBERS);
+                nb = (int)uni_u32((uint32_t)__popcll(fit));
+            }
+            const uint32_t total = wave_readlane_u32(incl, lo + nb - 1 < 63 ? lo + nb - 1 : 63) - before;
             const uint32_t excl = incl - n - before;
             if (CountBal<W>::ON && total == 0u && A.issued) continue;        // (uniform) none of these 16 records has members for this wave
-            if (lane >= lo && lane < lo + COUNT_CB && n) {
+            if (lane >= lo && lane < lo + nb && n) {
                 const int si = lane - (fa > lo ? fa : lo);
 #pragma unroll
                 for (int i = 0; i < RW; ++i) stage[si * RW + i] = R.r[i];
