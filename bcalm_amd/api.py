@@ -33,13 +33,13 @@ class Stats(C.Structure):
         "unitig_bases", "n_big_partitions", "n_cycles")] + [
         ("minimizer_size", C.c_int), ("log2_partitions", C.c_int), ("kmer_words", C.c_int)] + [
         (n, C.c_float) for n in ("ms_scan_hist", "ms_scan_emit", "ms_count", "ms_compact", "ms_glue", "ms_total", "ms_exchange")] + [
-        (n, C.c_uint64) for n in ("n_launch_scan", "n_launch_count", "n_launch_compact", "n_multipass_partitions", "n_tiles_overlapped", "n_glue_rounds")]
+        (n, C.c_uint64) for n in ("n_launch_scan", "n_launch_count", "n_launch_compact", "n_multipass_partitions", "n_tiles_overlapped", "n_split_buckets", "n_glue_rounds")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
+EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_release_cached", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
            "cdbg_generate_reads", "cdbg_expect_input", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
            "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats", "cdbg_digest", "cdbg_verify",
            "cdbg_fetch_unitigs_packed", "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", 

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,7 @@
 #include "comm.h"
 #include "k_count_fast.h"
 #include "k_compact_wave.h"
+#include "k_split.h"
 
 using namespace cdbg;
 
@@ -80,6 +82,29 @@ struct DBuf {                                   // owned device array
     DBuf& operator=(const DBuf&) = delete;
     ~DBuf() { release(); }
 };
+
+// The record region outlives its context.  The scan's 1.6 G scattered 16-byte stores are sensitive to WHERE the 75 GB region
+// lies physically: every free + re-allocation handed back a less contiguous set of pages, and five contexts created and
+// destroyed in one process scanned in 66.7 -> 70.8 -> 68.9 -> 75.3 -> 77.9 ms (profiles/r03_scan_variance_by_allocation.log).
+// A destroyed context therefore leaves its region with the process (one per device); the next context on that device adopts
+// it when it is large enough.  cdbg_release_cached() gives it back to the driver.
+struct RegionStash { std::mutex mu; uint64_t* p[64] = {}; size_t cap[64] = {}; };
+RegionStash& region_stash() { static RegionStash st; return st; }
+void stash_region(int dev, DBuf<uint64_t>& b) {
+    if (dev < 0 || dev >= 64 || !b.p || b.cap < (1u << 24)) return;          // (small regions are not worth keeping)
+    RegionStash& st = region_stash();
+    std::lock_guard<std::mutex> g(st.mu);
+    if (st.cap[dev] >= b.cap) return;                    // (the larger one stays; the caller's buffer is freed by its destructor)
+    if (st.p[dev]) (void)hipFree(st.p[dev]);
+    st.p[dev] = b.p; st.cap[dev] = b.cap; b.p = nullptr; b.n = 0; b.cap = 0;
+}
+void adopt_region(int dev, DBuf<uint64_t>& b, size_t want) {
+    if (dev < 0 || dev >= 64 || b.cap >= want) return;
+    RegionStash& st = region_stash();
+    std::lock_guard<std::mutex> g(st.mu);
+    if (st.cap[dev] < want) return;
+    b.release(); b.p = st.p[dev]; b.cap = st.cap[dev]; b.n = 0; st.p[dev] = nullptr; st.cap[dev] = 0;
+}
 
 #ifndef CDBG_TSC1
 #define CDBG_TSC1 4096
@@ -144,8 +169,9 @@ uint64_t resident_grid(K kern, int threads, uint64_t fallback) {
     return fallback;
 }
 // every persistent workgroup of every launch of a stage may leave one partly used output chunk behind: a stage has up to
-// four launches (count: one-pass, multi-pass retry, spill repair, HBM fallback; compact: two LDS tiers, HBM fallback)
-constexpr uint64_t CHUNK_SLACK_WGS = 4 * (PERSISTENT_GRID + 1);
+// eight launches (count: one-pass, second tier, multi-pass retry, spill repair, HBM fallback; compact: the workgroup tiers and the HBM
+// fallback, once over the buckets and once over the sub-buckets of the second-level split)
+constexpr uint64_t CHUNK_SLACK_WGS = 8 * (PERSISTENT_GRID + 1);
 constexpr uint64_t MAX_GRID = 1u << 22;          // workgroups per launch (grid * block must stay < 2^32)
 uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
 // slots of a junction table: 32-bit slot indices
@@ -187,6 +213,8 @@ struct cdbg_ctx {
     DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
     DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;   // (fallback junction table)
     DBuf<uint32_t> retry_list2;                              // partitions that did not fit the second count tier either
+    DBuf<uint32_t> var_cap; DBuf<uint64_t> var_pairs;        // single-pass layout of skewed inputs: region capacities, begin / end of every partition's records
+    DBuf<uint64_t> split_keys, vseg_off, split_cur; DBuf<uint32_t> split_cnt, vseg_n, vlist_a, vlist_b;   // second-level bucket split (k_split.h)
     DBuf<uint64_t> repair_recs, repair_off, rp_idx; DBuf<uint32_t> repair_part, rp_flag, rp_size, rp_fill;   // capped-scan spill repair (kept: no allocation per step)
     DBuf<uint32_t> jfill; DBuf<uint64_t> jrecs;              // join buckets
     bool direct_join = false; int join_log_jb = 0;           // the compaction kernels filled the join buckets themselves (no junction log)
@@ -550,6 +578,10 @@ int count_impl(cdbg_ctx* c) {
     bool capped = tiles > 8192;
     if (const char* e = getenv("CDBG_SCAN_MODE")) { if (!strcmp(e, "exact")) capped = false; else if (!strcmp(e, "capped")) capped = true; }
     if (tiles == 0) capped = false;                          // (a rank without reads: nothing to sample)
+    // var: ONE pass into regions of their own size per partition, estimated from a denser sample -- what a skewed input gets instead
+    // of the exact two-pass layout (CDBG_SCAN_MODE=var: test knob)
+    bool var = false;
+    if (const char* e = getenv("CDBG_SCAN_MODE")) { if (!strcmp(e, "var") && tiles && !multi) { var = true; capped = false; } }
     uint64_t n_records = 0, hs[2] = {0, 0};
     uint32_t part_cap = 0; uint64_t n_spill = 0; bool packed_exact = false;
     uint64_t n_spilled_parts = 0;                            // partitions whose region overflowed (capped mode): counted from gathered copies
@@ -579,9 +611,10 @@ int count_impl(cdbg_ctx* c) {
             if ((double)part_cap * (double)NPS * RW * 8.0 > 200e9) fits = false;       // would not fit: use the exact layout
             // (at least 32 sampled records in that partition: with a mean of a few records per partition -- long reads, k = 127 --
             //  the sampled maximum is Poisson noise, and scaling it up sent the config-5 share through two passes: 598 -> 662 ms)
-            else if (sample_max >= 32 && (double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && getenv("CDBG_SCAN_MODE") == nullptr) fits = false;
+            else if (sample_max >= 32 && (double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && getenv("CDBG_SCAN_MODE") == nullptr) { fits = false; var = !multi; }
             if (fits) {
                 if (c->xrecs.cap > c->records.cap) c->records.swap(c->xrecs);   // (sharded reads: the previous step left the region buffer there)
+                adopt_region(c->prm.device_id, c->records, (uint64_t)part_cap * NPS * RW);   // (what an earlier context of this process left behind)
                 CK(c->records.alloc((uint64_t)part_cap * NPS * RW, false));
                 CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
                 HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
@@ -638,7 +671,71 @@ int count_impl(cdbg_ctx* c) {
             }
         }
     }
-    if (!capped && !packed_exact) {
+    if (var && !capped && !packed_exact) {
+        const float ms_sample1 = c->st.ms_scan_hist;
+        CK(t.start(s));
+        HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+        const uint64_t stride = tiles >= 64 ? 4 : 1;         // a quarter of the tiles: +- 10 % on a partition of 400 records
+        const uint64_t ns = (tiles + stride - 1) / stride;
+        sp.tile_stride = (uint32_t)stride; sp.tile_offset = 0; sp.part_cap = 0; sp.var_limit = nullptr;
+        LAUNCH_SCAN(SCAN_HIST, ns);
+        CK(c->var_cap.alloc(NPS, false)); CK(c->var_pairs.alloc(2 * NPS, false));
+        uint64_t sample_records = 0;
+        CK(exscan(c->part_count.p)); CK(read_u64(c->part_off.p + NPS, &sample_records));
+        const double scale = (double)tiles / (double)ns, mean = (double)sample_records * scale / (double)NPS;
+        uint32_t cap_min = 0; capped_capacities(mean, NPS, cap_min, spill_cap);
+        VarParams vp{ c->part_count.p, c->var_cap.p, NPS, (float)scale, cap_min, c->part_off.p, c->part_cursor.p, c->var_pairs.p, c->dstats.p + 30 };
+        if (const char* e = getenv("CDBG_VAR_SCALE")) vp.scale = (float)atof(e);   // test knob (with CDBG_PART_CAP): regions far too small, so that partitions spill
+        CDBG_LAUNCH(k_var_caps, (NPS + 255) / 256, 256, s, vp);
+        CK(exscan_u32(c, c->var_cap.p, c->part_off.p, NPS));
+        uint64_t total_cap = 0; CK(read_u64(c->part_off.p + NPS, &total_cap));
+        float ms2 = 0; CK(t.stop(&ms2)); c->st.ms_scan_hist = ms_sample1 + ms2;
+        if ((double)total_cap * RW * 8.0 > 200e9) var = false;                     // would not fit: the exact layout
+        else {
+            spill_cap = std::max<uint64_t>(total_cap / 32, 65536);
+            CK(c->records.alloc(total_cap * RW, false));
+            CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
+            HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+            HIPCK(hipMemsetAsync(c->cursors.p + 6, 0, sizeof(uint64_t), s));
+            CK(t.start(s));
+            CDBG_LAUNCH(k_copy_u64, (NPS + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_cursor.p, NPS);
+            sp.tile_stride = 1; sp.records = c->records.p; sp.var_limit = c->part_off.p + 1;
+            sp.spill_recs = c->spill_recs.p; sp.spill_part = c->spill_part.p; sp.spill_cursor = c->cursors.p + 6; sp.spill_cap = spill_cap;
+            LAUNCH_SCAN(SCAN_EMIT, tiles);
+            sp.var_limit = nullptr;
+            CDBG_LAUNCH(k_var_finish, (NPS + 255) / 256, 256, s, vp);
+            CK(t.stop(&c->st.ms_scan_emit));
+            hm.mark("count: samples + single-pass scan into estimated regions");
+            CK(read_u64(c->dstats.p + 30, &n_records));
+            CK(read_u64(c->dstats.p, hs, 2));
+            CK(read_u64(c->cursors.p + 6, &n_spill));
+            uint32_t derr = 0; CK(read_u32(c->derr.p, &derr));
+            if (derr == 6 || n_spill > spill_cap) {          // the estimate was off by more than the spill list holds: exact layout
+                var = false; HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t))); HIPCK(hipMemset(c->cursors.p + 6, 0, sizeof(uint64_t)));
+            } else if (n_spill) {
+                RepairParams rp{};
+                rp.records = c->records.p; rp.spill_recs = c->spill_recs.p; rp.spill_part = c->spill_part.p; rp.n_spill = n_spill;
+                rp.part_fill = nullptr; rp.npl = NPL; rp.part_cap = 0; rp.RW = RW; rp.var_off = c->part_off.p; rp.var_cursor = c->part_cursor.p;
+                CK(c->rp_flag.alloc(NPL, false)); CK(c->rp_idx.alloc(NPL + 1, false));
+                rp.flag = c->rp_flag.p; rp.ridx = c->rp_idx.p;
+                CDBG_LAUNCH(k_repair_flag, (NPL + 255) / 256, 256, s, rp);
+                CK(exscan_u32(c, c->rp_flag.p, c->rp_idx.p, NPL));
+                CK(read_u64(c->rp_idx.p + NPL, &n_spilled_parts));
+                const uint64_t nsp = n_spilled_parts;
+                CK(c->repair_part.alloc(nsp, false)); CK(c->rp_size.alloc(nsp, false)); CK(c->repair_off.alloc(nsp + 1, false)); CK(c->rp_fill.alloc(nsp, true));
+                rp.item_part = c->repair_part.p; rp.item_size = c->rp_size.p; rp.item_off = c->repair_off.p; rp.item_fill = c->rp_fill.p;
+                CDBG_LAUNCH(k_repair_list, (NPL + 255) / 256, 256, s, rp);
+                CK(exscan_u32(c, c->rp_size.p, c->repair_off.p, nsp));
+                uint64_t total = 0; CK(read_u64(c->repair_off.p + nsp, &total));
+                CK(c->repair_recs.alloc(total * RW, false));
+                rp.out = c->repair_recs.p;
+                CDBG_LAUNCH(k_repair_gather, nsp, 256, s, rp);
+                CDBG_LAUNCH(k_repair_scatter, std::min<uint64_t>((n_spill + 255) / 256, 1u << 16), 256, s, rp);
+            }
+        }
+    }
+    if (!capped && !packed_exact && !var) {
         sp.tile_stride = 1; sp.part_cap = 0;
         HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
@@ -721,6 +818,7 @@ int count_impl(cdbg_ctx* c) {
     CountParams cp{};
     cp.records = c->records.p; cp.part_off = c->part_off.p; cp.part_list = nullptr;
     if (capped) { cp.part_stride = part_cap; cp.part_fill = c->part_count.p; }
+    if (var) { cp.part_off = c->var_pairs.p; cp.part_pairs = 1u; }   // (regions of estimated size: begin / end per partition)
     cp.k = c->k; cp.amin = (uint32_t)c->prm.abundance_min;
     cp.solid_keys = c->solid_keys.p; cp.solid_cnt = c->solid_cnt.p; cp.solid_cap = solid_cap; cp.solid_cursor = c->solid_cursor.p;
     cp.seg_off = c->seg_off.p; cp.seg_n = c->seg_n.p; cp.stats = c->dstats.p;
@@ -797,13 +895,15 @@ int count_impl(cdbg_ctx* c) {
         std::vector<uint32_t> h_fill; std::vector<uint64_t> h_off;
         if (nbig > 64) {
             if (capped) { h_fill.resize(NPL); CK(read_u32(c->part_count.p, h_fill.data(), NPL)); }
+            else if (var) { h_off.resize(2 * NPL); CK(read_u64(c->var_pairs.p, h_off.data(), 2 * NPL)); }
             else { h_off.resize(NPL + 1); CK(read_u64(c->part_off.p, h_off.data(), NPL + 1)); }
         }
         for (uint32_t i = 0; i < nbig; ++i) {
             uint64_t nrec_p;
             if (!h_fill.empty()) nrec_p = h_fill[bl[i]];
-            else if (!h_off.empty()) nrec_p = h_off[bl[i] + 1] - h_off[bl[i]];
+            else if (!h_off.empty()) nrec_p = var ? h_off[2 * (size_t)bl[i] + 1] - h_off[2 * (size_t)bl[i]] : h_off[bl[i] + 1] - h_off[bl[i]];
             else if (capped) { uint32_t f = 0; CK(read_u32(c->part_count.p + bl[i], &f)); nrec_p = f; }
+            else if (var) { uint64_t po[2]; CK(read_u64(c->var_pairs.p + 2 * (size_t)bl[i], po, 2)); nrec_p = po[1] - po[0]; }
             else { uint64_t po[2]; CK(read_u64(c->part_off.p + bl[i], po, 2)); nrec_p = po[1] - po[0]; }
             const uint64_t occ = nrec_p * nmax;
             offs[i + 1] = offs[i] + pow2_at_least(2 * occ + 4 * 256);
@@ -830,6 +930,12 @@ int count_impl(cdbg_ctx* c) {
 #endif
     c->st.n_distinct = cs[0]; c->st.n_occurrences = cs[1]; c->st.n_solid = cs[2]; c->st.n_solid_travellers = cs[3];
     CK(read_u64(c->solid_cursor.p, &c->n_solid_entries));
+    if (getenv("CDBG_DEBUG_SEGHIST")) {                      // dev aid: solid entries per bucket, log2 bins (stderr)
+        std::vector<uint32_t> sn(NPL); CK(read_u32(c->seg_n.p, sn.data(), NPL));
+        uint64_t nb[32] = {0}, ne[32] = {0};
+        for (uint64_t p = 0; p < NPL; ++p) { int b = 0; while ((1u << b) <= sn[p] && b < 31) ++b; ++nb[b]; ne[b] += sn[p]; }
+        for (int b = 0; b < 32; ++b) if (nb[b]) fprintf(stderr, "[seghist] entries < 2^%-2d : %10llu buckets %12llu entries\n", b, (unsigned long long)nb[b], (unsigned long long)ne[b]);
+    }
     c->st.input_bytes = c->nbytes;
     float ms = 0; CK(t_total.stop(&ms)); c->st.ms_total = ms;
     c->stage = 1;
@@ -860,7 +966,8 @@ int compact_impl(cdbg_ctx* c) {
         // glue log: <= 2 open ends + 1 confirm per junction, one junction per solid traveller at most; the tail of a
         // chunk that the next bucket does not fit into is abandoned, hence the generous second attempt
         // (every persistent wave of tier 0 may strand one partly used chunk of each output array as well)
-        const uint64_t wave_slack = std::min<uint64_t>(NPL, 256ull * 32);
+        // (... in the wave tiers over the buckets and over the sub-buckets of the second-level split)
+        const uint64_t wave_slack = 2 * std::min<uint64_t>(NPL, 256ull * 32) + 2 * std::min<uint64_t>(c->n_solid_entries / 32 + 4, 256ull * 32);
         c->glog_cap = (attempt == 0 ? 3 : 8) * c->st.n_solid_travellers + (attempt + 1) * (CHUNK_SLACK_WGS * (uint64_t)GLOG_CHUNK + wave_slack * CW_GLOG_CHUNK) + 64;
         if (direct) {
             c->glog_cap = ~0ull >> 2;                        // (the log cursor only counts)
@@ -893,67 +1000,94 @@ int compact_impl(cdbg_ctx* c) {
         kp.jfill = direct ? c->jfill.p : nullptr; kp.jrecs = direct ? c->jrecs.p : nullptr; kp.log_jb = log_jb;
         kp.big_list = c->big_list.p; kp.big_count = c->big_count.p; kp.error = c->derr.p; kp.stats = c->dstats.p;
         kp.n_items = (uint32_t)NPL;
-        // tier 0: one wave per bucket (k_compact_wave.h); buckets beyond its table come back on big_list
-        uint32_t nbig = 0;
-        {
-            CompactWaveParams wp{ kp, (uint32_t)NPL, reinterpret_cast<uint32_t*>(c->cursors.p + 5) };
-            const uint64_t wgrid = resident_grid(k_compact_wave<W, Cfg<W>::TSW>, CW_THREADS, 256 * 3);
-            CDBG_LAUNCH((k_compact_wave<W, Cfg<W>::TSW>), std::min<uint64_t>((NPL + CW_THREADS / 64 - 1) / (CW_THREADS / 64), wgrid), CW_THREADS, s, wp);
-            c->st.n_launch_compact = NPL;
-            HIPCK(hipStreamSynchronize(s));
-            hm.mark("compact: buffers + wave tier");
-            CK(read_u32(c->big_count.p, &nbig));
+        // The LDS tiers over the buckets 0 .. n of `base` (their segments: base.seg_off / seg_n): one wave per bucket
+        // (k_compact_wave.h), W >= 2: again one wave each with a table twice the size, then a workgroup per bucket with an LDS
+        // table of TS and of 2 TS slots (k_compact.h).  Every tier hands the buckets beyond its table to the next on a list;
+        // la / lb: the two lists (>= n entries each).  Returns the survivors (count, and which list holds them).
+        auto lds_tiers = [&](const CompactParams& base, uint32_t n, DBuf<uint32_t>& la, DBuf<uint32_t>& lb, uint32_t& nleft, const uint32_t*& left) -> int {
+            CK(c->big_count.alloc(4, false)); CK(c->big_count2.alloc(4, false));
+            HIPCK(hipMemsetAsync(c->big_count.p, 0, 4 * sizeof(uint32_t), s)); HIPCK(hipMemsetAsync(c->big_count2.p, 0, 4 * sizeof(uint32_t), s));
+            uint32_t nbig = 0;
+            {   // tier 0
+                CompactParams k0 = base; k0.part_list = nullptr; k0.n_items = n; k0.big_list = la.p; k0.big_count = c->big_count.p;
+                HIPCK(hipMemsetAsync(c->cursors.p + 5, 0, sizeof(uint64_t), s));       // the bucket queue (re)starts
+                CompactWaveParams wp{ k0, n, reinterpret_cast<uint32_t*>(c->cursors.p + 5) };
+                const uint64_t wgrid = resident_grid(k_compact_wave<W, Cfg<W>::TSW>, CW_THREADS, 256 * 3);
+                CDBG_LAUNCH((k_compact_wave<W, Cfg<W>::TSW>), std::min<uint64_t>(((uint64_t)n + CW_THREADS / 64 - 1) / (CW_THREADS / 64), wgrid), CW_THREADS, s, wp);
+                HIPCK(hipStreamSynchronize(s));
+                CK(read_u32(c->big_count.p, &nbig));
+            }
+            DBuf<uint32_t>* cur = &la; DBuf<uint32_t>* oth = &lb; uint32_t* cnt_cur = c->big_count.p; uint32_t* cnt_oth = c->big_count2.p;
+            auto next_tier = [&](CompactParams& kt) { kt = base; kt.part_list = cur->p; kt.n_items = nbig; kt.big_list = oth->p; kt.big_count = cnt_oth; };
+            auto flip = [&]() -> int { HIPCK(hipStreamSynchronize(s)); CK(read_u32(cnt_oth, &nbig)); std::swap(cur, oth); std::swap(cnt_cur, cnt_oth);
+                                       HIPCK(hipMemsetAsync(cnt_oth, 0, 4 * sizeof(uint32_t), s)); return CDBG_OK; };
+            if (nbig && Cfg<W>::TSW2 > Cfg<W>::TSW) {
+                // tier 0b: the deferred buckets again one wave each, with a table twice the size (fewer waves per CU, but no
+                // workgroup barriers: at the config-4 share the workgroup tier below spent 44 ms on the 129..256-entry buckets)
+                CompactParams k0; next_tier(k0);
+                HIPCK(hipMemsetAsync(c->cursors.p + 5, 0, sizeof(uint64_t), s));
+                CompactWaveParams wp{ k0, nbig, reinterpret_cast<uint32_t*>(c->cursors.p + 5) };
+                const uint64_t wgrid = resident_grid(k_compact_wave<W, Cfg<W>::TSW2>, CW_THREADS, 256 * 2);
+                CDBG_LAUNCH((k_compact_wave<W, Cfg<W>::TSW2>), std::min<uint64_t>(((uint64_t)nbig + CW_THREADS / 64 - 1) / (CW_THREADS / 64), wgrid), CW_THREADS, s, wp);
+                CK(flip());
+            }
+            if (nbig) {                                      // tier 1: a workgroup per bucket, LDS table of TS slots
+                CompactParams k1; next_tier(k1);
+                CDBG_LAUNCH((k_compact<W, TS, false>), std::min<uint64_t>(nbig, PERSISTENT_GRID), COMPACT_THREADS, s, k1);
+                CK(flip());
+            }
+            if (nbig) {                                      // tier 2: the deferred buckets with a table twice the size
+                CompactParams k2; next_tier(k2);
+                CDBG_LAUNCH((k_compact<W, Cfg<W>::TSK2, false>), std::min<uint64_t>(nbig, PERSISTENT_GRID), COMPACT_THREADS, s, k2);
+                CK(flip());
+            }
+            nleft = nbig; left = cur->p;
+            return CDBG_OK;
+        };
+        uint32_t nbig = 0; const uint32_t* left = nullptr;
+        CK(c->big_list.alloc(NPL, false)); CK(c->big_list2.alloc(NPL, false));
+        CK(lds_tiers(kp, (uint32_t)NPL, c->big_list, c->big_list2, nbig, left));
+        c->st.n_launch_compact = NPL;
+        hm.mark("compact: buffers + LDS tiers");
+        CompactParams kh = kp; uint64_t n_src = NPL;         // what the HBM tier below reads: the buckets themselves, or their sub-buckets
+        if (nbig && getenv("CDBG_NO_SPLIT") == nullptr) {
+            // Second-level split (k_split.h): what no LDS tier could take is re-bucketed by junction into sub-buckets of ~100 entries,
+            // which go through the same tiers again (the hostile config-3 line spent 76 ms walking 17 K such buckets through HBM tables)
+            CK(c->split_cur.alloc(4, true));
+            SplitParams sp{ kp.solid_keys, kp.solid_cnt, kp.seg_off, kp.seg_n, left, nbig, c->k, c->m, nullptr, nullptr, 0, nullptr, nullptr, 0, c->split_cur.p, c->derr.p };
+            CDBG_LAUNCH(k_split_measure, (nbig + 255) / 256, 256, s, sp);
+            uint64_t need[2] = {0, 0}; CK(read_u64(c->split_cur.p + 2, need, 2));
+            if (need[1] >= (1ull << 31)) return fail(CDBG_E_INTERNAL, "bucket split: %llu sub-buckets exceed 31-bit ids", (unsigned long long)need[1]);
+            CK(c->split_keys.alloc(2 * need[0] * W + W, false)); CK(c->split_cnt.alloc(2 * need[0] + 1, false));
+            CK(c->vseg_off.alloc(need[1] + 1, false)); CK(c->vseg_n.alloc(need[1] + 1, false));
+            CK(c->vlist_a.alloc(need[1] + 1, false)); CK(c->vlist_b.alloc(need[1] + 1, false));
+            sp.out_keys = c->split_keys.p; sp.out_cnt = c->split_cnt.p; sp.out_cap = 2 * need[0]; sp.vseg_off = c->vseg_off.p; sp.vseg_n = c->vseg_n.p; sp.vcap = (uint32_t)need[1];
+            CDBG_LAUNCH((k_split_buckets<W>), std::min<uint64_t>(nbig, PERSISTENT_GRID), SPLIT_THREADS, s, sp);
+            kh = kp; kh.solid_keys = c->split_keys.p; kh.solid_cnt = c->split_cnt.p; kh.seg_off = c->vseg_off.p; kh.seg_n = c->vseg_n.p; kh.split = 1u;
+            n_src = need[1];
+            c->st.n_split_buckets += nbig;
+            CK(lds_tiers(kh, (uint32_t)need[1], c->vlist_a, c->vlist_b, nbig, left));
+            hm.mark("compact: split + LDS tiers");
         }
-        if (nbig && Cfg<W>::TSW2 > Cfg<W>::TSW) {
-            // tier 0b: the deferred buckets again one wave each, with a table twice the size (fewer waves per CU, but no
-            // workgroup barriers: at the config-4 share the workgroup tier below spent 44 ms on the 129..256-entry buckets)
-            CK(c->big_list2.alloc(nbig, false)); CK(c->big_count2.alloc(4, true));
-            CompactParams k0 = kp;
-            k0.part_list = c->big_list.p; k0.n_items = nbig; k0.big_list = c->big_list2.p; k0.big_count = c->big_count2.p;
-            HIPCK(hipMemsetAsync(c->cursors.p + 5, 0, sizeof(uint64_t), s));       // the bucket queue restarts
-            CompactWaveParams wp{ k0, nbig, reinterpret_cast<uint32_t*>(c->cursors.p + 5) };
-            const uint64_t wgrid = resident_grid(k_compact_wave<W, Cfg<W>::TSW2>, CW_THREADS, 256 * 2);
-            CDBG_LAUNCH((k_compact_wave<W, Cfg<W>::TSW2>), std::min<uint64_t>((nbig + CW_THREADS / 64 - 1) / (CW_THREADS / 64), wgrid), CW_THREADS, s, wp);
-            HIPCK(hipStreamSynchronize(s));
-            CK(read_u32(c->big_count2.p, &nbig));
-            // (the survivors are the input of the workgroup tiers)
-            if (nbig) HIPCK(hipMemcpyAsync(c->big_list.p, c->big_list2.p, (size_t)nbig * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
-        }
-        if (nbig) {                                          // tier 1: a workgroup per bucket, LDS table of TS slots
-            CK(c->big_list2.alloc(nbig, false)); CK(c->big_count2.alloc(4, true));
-            CompactParams k1 = kp;
-            k1.part_list = c->big_list.p; k1.n_items = nbig; k1.big_list = c->big_list2.p; k1.big_count = c->big_count2.p;
-            CDBG_LAUNCH((k_compact<W, TS, false>), std::min<uint64_t>(nbig, PERSISTENT_GRID), COMPACT_THREADS, s, k1);
-            HIPCK(hipStreamSynchronize(s));
-            CK(read_u32(c->big_count2.p, &nbig));
-        }
-        if (nbig) {                                          // tier 2: the deferred buckets with a table twice the size
-            HIPCK(hipMemsetAsync(c->big_count.p, 0, 4 * sizeof(uint32_t), s));
-            CompactParams k2 = kp;
-            k2.part_list = c->big_list2.p; k2.n_items = nbig; k2.big_list = c->big_list.p; k2.big_count = c->big_count.p;
-            CDBG_LAUNCH((k_compact<W, Cfg<W>::TSK2, false>), std::min<uint64_t>(nbig, PERSISTENT_GRID), COMPACT_THREADS, s, k2);
-            HIPCK(hipStreamSynchronize(s));
-            CK(read_u32(c->big_count.p, &nbig));
-        }
-        DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_cnt, g_lnk, g_aux;
+        DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_cnt, g_lnk, g_aux, hb_list;
         if (nbig) {                                          // buckets with more entries than fit LDS
-            std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list.p, bl.data(), nbig));
+            std::vector<uint32_t> bl(nbig); CK(read_u32(left, bl.data(), nbig));
             std::sort(bl.begin(), bl.end());
             std::vector<uint64_t> offs(nbig + 1, 0);
             std::vector<uint32_t> h_segn;
-            if (nbig > 64) { h_segn.resize(NPL); CK(read_u32(c->seg_n.p, h_segn.data(), NPL)); }   // (one bulk copy, not one per bucket)
+            if (nbig > 64) { h_segn.resize(n_src); CK(read_u32(kh.seg_n, h_segn.data(), n_src)); }   // (one bulk copy, not one per bucket)
             for (uint32_t i = 0; i < nbig; ++i) {
                 uint32_t e = 0;
-                if (!h_segn.empty()) e = h_segn[bl[i]]; else CK(read_u32(c->seg_n.p + bl[i], &e));
+                if (!h_segn.empty()) e = h_segn[bl[i]]; else CK(read_u32(kh.seg_n + bl[i], &e));
                 offs[i + 1] = offs[i] + pow2_at_least(2 * (uint64_t)e + 16);
             }
             CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_cnt.alloc(offs[nbig], false));
             CK(g_lnk.alloc(2 * offs[nbig], false)); CK(g_aux.alloc(3 * offs[nbig], false));
-            CK(big_off.alloc(nbig + 1, false));
+            CK(big_off.alloc(nbig + 1, false)); CK(hb_list.alloc(nbig, false));
             HIPCK(hipMemcpy(big_off.p, offs.data(), (nbig + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-            HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
-            CompactParams bp = kp;
-            bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_cnt = g_cnt.p;
+            HIPCK(hipMemcpy(hb_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
+            CompactParams bp = kh;
+            bp.part_list = hb_list.p; bp.g_keys = g_keys.p; bp.g_cnt = g_cnt.p;
             bp.g_lnk = g_lnk.p; bp.g_aux = g_aux.p; bp.big_off = big_off.p;
             bp.n_items = nbig;
             CDBG_LAUNCH((k_compact<W, TS, true>), std::min<uint64_t>(nbig, PERSISTENT_GRID), COMPACT_THREADS, s, bp);
@@ -1804,8 +1938,18 @@ void cdbg_destroy(cdbg_ctx* c) {
 #ifndef CDBG_HOSTSIM
     if (c->rccl) { c->rccl->destroy(); delete c->rccl; c->rccl = nullptr; }
 #endif
+    (void)hipStreamSynchronize(c->stream);
+    stash_region(c->prm.device_id, c->records);
     (void)hipStreamDestroy(c->stream);
     delete c;
+}
+int cdbg_release_cached(void) {
+    RegionStash& st = region_stash();
+    std::lock_guard<std::mutex> g(st.mu);
+    int cur = 0; (void)hipGetDevice(&cur);
+    for (int d = 0; d < 64; ++d) if (st.p[d]) { (void)hipSetDevice(d); (void)hipFree(st.p[d]); st.p[d] = nullptr; st.cap[d] = 0; }
+    (void)hipSetDevice(cur);
+    return CDBG_OK;
 }
 
 int cdbg_push_reads(cdbg_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads) {

@@ -82,6 +82,7 @@ struct CompactParams {
     // HBM scratch (GLOBAL variant)
     uint64_t* g_keys; uint32_t* g_cnt; uint32_t* g_lnk; uint32_t* g_aux; const uint64_t* big_off;
     uint32_t n_items;              // buckets (or part_list entries) to process
+    uint32_t split;                // the buckets are sub-buckets of the second-level split (k_split.h): ownership is NOT by minimizer partition
 };
 
 // join buckets of the glue stage: <= JB_CAP records each, chosen by a hash of the junction key; a record = W key words
@@ -246,7 +247,7 @@ CDBG_DEV void compact_bucket(const CompactParams& P, const uint32_t item, uint64
 #ifdef CDBG_HOSTSIM
         {   // (the simulator build checks every flag against the definition)
             uint32_t gl, gr; kmer_junction_mins<W>(x, k, P.m, gl, gr);
-            if ((part_of(gl, P.log_np) == pg) != !(fl & KEY_FOREIGN_L) || (part_of(gr, P.log_np) == pg) != !(fl & KEY_FOREIGN_R)) *P.error = 9;
+            if (!P.split && ((part_of(gl, P.log_np) == pg) != !(fl & KEY_FOREIGN_L) || (part_of(gr, P.log_np) == pg) != !(fl & KEY_FOREIGN_R))) *P.error = 9;   // (sub-buckets of k_split.h own junctions by sub-minimizer)
         }
 #endif
         slots[e] = s;

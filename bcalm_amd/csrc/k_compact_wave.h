@@ -185,7 +185,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
 #ifdef CDBG_HOSTSIM
             {   // (the simulator build checks every flag against the definition)
                 uint32_t gl, gr; kmer_junction_mins<W>(x, k, P.m, gl, gr);
-                if ((part_of(gl, P.log_np) == pg) != !(fl & KEY_FOREIGN_L) || (part_of(gr, P.log_np) == pg) != !(fl & KEY_FOREIGN_R)) *P.error = 9;
+                if (!P.split && ((part_of(gl, P.log_np) == pg) != !(fl & KEY_FOREIGN_L) || (part_of(gr, P.log_np) == pg) != !(fl & KEY_FOREIGN_R))) *P.error = 9;   // (sub-buckets of k_split.h own junctions by sub-minimizer)
             }
 #endif
             if (!(cv & TRAV_FLAG)) ++n_home;

@@ -250,7 +250,8 @@ struct RecView {
 
 struct CountParams {
     const uint64_t* records;       // RW words per record
-    const uint64_t* part_off;      // [n_parts + 1] record offsets (exact two-pass layout)
+    const uint64_t* part_off;      // [n_parts + 1] record offsets (exact two-pass layout); part_pairs: [2 n_parts] begin / end of every partition's records
+    uint32_t part_pairs;           //       (regions of estimated size filled in one pass: a region has slack behind its records; a spilled partition: begin == end)
     uint32_t part_stride;          // != 0: capped single-pass layout, partition p = records [p*stride, p*stride + fill[p])
     const uint32_t* part_fill;     //       records offered to p; fill > stride => spilled, handled by the repair launch
     const uint64_t* item_off;      // != null: work item i = records [item_off[i], item_off[i+1]) (repair launch)
@@ -314,7 +315,8 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
         const uint32_t f = P.part_fill[p];
         if (f > P.part_stride) return;                           // spilled: counted by the repair launch
         rec0 = (uint64_t)p * P.part_stride; rec1 = rec0 + f;
-    } else { rec0 = P.part_off[p]; rec1 = P.part_off[p + 1]; }
+    } else if (P.part_pairs) { rec0 = P.part_off[2ull * p]; rec1 = P.part_off[2ull * p + 1]; }
+    else { rec0 = P.part_off[p]; rec1 = P.part_off[p + 1]; }
     CDBG_PH(0);
     if (rec1 == rec0) { if (tid == 0) { P.seg_off[p] = 0; P.seg_n[p] = 0; } return; }
 
@@ -658,6 +660,7 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(GLOBAL ? 1024 : (size_t
 struct RepairParams {
     const uint64_t* records; const uint64_t* spill_recs; const uint32_t* spill_part; uint64_t n_spill;
     const uint32_t* part_fill; uint64_t npl; uint32_t part_cap; int RW;
+    const uint64_t* var_off; const uint64_t* var_cursor;   // != null: regions of their own size -- partition p owns records [var_off[p], var_off[p + 1]), var_cursor[p] - var_off[p] were offered
     uint32_t* flag;              // [npl]  1 = spilled
     const uint64_t* ridx;        // [npl + 1] exclusive scan of flag: list index of a spilled partition
     uint32_t* item_part;         // [nsp]  spilled partitions, ascending
@@ -668,29 +671,59 @@ struct RepairParams {
 };
 __global__ void k_repair_flag(RepairParams P) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < P.npl) P.flag[p] = P.part_fill[p] > P.part_cap ? 1u : 0u;
+    if (p < P.npl) P.flag[p] = P.var_off ? (P.var_cursor[p] > P.var_off[p + 1] ? 1u : 0u) : (P.part_fill[p] > P.part_cap ? 1u : 0u);
 }
 __global__ void k_repair_list(RepairParams P) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P.npl || !P.flag[p]) return;
     const uint64_t i = P.ridx[p];
-    P.item_part[i] = (uint32_t)p; P.item_size[i] = P.part_fill[p];
+    P.item_part[i] = (uint32_t)p; P.item_size[i] = P.var_off ? (uint32_t)(P.var_cursor[p] - P.var_off[p]) : P.part_fill[p];
 }
 __global__ void k_repair_gather(RepairParams P) {        // one workgroup per spilled partition: its region
     const uint32_t it = blockIdx.x;
     const uint64_t o0 = P.item_off[it] * P.RW, p = P.item_part[it];
-    const uint64_t nreg = (uint64_t)P.part_cap * P.RW;
-    for (uint64_t i = threadIdx.x; i < nreg; i += blockDim.x) P.out[o0 + i] = P.records[p * nreg + i];
+    const uint64_t nreg = (P.var_off ? P.var_off[p + 1] - P.var_off[p] : (uint64_t)P.part_cap) * P.RW;
+    const uint64_t src = P.var_off ? P.var_off[p] * P.RW : p * nreg;
+    for (uint64_t i = threadIdx.x; i < nreg; i += blockDim.x) P.out[o0 + i] = P.records[src + i];
 }
 __global__ void k_repair_scatter(RepairParams P) {       // one thread per spilled record
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < P.n_spill; o += stride) {
-        const uint64_t it = P.ridx[P.spill_part[o]];
-        const uint64_t dst = (P.item_off[it] + P.part_cap + atomic_add_u32(&P.item_fill[it], 1u)) * P.RW;
+        const uint64_t sp = P.spill_part[o], it = P.ridx[sp];
+        const uint64_t cap = P.var_off ? P.var_off[sp + 1] - P.var_off[sp] : (uint64_t)P.part_cap;
+        const uint64_t dst = (P.item_off[it] + cap + atomic_add_u32(&P.item_fill[it], 1u)) * P.RW;
         for (int w = 0; w < P.RW; ++w) P.out[dst + w] = P.spill_recs[o * P.RW + w];
     }
 }
 
+
+// ---- single-pass record layout for SKEWED inputs: a region of its own size per partition, estimated from a sampled histogram ----
+// (the uniform capacity of the capped layout cannot hold a coverage peak or a repeat; the exact layout costs a second pass over
+//  the reads: 64 ms of histogram at the hostile config-3 line).  k_var_caps: sampled count s -> capacity scale * (s + 4 sqrt(s) + 2),
+//  at least cap_min; the host scans the capacities into region offsets.  k_var_finish (after the scan): begin / end of every
+//  partition's records for the count kernels (part_pairs), spilled partitions empty there (the repair launch counts them).
+struct VarParams {
+    const uint32_t* sample; uint32_t* cap; uint64_t n; float scale; uint32_t cap_min;
+    const uint64_t* off; const uint64_t* cursor; uint64_t* pairs; uint64_t* stats;   // stats[0] += records offered
+};
+__global__ void k_var_caps(VarParams P) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P.n) return;
+    const float s = (float)P.sample[p];
+    const uint32_t c = (uint32_t)(P.scale * (s + 4.0f * sqrtf(s) + 2.0f)) + 8u;
+    P.cap[p] = ((c > P.cap_min ? c : P.cap_min) + 7u) & ~7u;
+}
+__global__ void k_var_finish(VarParams P) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t n = 0;
+    if (p < P.n) {
+        const uint64_t b = P.off[p], lim = P.off[p + 1], e = P.cursor[p];
+        n = e - b;
+        P.pairs[2 * p] = b; P.pairs[2 * p + 1] = e > lim ? b : e;
+    }
+    n = wave_sum_u64(n);
+    if ((threadIdx.x & 63) == 0 && n) atomic_add_u64(&P.stats[0], n);
+}
 
 // ---- multi-GPU, single-pass scan: squeeze the capped regions into the exact owner-major layout that travels ----
 // (slot = owner * npl + local partition; off = exclusive scan of the fill counts; one wave per slot, grid-stride)

@@ -110,6 +110,7 @@ CDBG_DEV CountRaw<CAPPED> count_raw_load(const CountParams& P, uint32_t item) {
     uint32_t p = i;
     if constexpr (CAPPED & 2) { p = P.part_list[i]; r.p = p; }
     if constexpr (CAPPED & 1) r.f = P.part_fill[p];
+    else if (P.part_pairs) { r.a = P.part_off[2ull * p]; r.b = P.part_off[2ull * p + 1]; }
     else { r.a = P.part_off[p]; r.b = P.part_off[p + 1]; }
     return r;
 }

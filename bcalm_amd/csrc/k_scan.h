@@ -69,6 +69,7 @@ struct ScanParams {
     uint32_t part_cap; uint32_t* part_fill;
     uint64_t* spill_recs; uint32_t* spill_part; uint64_t* spill_cursor; uint64_t spill_cap; uint32_t* error;
     uint32_t emit_all, npl;      // multi-GPU with sharded reads: emit every partition, slot = owner * npl + local partition
+    const uint64_t* var_limit;   // SCAN_EMIT with estimated regions: end of partition p's region (records beyond it go to the spill list); nullptr = exact offsets
 };
 constexpr int SCAN_HIST = 0, SCAN_EMIT = 1, SCAN_EMIT_CAPPED = 2;
 
@@ -99,16 +100,23 @@ CDBG_DEV void scan_emit_record(const ScanParams& P, const uint32_t* pk, int bito
     constexpr int RW = RecFmt<W>::RW;
     if (MODE == SCAN_HIST) { atomic_add_u32(&P.part_count[lpart], 1u); return; }
     uint64_t* dst;
-    if (MODE == SCAN_EMIT) dst = P.records + atomic_add_u64(&P.part_cursor[lpart], 1ULL) * RW;
-    else {
+    bool fits;
+    if (MODE == SCAN_EMIT) {
+        // exact layout (var_limit == nullptr: the histogram pass sized every region), or ESTIMATED regions of their own size per
+        // partition (var_limit[p] = end of p's region, sized from a sampled histogram: the single-pass layout of skewed inputs)
+        const uint64_t pos = atomic_add_u64(&P.part_cursor[lpart], 1ULL);
+        fits = P.var_limit == nullptr || pos < P.var_limit[lpart];
+        dst = P.records + pos * RW;
+    } else {
         const uint32_t j = atomic_add_u32(&P.part_fill[lpart], 1u);
-        if (j < P.part_cap) dst = P.records + ((uint64_t)lpart * P.part_cap + j) * RW;
-        else {
-            const uint64_t o = atomic_add_u64(P.spill_cursor, 1ULL);
-            if (o >= P.spill_cap) { *P.error = 6; return; }
-            P.spill_part[o] = lpart;
-            dst = P.spill_recs + o * RW;
-        }
+        fits = j < P.part_cap;
+        dst = P.records + ((uint64_t)lpart * P.part_cap + j) * RW;
+    }
+    if (!fits) {
+        const uint64_t o = atomic_add_u64(P.spill_cursor, 1ULL);
+        if (o >= P.spill_cap) { *P.error = 6; return; }
+        P.spill_part[o] = lpart;
+        dst = P.spill_recs + o * RW;
     }
 #pragma unroll
     for (int wv = 0; wv < RW; ++wv) {
@@ -357,7 +365,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
     if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) atomic_add_u64(&P.stats[16 + i], sph[i]);
 #endif
-    if (MODE != SCAN_EMIT) {                            // one device atomic per workgroup, not per lane
+    if (MODE != SCAN_EMIT || P.var_limit) {             // one device atomic per workgroup, not per lane (the exact layout's histogram pass counted already)
         uint32_t nm = (uint32_t)n_members, nt = (uint32_t)n_trav;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { nm += __shfl_xor(nm, d); nt += __shfl_xor(nt, d); }

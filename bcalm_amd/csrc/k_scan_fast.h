@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : WN
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
     if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) atomic_add_u64(&P.stats[16 + i], sph[i]);
 #endif
-    if (MODE != SCAN_EMIT) {
+    if (MODE != SCAN_EMIT || P.var_limit) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { n_members += __shfl_xor(n_members, d); n_trav += __shfl_xor(n_trav, d); }
         if (lane == 0) { if (n_members) atomic_add_u32(&s_members, n_members); if (n_trav) atomic_add_u32(&s_trav, n_trav); }

@@ -233,7 +233,8 @@ CDBG_HD uint32_t junction_min(const Kmer<W>& j, int k, int m) {
 // minimizer keys of BOTH junctions of k-mer x (left = prefix (k-1)-mer, right = suffix (k-1)-mer) in one
 // rolling pass over its k-m+1 m-mers (canonical m-mers: the strand of x does not matter)
 template <int W>
-CDBG_HD void kmer_junction_mins(const Kmer<W>& x, int k, int m, uint32_t& g_left, uint32_t& g_right) {
+CDBG_HD void kmer_junction_mins(const Kmer<W>& x, int k, int m, uint32_t& g_left, uint32_t& g_right, const uint32_t seed = 0u) {
+    // (seed != 0: the same minima under ANOTHER order of the m-mers -- the sub-minimizers of k_split.h)
     // every m-mer and its reverse complement are bit fields of x and of rc(x): the reverse complement of the
     // m-mer at base j is the m-mer of rc(x) at base k-m-j (no per-base rolling, one rc() for the whole k-mer)
     uint32_t gl = 0xFFFFFFFFu, gr = 0xFFFFFFFFu;
@@ -257,7 +258,7 @@ CDBG_HD void kmer_junction_mins(const Kmer<W>& x, int k, int m, uint32_t& g_left
                 ++i;
                 if (i >= m) {
                     const int j = i - m;
-                    const uint32_t key = mix32(rc < fw ? rc : fw);
+                    const uint32_t key = mix32((rc < fw ? rc : fw) ^ seed);
                     if (j < last) gl = key < gl ? key : gl;
                     if (j >= 1) gr = key < gr ? key : gr;
                 }
@@ -269,7 +270,7 @@ CDBG_HD void kmer_junction_mins(const Kmer<W>& x, int k, int m, uint32_t& g_left
     const Kmer<W> r = x.rc(k);
     for (int j = 0; j <= last; ++j) {
         const uint32_t fw = mmer_at<W>(x, k, j, m), rc = mmer_at<W>(r, k, last - j, m);
-        const uint32_t key = mix32(rc < fw ? rc : fw);
+        const uint32_t key = mix32((rc < fw ? rc : fw) ^ seed);
         if (j < last) gl = key < gl ? key : gl;
         if (j >= 1) gr = key < gr ? key : gr;
     }

@@ -67,6 +67,7 @@ typedef struct cdbg_stats_t {
     uint64_t n_launch_scan, n_launch_count, n_launch_compact;   /* workgroups launched */
     uint64_t n_multipass_partitions; /* partitions whose distinct k-mers did not fit one LDS pass (multi-pass kernel) */
     uint64_t n_tiles_overlapped;     /* scan tiles processed while the input was still arriving (cdbg_expect_input) */
+    uint64_t n_split_buckets;        /* buckets that no LDS tier of the compaction could take and that were split by sub-minimizer (k_split.h) */
     uint64_t n_glue_rounds;          /* multi-GPU sharded glue: query / reply rounds of the distributed list ranking (0: single GPU, or
                                         the replicated exchange -- emit_replicated, or closed chains across ranks) */
 } cdbg_stats_t;
@@ -81,6 +82,10 @@ typedef struct cdbg_stats_t {
 
 int  cdbg_create(const cdbg_params* params, cdbg_ctx** out);
 void cdbg_destroy(cdbg_ctx* ctx);
+/* cdbg_destroy leaves the context's largest buffer (the super-k-mer record region, 75 GB at config 3) with the process, one per
+ * device, and the next context on that device adopts it: the read scan is sensitive to the physical placement of that region, and
+ * every free + re-allocation made it slower.  cdbg_release_cached returns it to the driver. */
+int cdbg_release_cached(void);
 const char* cdbg_last_error(void);
 
 /* Input.  Host ASCII, caller-owned, borrowed for the call; may be called repeatedly.

@@ -294,14 +294,26 @@ def test_config5_shape_long_reads_k127(hip):
     assert sum(kc for _, kc in ut) == sum(c for _, c in solid)
     # the size that overflowed: ~450 entries per bucket over 16384 buckets, so each of the three compaction
     # launches runs its full complement of persistent workgroups while the traveller-based bounds are tiny
-    g = bcalm_amd.Graph(k, 2, lib=hip, log2_partitions=14)
-    g.generate_reads(200000, 1000, 5)
-    g.run()
-    st = g.stats()
-    ut = g.unitigs()
-    g.close()
-    assert st["n_big_partitions"] > 3000
-    assert sum(len(s) - k + 1 for s, _ in ut) == st["n_solid"] and len(ut) == st["n_unitigs"]
+    # (the buckets no LDS tier takes: through the second-level split, k_split.h -- and, with CDBG_NO_SPLIT, through the HBM-table tier)
+    from parity import assert_verified
+    digests = []
+    for no_split in (False, True):
+        if no_split:
+            os.environ["CDBG_NO_SPLIT"] = "1"
+        try:
+            g = bcalm_amd.Graph(k, 2, lib=hip, log2_partitions=14)
+            g.generate_reads(200000, 1000, 5)
+            g.run()
+            st = g.stats()
+            ut = g.unitigs()
+            assert_verified(g)
+            digests.append(g.digest()["set_digest"])
+            g.close()
+        finally:
+            os.environ.pop("CDBG_NO_SPLIT", None)
+        assert (st["n_big_partitions"] > 3000) if no_split else (st["n_split_buckets"] > 3000 and st["n_big_partitions"] < 50), st
+        assert sum(len(s) - k + 1 for s, _ in ut) == st["n_solid"] and len(ut) == st["n_unitigs"]
+    assert digests[0] == digests[1]
 
 
 def test_parity_one_million_reads(oracle, oracle_1m, hip):

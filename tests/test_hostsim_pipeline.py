@@ -215,6 +215,44 @@ def test_count_tiers(oracle, sim, k, glen, mode, monkeypatch):
     assert got["stats"]["n_multipass_partitions"] == (0 if small else 1)
 
 
+@pytest.mark.parametrize("k,cfg,n_reads,read_len,log_np,part_min", [(31, 3 | 0x100, 3000, 150, 6, None), (31, 3, 3000, 150, 5, None), (55, 4 | 0x100, 1500, 150, 4, None),
+                                                                     (127, 5 | 0x100, 200, 1000, 3, None), (21, 3 | 0x100, 3000, 150, 6, 1), (64, 4 | 0x100, 1500, 150, 4, 1)])
+def test_single_pass_scan_into_estimated_regions(oracle, sim, k, cfg, n_reads, read_len, log_np, part_min, monkeypatch):
+    """CDBG_SCAN_MODE=var: the record layout of skewed inputs -- one scan pass into regions of their own size per partition,
+    estimated from a sampled histogram; with CDBG_PART_CAP=1 the estimate is made useless on purpose (every busy partition
+    spills and is repaired on the device).  Same solid set and unitigs as the oracle"""
+    monkeypatch.setenv("CDBG_SCAN_MODE", "var")
+    if part_min:
+        monkeypatch.setenv("CDBG_PART_CAP", str(part_min)); monkeypatch.setenv("CDBG_VAR_SCALE", "0.02")
+    text = oracle.synth_reads(n_reads, read_len, cfg)
+    assert_parity(oracle, sim, text, k, 2, log2_partitions=log_np)
+    assert_parity(oracle, sim, text, k, 1, log2_partitions=log_np)
+
+
+@pytest.mark.parametrize("k,glen,log_np", [(15, 6000, 0), (31, 9000, 1), (32, 6000, 0), (55, 5000, 0), (96, 4000, 1), (127, 4000, 0)])
+@pytest.mark.parametrize("split", [True, False])
+def test_second_level_bucket_split(oracle, sim, k, glen, log_np, split, monkeypatch):
+    """buckets that no LDS tier of the compaction takes (thousands of solid k-mers: a random stretch, a two-letter
+    low-complexity stretch, an inverted and a direct repeat, a homopolymer run, all in one or two buckets) are re-bucketed by
+    sub-minimizer and go through the wave tier again (k_split.h); with CDBG_NO_SPLIT the HBM-table tier takes them.
+    Same unitigs either way, and the device-side definition check holds"""
+    from bcalm_amd import api
+    from parity import assert_verified
+    if not split:
+        monkeypatch.setenv("CDBG_NO_SPLIT", "1")
+    rng = random.Random(glen + k)
+    comp = str.maketrans("ACGT", "TGCA")
+    g = "".join(rng.choice("ACGT") for _ in range(glen))
+    low = "".join(rng.choice("AT") for _ in range(glen // 3))
+    text = "\n".join([g, low, g[300:300 + 3 * k][::-1].translate(comp) + "A" * (2 * k) + g[700:700 + 2 * k], g[100:100 + 2 * k]]) + "\n"
+    got = assert_parity(oracle, sim, text, k, 1, log2_partitions=log_np)
+    st = got["stats"]
+    # (n_big_partitions counts the HBM-table fallbacks of count AND compact; a sub-bucket may still need one: short minimizers of a two-letter stretch collide)
+    assert (st["n_split_buckets"] >= 1) == split and (split or st["n_big_partitions"] >= 1), st
+    gg = api.Graph(k, 1, lib=sim, log2_partitions=log_np)
+    gg.push_text(text); gg.run(); assert_verified(gg); gg.close()
+
+
 @pytest.mark.parametrize("k,m", [(31, 16), (21, 6), (25, 10), (31, 10), (17, 16), (55, 16), (63, 16), (33, 15), (45, 12), (63, 8), (71, 16), (127, 16)])
 def test_scan_window_variants(oracle, sim, k, m):
     """every (k, m) shape of the register-window scan: the 15-key specialisation (k-m == 15, with and without a
