@@ -1,0 +1,528 @@
+// host_count.h -- libcdbg.so, host side of stage 1: record placement (capped / estimated /
+// exact regions), the streaming scan, the record exchange of sharded reads, the count tiers.  Included by cdbg_impl.cpp only.
+#pragma once
+
+namespace {
+
+// the scan kernel for this k / m / mode on the context's stream (persistent grid: resident workgroups)
+template <int W, int MODE>
+void launch_scan_mode(cdbg_ctx* c, ScanParams& sp, uint64_t grid) {
+    hipStream_t s = c->stream;
+    const bool fast_scan = c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX;
+    sp.n_tiles = grid;
+    if (grid == 0) return;                                   // (a rank without reads)
+    // compile-time minimizer windows (k - m): the k = 31 family m = 16 .. 12 and k = 55, m = 16 (config 4)
+#define CDBG_SCAN_WNT(WW, WNT_)                                                                                                  \
+    if (fast_scan && W == WW && c->k - c->m == WNT_) {                                                                           \
+        CDBG_LAUNCH((k_scan_fast<W, MODE, W == WW ? WNT_ : 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, W == WW ? WNT_ : 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp); \
+        return;                                                                                                                  \
+    }
+    CDBG_SCAN_WNT(1, 15) CDBG_SCAN_WNT(1, 16) CDBG_SCAN_WNT(1, 17) CDBG_SCAN_WNT(1, 18) CDBG_SCAN_WNT(1, 19) CDBG_SCAN_WNT(2, 39)
+#undef CDBG_SCAN_WNT
+    if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE, 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);
+    else CDBG_LAUNCH((k_scan<W, MODE>), std::min<uint64_t>(grid, resident_grid(k_scan<W, MODE>, SCAN_THREADS, SCAN_GRID)), SCAN_THREADS, s, sp);
+}
+inline uint64_t scan_tile_bytes(const cdbg_ctx* c) { return (c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX) ? (uint64_t)SCANF_TILE : (uint64_t)SCAN_TILE; }
+void scan_params_base(cdbg_ctx* c, ScanParams& sp) {
+    sp.reads = c->reads.p; sp.nbytes = c->nbytes; sp.nbytes_padded = c->nbytes_padded;
+    sp.k = c->k; sp.m = c->m; sp.log_np = c->log_np; sp.rank_bits = c->rank_bits; sp.rank = c->prm.rank;
+    sp.part_count = c->part_count.p; sp.part_cursor = c->part_cursor.p; sp.records = nullptr; sp.stats = c->dstats.p;
+    sp.tile_stride = 1; sp.tile_offset = 0; sp.error = c->derr.p;
+}
+// capacity of a partition region from a sampled histogram (single-pass capped layout)
+void capped_capacities(double mean, uint64_t NPL, uint32_t& part_cap, uint64_t& spill_cap) {
+    part_cap = (uint32_t)(mean * 2.5 + 8.0 * std::sqrt(mean + 1.0) + 16.0);
+    part_cap = (part_cap + 7u) & ~7u;
+    if (const char* e = getenv("CDBG_PART_CAP")) part_cap = (uint32_t)std::max(1, atoi(e));   // test knob: force spills
+    spill_cap = std::max<uint64_t>((uint64_t)(mean * (double)NPL / 32.0), 65536);
+}
+
+// ---------------------------------------------------------------------------------------
+// Streaming scan: with cdbg_expect_input() the library knows the input volume before the last byte has
+// arrived, so partitioning and region capacities are fixed from the first ~128 MB that landed and the single-pass scan
+// runs on the tiles that are complete while the host is still parsing / copying the rest.
+// ---------------------------------------------------------------------------------------
+template <int W>
+int stream_scan_advance(cdbg_ctx* c) {
+    constexpr int RW = RecFmt<W>::RW;
+    hipStream_t s = c->stream;
+    const uint64_t landed = c->n_dev & ~15ull;
+    if (!c->ss_on) {
+        // (test knobs: CDBG_STREAM_MIN_BYTES / CDBG_STREAM_BATCH_TILES shrink the thresholds to simulator sizes)
+        const char* emin = getenv("CDBG_STREAM_MIN_BYTES");
+        const uint64_t min_bytes = emin ? strtoull(emin, nullptr, 10) : (128ull << 20);
+        if (landed < std::min<uint64_t>(c->expect_bytes / 2, min_bytes)) return CDBG_OK;
+        configure(c, c->expect_bytes);
+        const uint64_t TB = scan_tile_bytes(c);
+        const uint64_t tiles_now = landed > TB + 8192 ? (landed - 8192) / TB : 0;
+        const uint64_t tiles_exp = (c->expect_bytes + TB - 1) / TB;
+        if (!emin && (tiles_now < 1024 || tiles_exp <= 8192)) return CDBG_OK;    // small input: count decides
+        if (tiles_now < 1) return CDBG_OK;
+        const uint64_t NPL = c->n_local_parts;
+        CK(c->part_count.alloc(NPL, true)); CK(c->part_off.alloc(NPL + 1, false)); CK(c->part_cursor.alloc(NPL, false));
+        CK(c->dstats.alloc(32, true)); CK(c->derr.alloc(4, true)); CK(c->cursors.alloc(8, true));
+        HIPCK(hipStreamSynchronize(c->copy_stream));                               // the sample reads what has landed
+        ScanParams sp{}; c->nbytes = landed; c->nbytes_padded = landed; scan_params_base(c, sp);
+        const uint64_t stride = std::min<uint64_t>(64, std::max<uint64_t>(1, tiles_now / 2048));
+        const uint64_t ns = (tiles_now + stride - 1) / stride;
+        sp.tile_stride = (uint32_t)stride;
+        launch_scan_mode<W, SCAN_HIST>(c, sp, ns);
+        CK(exscan_u32(c, c->part_count.p, c->part_off.p, NPL));
+        uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPL, &sample_records));
+        const double mean = (double)sample_records * (double)tiles_exp / (double)ns / (double)NPL;
+        capped_capacities(mean, NPL, c->ss_part_cap, c->ss_spill_cap);
+        if ((double)c->ss_part_cap * (double)NPL * RW * 8.0 > 200e9) { c->expect_bytes = 0; return CDBG_OK; }   // would not fit: no streaming
+        CK(c->records.alloc((uint64_t)c->ss_part_cap * NPL * RW, false));
+        CK(c->spill_recs.alloc(c->ss_spill_cap * RW, false)); CK(c->spill_part.alloc(c->ss_spill_cap, false));
+        HIPCK(hipMemsetAsync(c->part_count.p, 0, NPL * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+        c->ss_on = true; c->ss_done = 0;
+    }
+    const uint64_t TB = scan_tile_bytes(c);
+    const uint64_t tiles_now = landed > TB + 8192 ? (landed - 8192) / TB : 0;      // tiles whose halo has landed as well
+    const char* ebt = getenv("CDBG_STREAM_BATCH_TILES");
+    if (tiles_now < c->ss_done + (ebt ? strtoull(ebt, nullptr, 10) : 32768ull)) return CDBG_OK;   // batches of >= 128 MB
+    // the kernel must see the bytes: order the compute stream behind the copies enqueued so far
+    hipEvent_t ev; HIPCK(hipEventCreate(&ev));
+    HIPCK(hipEventRecord(ev, c->copy_stream)); HIPCK(hipStreamWaitEvent(s, ev, 0)); (void)hipEventDestroy(ev);
+    ScanParams sp{}; c->nbytes = landed; c->nbytes_padded = landed; scan_params_base(c, sp);
+    sp.records = c->records.p; sp.part_cap = c->ss_part_cap; sp.part_fill = c->part_count.p;
+    sp.spill_recs = c->spill_recs.p; sp.spill_part = c->spill_part.p; sp.spill_cursor = c->cursors.p + 6; sp.spill_cap = c->ss_spill_cap;
+    sp.tile_offset = (uint32_t)c->ss_done;
+    launch_scan_mode<W, SCAN_EMIT_CAPPED>(c, sp, tiles_now - c->ss_done);
+    c->ss_done = tiles_now;
+    return CDBG_OK;
+}
+int stream_scan_dispatch(cdbg_ctx* c) {
+    switch (c->W) { case 1: return stream_scan_advance<1>(c); case 2: return stream_scan_advance<2>(c); case 3: return stream_scan_advance<3>(c); default: return stream_scan_advance<4>(c); }
+}
+
+template <int W>
+int count_impl(cdbg_ctx* c) {
+    constexpr int RW = RecFmt<W>::RW;
+    constexpr int TS = Cfg<W>::TSC;
+    const bool multi_ctx = c->prm.world_size > 1 || c->force_multi;
+    const int world = c->prm.world_size;
+    if (multi_ctx && !c->have_tr) return fail(CDBG_E_STATE, "world_size %d but no transport: call cdbg_comm_init_rccl or cdbg_set_transport first", world);
+    int rc_in = upload_pending(c);
+    if (rc_in == CDBG_OK && (!c->reads.p || (c->nbytes == 0 && !multi_ctx))) rc_in = fail(CDBG_E_STATE, "no reads: call cdbg_push_reads/cdbg_push_text/cdbg_generate_reads first");
+    if (!multi_ctx) CK(rc_in);
+    // multi-GPU, reads SHARDED over the ranks (X1): the scan fills the partitions of every rank and the records travel to
+    // their owners; every rank must choose the same partitioning, so the input volume that drives configure() is the sum
+    // over the ranks.  Reads REPLICATED (X0): every rank scans the whole text for its own partitions, nothing travels.
+    const bool multi = multi_ctx && !c->prm.reads_replicated;
+    uint64_t total_bytes = c->nbytes;
+    if (multi_ctx) {
+        // one small all-gather: every rank's input status (a rank-local failure stops all ranks together) and byte count
+        const std::string mine_err = rc_in != CDBG_OK ? g_err : std::string();
+        std::vector<uint64_t> all(2 * (size_t)world); const uint64_t mine[2] = { (uint64_t)(int64_t)rc_in, c->nbytes };
+        if (c->tr.all_gather_u64(c->tr.user, mine, all.data(), 2) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
+        if (rc_in != CDBG_OK) { g_err = mine_err; return rc_in; }
+        for (int r = 0; r < world; ++r) if (all[2 * r]) return fail(CDBG_E_INTERNAL, "count: input: rank %d reported error %lld; all ranks stop", r, (long long)(int64_t)all[2 * r]);
+        if (multi) { total_bytes = 0; for (int r = 0; r < world; ++r) total_bytes += all[2 * r + 1]; }
+        else for (int r = 0; r < world; ++r) if (all[2 * r + 1] != mine[1]) return fail(CDBG_E_PARAM, "reads_replicated: the ranks hold different texts (%llu vs %llu bytes)", (unsigned long long)mine[1], (unsigned long long)all[2 * r + 1]);
+        if (total_bytes == 0) return fail(CDBG_E_STATE, "no reads on any rank");
+    }
+    if (!c->ss_on) configure(c, total_bytes);             // (a streaming scan fixed the partitioning from the announced volume)
+    const uint64_t NPL = c->n_local_parts;
+    const uint64_t NPS = multi ? (NPL << c->rank_bits) : NPL;    // partition slots the scan fills: all of them when the reads are sharded
+    hipStream_t s = c->stream;
+    HostMarks hm;
+    Timer t_total; CK(t_total.start(s));
+
+    if (!c->ss_on) {
+        CK(c->part_count.alloc(NPS, true));
+        CK(c->part_off.alloc(NPS + 1, false));
+        CK(c->part_cursor.alloc(NPS, false));
+        CK(c->dstats.alloc(32, true));
+        CK(c->derr.alloc(4, true));
+        CK(c->cursors.alloc(8, true));
+    }
+
+    hm.mark("count: allocations");
+    ScanParams sp{};
+    scan_params_base(c, sp);
+    sp.emit_all = multi ? 1u : 0u; sp.npl = (uint32_t)NPL;
+    // instruction-lean scan when the window fits registers; generic LDS-doubling scan otherwise
+    const bool fast_scan = c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX;
+    const uint64_t tiles = fast_scan ? (c->nbytes + SCANF_TILE - 1) / SCANF_TILE : (c->nbytes + SCAN_TILE - 1) / SCAN_TILE;
+    c->st.n_launch_scan = tiles;
+#define LAUNCH_SCAN(MODE, GRID) launch_scan_mode<W, MODE>(c, sp, (GRID))
+    auto exscan = [&](const uint32_t* counts) -> int {       // counts -> part_off (exclusive), part_off[NPS] = total
+        return exscan_u32(c, counts, c->part_off.p, NPS);
+    };
+
+    // Record placement.  exact : histogram pass + emit pass at exact offsets (two scans, zero slack).
+    //                    capped: ONE scan into fixed-capacity partition regions sized from a sampled
+    //                            histogram; the rare records that do not fit go to a spill list and their
+    //                            partitions are repaired (gathered contiguously) before counting.
+    // (sharded reads: the exact layout is what travels -- no slack on the wire; a single-pass scan into capped regions is
+    //  squeezed into it by k_pack_regions, which costs one pass over the rank's records instead of a second pass over its reads)
+    bool capped = tiles > 8192;
+    if (const char* e = getenv("CDBG_SCAN_MODE")) { if (!strcmp(e, "exact")) capped = false; else if (!strcmp(e, "capped")) capped = true; }
+    if (tiles == 0) capped = false;                          // (a rank without reads: nothing to sample)
+    // var: ONE pass into regions of their own size per partition, estimated from a denser sample -- what a skewed input gets instead
+    // of the exact two-pass layout (CDBG_SCAN_MODE=var: test knob)
+    bool var = false;
+    if (const char* e = getenv("CDBG_SCAN_MODE")) { if (!strcmp(e, "var") && tiles && !multi) { var = true; capped = false; } }
+    uint64_t n_records = 0, hs[2] = {0, 0};
+    uint32_t part_cap = 0; uint64_t n_spill = 0; bool packed_exact = false;
+    uint64_t n_spilled_parts = 0;                            // partitions whose region overflowed (capped mode): counted from gathered copies
+    Timer t;
+    uint64_t spill_cap = 0;
+    if (c->ss_on) capped = true;                             // tiles [0, ss_done) were scanned while the input was arriving
+    if (capped) {
+        bool fits = true;
+        if (c->ss_on) { part_cap = c->ss_part_cap; spill_cap = c->ss_spill_cap; }
+        else {
+            CK(t.start(s));
+            const uint64_t stride = std::min<uint64_t>(64, std::max<uint64_t>(1, tiles / 4096));
+            const uint64_t ns = (tiles + stride - 1) / stride;
+            sp.tile_stride = (uint32_t)stride;
+            LAUNCH_SCAN(SCAN_HIST, ns);
+            CK(exscan(c->part_count.p));
+            uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPS, &sample_records));
+            // the fullest partition of the sample: a skewed input (repeats, low complexity, coverage peaks) puts far more
+            // into some partitions than any capacity covers; the capped pass would then hammer a few fill counters and spill
+            // (145 ms at the hostile config-3 line before falling back) -- such inputs go straight to the exact two-pass layout
+            HIPCK(hipMemsetAsync(c->dstats.p + 31, 0, sizeof(uint64_t), s));
+            CDBG_LAUNCH(k_max_u32, std::min<uint64_t>((NPS + 255) / 256, 4096), 256, s, (const uint32_t*)c->part_count.p, NPS, c->dstats.p + 31);
+            uint64_t sample_max = 0; CK(read_u64(c->dstats.p + 31, &sample_max));
+            CK(t.stop(&c->st.ms_scan_hist));
+            const double mean = (double)sample_records * (double)tiles / (double)ns / (double)NPS;
+            capped_capacities(mean, NPS, part_cap, spill_cap);
+            if ((double)part_cap * (double)NPS * RW * 8.0 > 200e9) fits = false;       // would not fit: use the exact layout
+            // (at least 32 sampled records in that partition: with a mean of a few records per partition -- long reads, k = 127 --
+            //  the sampled maximum is Poisson noise, and scaling it up sent the config-5 share through two passes: 598 -> 662 ms)
+            else if (sample_max >= 32 && (double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && getenv("CDBG_SCAN_MODE") == nullptr) { fits = false; var = !multi; }
+            if (fits) {
+                if (c->xrecs.cap > c->records.cap) c->records.swap(c->xrecs);   // (sharded reads: the previous step left the region buffer there)
+                adopt_region(c->prm.device_id, c->records, (uint64_t)part_cap * NPS * RW);   // (what an earlier context of this process left behind)
+                CK(c->records.alloc((uint64_t)part_cap * NPS * RW, false));
+                CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
+                HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
+                HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+            }
+        }
+        if (!fits) capped = false;
+        else {
+            sp.tile_stride = 1; sp.records = c->records.p; sp.part_cap = part_cap; sp.part_fill = c->part_count.p;
+            sp.spill_recs = c->spill_recs.p; sp.spill_part = c->spill_part.p; sp.spill_cursor = c->cursors.p + 6; sp.spill_cap = spill_cap;
+            CK(t.start(s));
+            const uint64_t done = c->ss_on ? std::min<uint64_t>(c->ss_done, tiles) : 0;
+            sp.tile_offset = (uint32_t)done;
+            if (tiles > done) LAUNCH_SCAN(SCAN_EMIT_CAPPED, tiles - done);
+            sp.tile_offset = 0;
+            c->st.n_tiles_overlapped = done;
+            CK(exscan(c->part_count.p));                     // only for the total number of records
+            CK(t.stop(&c->st.ms_scan_emit));
+            hm.mark("count: sample + capped scan");
+            CK(read_u64(c->part_off.p + NPS, &n_records));
+            CK(read_u64(c->dstats.p, hs, 2));
+            CK(read_u64(c->cursors.p + 6, &n_spill));
+            uint32_t derr = 0; CK(read_u32(c->derr.p, &derr));
+            c->ss_on = false;                                // (the streamed part is accounted for; a re-count scans everything)
+            if (derr == 6 || n_spill > spill_cap || (multi && n_spill)) {   // estimate was off (very skewed input): exact layout instead
+                capped = false; HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t))); HIPCK(hipMemset(c->cursors.p + 6, 0, sizeof(uint64_t)));
+            } else if (multi) {
+                // what travels is the exact owner-major layout: squeeze the regions (part_off = exclusive scan of the fills)
+                CK(c->xrecs.alloc(std::max<uint64_t>(n_records, 1) * RW, false));
+                PackRegionParams pk{ c->records.p, c->part_count.p, c->part_off.p, NPS, part_cap, RW, c->xrecs.p };
+                CDBG_LAUNCH(k_pack_regions, std::min<uint64_t>((NPS + 3) / 4, 256 * 16), 256, s, pk);
+                c->records.swap(c->xrecs);
+                capped = false; packed_exact = true;
+            } else if (n_spill) {
+                // repair: gather region + spilled records of each spilled partition into one contiguous run (k_count.h)
+                RepairParams rp{};
+                rp.records = c->records.p; rp.spill_recs = c->spill_recs.p; rp.spill_part = c->spill_part.p; rp.n_spill = n_spill;
+                rp.part_fill = c->part_count.p; rp.npl = NPL; rp.part_cap = part_cap; rp.RW = RW;
+                CK(c->rp_flag.alloc(NPL, false)); CK(c->rp_idx.alloc(NPL + 1, false));
+                rp.flag = c->rp_flag.p; rp.ridx = c->rp_idx.p;
+                CDBG_LAUNCH(k_repair_flag, (NPL + 255) / 256, 256, s, rp);
+                CK(exscan_u32(c, c->rp_flag.p, c->rp_idx.p, NPL));
+                CK(read_u64(c->rp_idx.p + NPL, &n_spilled_parts));
+                const uint64_t nsp = n_spilled_parts;
+                CK(c->repair_part.alloc(nsp, false)); CK(c->rp_size.alloc(nsp, false)); CK(c->repair_off.alloc(nsp + 1, false)); CK(c->rp_fill.alloc(nsp, true));
+                rp.item_part = c->repair_part.p; rp.item_size = c->rp_size.p; rp.item_off = c->repair_off.p; rp.item_fill = c->rp_fill.p;
+                CDBG_LAUNCH(k_repair_list, (NPL + 255) / 256, 256, s, rp);
+                CK(exscan_u32(c, c->rp_size.p, c->repair_off.p, nsp));
+                uint64_t total = 0; CK(read_u64(c->repair_off.p + nsp, &total));
+                CK(c->repair_recs.alloc(total * RW, false));
+                rp.out = c->repair_recs.p;
+                CDBG_LAUNCH(k_repair_gather, nsp, 256, s, rp);
+                CDBG_LAUNCH(k_repair_scatter, std::min<uint64_t>((n_spill + 255) / 256, 1u << 16), 256, s, rp);
+            }
+        }
+    }
+    if (var && !capped && !packed_exact) {
+        const float ms_sample1 = c->st.ms_scan_hist;
+        CK(t.start(s));
+        HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+        const uint64_t stride = tiles >= 64 ? 4 : 1;         // a quarter of the tiles: +- 10 % on a partition of 400 records
+        const uint64_t ns = (tiles + stride - 1) / stride;
+        sp.tile_stride = (uint32_t)stride; sp.tile_offset = 0; sp.part_cap = 0; sp.var_limit = nullptr;
+        LAUNCH_SCAN(SCAN_HIST, ns);
+        CK(c->var_cap.alloc(NPS, false)); CK(c->var_pairs.alloc(2 * NPS, false));
+        uint64_t sample_records = 0;
+        CK(exscan(c->part_count.p)); CK(read_u64(c->part_off.p + NPS, &sample_records));
+        const double scale = (double)tiles / (double)ns, mean = (double)sample_records * scale / (double)NPS;
+        uint32_t cap_min = 0; capped_capacities(mean, NPS, cap_min, spill_cap);
+        VarParams vp{ c->part_count.p, c->var_cap.p, NPS, (float)scale, cap_min, c->part_off.p, c->part_cursor.p, c->var_pairs.p, c->dstats.p + 30 };
+        if (const char* e = getenv("CDBG_VAR_SCALE")) vp.scale = (float)atof(e);   // test knob (with CDBG_PART_CAP): regions far too small, so that partitions spill
+        CDBG_LAUNCH(k_var_caps, (NPS + 255) / 256, 256, s, vp);
+        CK(exscan_u32(c, c->var_cap.p, c->part_off.p, NPS));
+        uint64_t total_cap = 0; CK(read_u64(c->part_off.p + NPS, &total_cap));
+        float ms2 = 0; CK(t.stop(&ms2)); c->st.ms_scan_hist = ms_sample1 + ms2;
+        if ((double)total_cap * RW * 8.0 > 200e9) var = false;                     // would not fit: the exact layout
+        else {
+            spill_cap = std::max<uint64_t>(total_cap / 32, 65536);
+            CK(c->records.alloc(total_cap * RW, false));
+            CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
+            HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+            HIPCK(hipMemsetAsync(c->cursors.p + 6, 0, sizeof(uint64_t), s));
+            CK(t.start(s));
+            CDBG_LAUNCH(k_copy_u64, (NPS + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_cursor.p, NPS);
+            sp.tile_stride = 1; sp.records = c->records.p; sp.var_limit = c->part_off.p + 1;
+            sp.spill_recs = c->spill_recs.p; sp.spill_part = c->spill_part.p; sp.spill_cursor = c->cursors.p + 6; sp.spill_cap = spill_cap;
+            LAUNCH_SCAN(SCAN_EMIT, tiles);
+            sp.var_limit = nullptr;
+            CDBG_LAUNCH(k_var_finish, (NPS + 255) / 256, 256, s, vp);
+            CK(t.stop(&c->st.ms_scan_emit));
+            hm.mark("count: samples + single-pass scan into estimated regions");
+            CK(read_u64(c->dstats.p + 30, &n_records));
+            CK(read_u64(c->dstats.p, hs, 2));
+            CK(read_u64(c->cursors.p + 6, &n_spill));
+            uint32_t derr = 0; CK(read_u32(c->derr.p, &derr));
+            if (derr == 6 || n_spill > spill_cap) {          // the estimate was off by more than the spill list holds: exact layout
+                var = false; HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t))); HIPCK(hipMemset(c->cursors.p + 6, 0, sizeof(uint64_t)));
+            } else if (n_spill) {
+                RepairParams rp{};
+                rp.records = c->records.p; rp.spill_recs = c->spill_recs.p; rp.spill_part = c->spill_part.p; rp.n_spill = n_spill;
+                rp.part_fill = nullptr; rp.npl = NPL; rp.part_cap = 0; rp.RW = RW; rp.var_off = c->part_off.p; rp.var_cursor = c->part_cursor.p;
+                CK(c->rp_flag.alloc(NPL, false)); CK(c->rp_idx.alloc(NPL + 1, false));
+                rp.flag = c->rp_flag.p; rp.ridx = c->rp_idx.p;
+                CDBG_LAUNCH(k_repair_flag, (NPL + 255) / 256, 256, s, rp);
+                CK(exscan_u32(c, c->rp_flag.p, c->rp_idx.p, NPL));
+                CK(read_u64(c->rp_idx.p + NPL, &n_spilled_parts));
+                const uint64_t nsp = n_spilled_parts;
+                CK(c->repair_part.alloc(nsp, false)); CK(c->rp_size.alloc(nsp, false)); CK(c->repair_off.alloc(nsp + 1, false)); CK(c->rp_fill.alloc(nsp, true));
+                rp.item_part = c->repair_part.p; rp.item_size = c->rp_size.p; rp.item_off = c->repair_off.p; rp.item_fill = c->rp_fill.p;
+                CDBG_LAUNCH(k_repair_list, (NPL + 255) / 256, 256, s, rp);
+                CK(exscan_u32(c, c->rp_size.p, c->repair_off.p, nsp));
+                uint64_t total = 0; CK(read_u64(c->repair_off.p + nsp, &total));
+                CK(c->repair_recs.alloc(total * RW, false));
+                rp.out = c->repair_recs.p;
+                CDBG_LAUNCH(k_repair_gather, nsp, 256, s, rp);
+                CDBG_LAUNCH(k_repair_scatter, std::min<uint64_t>((n_spill + 255) / 256, 1u << 16), 256, s, rp);
+            }
+        }
+    }
+    if (!capped && !packed_exact && !var) {
+        sp.tile_stride = 1; sp.part_cap = 0;
+        HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+        // pass 1: histogram of records per partition
+        CK(t.start(s));
+        LAUNCH_SCAN(SCAN_HIST, tiles);
+        CK(exscan(c->part_count.p));
+        CK(t.stop(&c->st.ms_scan_hist));
+        CK(read_u64(c->part_off.p + NPS, &n_records));
+        CK(read_u64(c->dstats.p, hs, 2));
+        // pass 2: emit records at exact offsets
+        CK(c->records.alloc(std::max<uint64_t>(n_records, 1) * RW, false));
+        CK(t.start(s));
+        CDBG_LAUNCH(k_copy_u64, (NPS + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_cursor.p, NPS);
+        sp.records = c->records.p;
+        LAUNCH_SCAN(SCAN_EMIT, tiles);
+        CK(t.stop(&c->st.ms_scan_emit));
+    }
+    if (multi) {
+        // ---- record exchange: block r of the record array (the partitions rank r owns) goes to rank r ----
+        Timer tx; CK(tx.start(s));
+        CK(c->xcnt.alloc((uint64_t)world * NPL, false)); CK(c->xoff.alloc((uint64_t)world * (NPL + 1), false)); CK(c->xbase.alloc(world, false));
+        std::vector<uint64_t> so(world), sc(world), ro(world), rc(world);
+        // per-partition counts first (equal blocks of NPL counts)
+        for (int r = 0; r < world; ++r) { so[r] = (uint64_t)r * NPL * 4; sc[r] = NPL * 4; ro[r] = so[r]; rc[r] = sc[r]; }
+        if (!c->tr_ordered) HIPCK(hipStreamSynchronize(s));
+        if (c->tr.all_to_all_v(c->tr.user, c->part_count.p, so.data(), sc.data(), c->xcnt.p, ro.data(), rc.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_to_all_v (counts) failed");
+        c->comm_bytes += 2 * (uint64_t)(world - 1) * NPL * 4;
+        // where the records of sender s start inside its block, per partition; block sizes
+        std::vector<uint64_t> xb(world + 1, 0);
+        for (int r = 0; r < world; ++r) {
+            CK(exscan_u32(c, c->xcnt.p + (uint64_t)r * NPL, c->xoff.p + (uint64_t)r * (NPL + 1), NPL));
+            uint64_t tot = 0; CK(read_u64(c->xoff.p + (uint64_t)r * (NPL + 1) + NPL, &tot));
+            xb[r + 1] = xb[r] + tot;
+        }
+        HIPCK(hipMemcpy(c->xbase.p, xb.data(), world * sizeof(uint64_t), hipMemcpyHostToDevice));
+        CK(c->xrecs.alloc(std::max<uint64_t>(xb[world], 1) * RW, false));
+        for (int r = 0; r < world; ++r) {
+            uint64_t b[1], e[1]; CK(read_u64(c->part_off.p + (uint64_t)r * NPL, b)); CK(read_u64(c->part_off.p + (uint64_t)(r + 1) * NPL, e));
+            so[r] = b[0] * RW * 8; sc[r] = (e[0] - b[0]) * RW * 8;
+            ro[r] = xb[r] * RW * 8; rc[r] = (xb[r + 1] - xb[r]) * RW * 8;
+            if (r != c->prm.rank) c->comm_bytes += sc[r] + rc[r];
+        }
+        if (c->tr.all_to_all_v(c->tr.user, c->records.p, so.data(), sc.data(), c->xrecs.p, ro.data(), rc.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_to_all_v (records) failed");
+        // merge the blocks: partition lp = its segments in sender order
+        CK(c->part_count.alloc(NPL, false)); CK(c->part_off.alloc(NPL + 1, false));
+        SumCountParams scp{ c->xcnt.p, world, NPL, c->part_count.p };
+        CDBG_LAUNCH(k_sum_counts, (NPL + 255) / 256, 256, s, scp);
+        CK(exscan_u32(c, c->part_count.p, c->part_off.p, NPL));
+        n_records = xb[world];
+        CK(c->records.alloc(std::max<uint64_t>(n_records, 1) * RW, false));
+        HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+        MergeRecParams mp{ c->xcnt.p, c->xoff.p, c->xbase.p, world, NPL, RW, c->xrecs.p, c->part_off.p, c->records.p, c->dstats.p };
+        CDBG_LAUNCH(k_merge_records, std::min<uint64_t>((NPL + 3) / 4, 8192), 256, s, mp);
+        HIPCK(hipStreamSynchronize(s));
+        CK(read_u64(c->dstats.p, hs, 2));
+        float msx = 0; CK(tx.stop(&msx)); c->st.ms_exchange += msx;
+    }
+#undef LAUNCH_SCAN
+#ifdef CDBG_PROFILE_PHASES
+    { uint64_t ph[6]; CK(read_u64(c->dstats.p + 16, ph, 6)); fprintf(stderr, "k_scan phase ticks: load %llu keys %llu winmin %llu flags %llu collect %llu emit %llu\n", (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3], (unsigned long long)ph[4], (unsigned long long)ph[5]); }
+#endif
+    c->st.n_records = n_records; c->st.n_member_kmers = hs[0];
+    hm.mark("count: spill repair/exchange");
+
+    // count
+    // (slack: every persistent workgroup of every launch of the stage may strand one partly used chunk)
+    // (launches of the stage: one-pass tier 1, tier 2 of at most 256 workgroups, multi-pass retry, spill repair, HBM tables)
+    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + (4 * std::min<uint64_t>(NPL, PERSISTENT_GRID) + 256 + 5) * (uint64_t)COUNT_CHUNK;
+    CK(c->solid_keys.alloc(solid_cap * W, false));
+    CK(c->solid_cnt.alloc(solid_cap, false));
+    CK(c->solid_cursor.alloc(4, true));
+    CK(c->seg_off.alloc(NPL, true));
+    CK(c->seg_n.alloc(NPL, true));
+    CK(c->big_list.alloc(NPL, false));
+    CK(c->retry_list.alloc(NPL, false));
+    CK(c->big_count.alloc(4, true));                         // [0] partitions for the HBM pass, [1] partitions for the multi-pass kernel
+    HIPCK(hipMemset(c->dstats.p, 0, 32 * sizeof(uint64_t)));
+
+    CountParams cp{};
+    cp.records = c->records.p; cp.part_off = c->part_off.p; cp.part_list = nullptr;
+    if (capped) { cp.part_stride = part_cap; cp.part_fill = c->part_count.p; }
+    if (var) { cp.part_off = c->var_pairs.p; cp.part_pairs = 1u; }   // (regions of estimated size: begin / end per partition)
+    cp.k = c->k; cp.amin = (uint32_t)c->prm.abundance_min;
+    cp.solid_keys = c->solid_keys.p; cp.solid_cnt = c->solid_cnt.p; cp.solid_cap = solid_cap; cp.solid_cursor = c->solid_cursor.p;
+    cp.seg_off = c->seg_off.p; cp.seg_n = c->seg_n.p; cp.stats = c->dstats.p;
+    cp.big_list = c->big_list.p; cp.big_count = c->big_count.p; cp.error = c->derr.p;
+    hm.mark("count: solid buffers");
+    CK(t.start(s));
+    cp.n_items = (uint32_t)NPL; cp.max_passes = 64;
+    // one-pass kernel over all partitions; the ones whose distinct k-mers do not fit the LDS table at once come back on
+    // the retry list and go through the multi-pass kernel
+    {
+        // (admission by predicted fill: k_count_fast.h; one-word k-mers: off -- their second tier runs one workgroup per CU against three)
+        CountFastParams fp{ cp, c->retry_list.p, c->big_count.p + 1, count_fast_record_limit<W>(c->k), W == 1 ? 0u : W == 2 ? 177u : 200u };
+        if (const char* e = getenv("CDBG_FAST_SKIP_Q8")) fp.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
+        if (const char* e = getenv("CDBG_FAST_MAX_RECORDS")) fp.fast_max_records = std::min<uint32_t>(count_fast_record_limit<W>(c->k), (uint32_t)std::max(1, atoi(e)));   // dev knob
+        if (capped) CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, true>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, fp);
+        else CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, fp);
+    }
+    c->st.n_launch_count = NPL;
+    uint32_t nretry = 0;
+    HIPCK(hipStreamSynchronize(s));
+    hm.mark("count: tier 1");
+    CK(read_u32(c->big_count.p + 1, &nretry));
+    const uint32_t* retry_ptr = c->retry_list.p;
+    if (nretry && getenv("CDBG_NO_COUNT_TIER2") == nullptr) {
+        // second tier: the same one-pass kernel with a table twice the size (one workgroup per CU) over the retry list; at the
+        // config-5 share 6 % of the partitions -- a minimizer locus of long reads -- cost 250 of 590 ms in the multi-pass kernel
+        CK(c->retry_list2.alloc(nretry, false));
+        HIPCK(hipMemsetAsync(c->big_count.p + 2, 0, sizeof(uint32_t), s));
+        CountParams c2 = cp; c2.part_list = c->retry_list.p; c2.n_items = nretry;
+        // (three- and four-word k-mers: the admission rule here as well -- a partition predicted beyond 0.68 of the 4096 slots goes to
+        //  the multi-pass kernel untried: count 216 -> 201 ms at the config-5 share; two-word k-mers: no difference, off)
+        CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2, count_fast_record_limit<W>(c->k), W >= 3 ? 175u : 0u };
+        if (const char* e = getenv("CDBG_FAST_SKIP2_Q8")) fp2.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
+        // (multi-word k-mers: 1024 threads -- the table fills the CU's LDS either way, so the workgroup size IS the occupancy: 16
+        //  waves per CU instead of 8, second tier 81 -> 67 ms at the config-5 share, 24 -> 18 at the config-4 share)
+#ifndef CDBG_NT_TIER2
+#define CDBG_NT_TIER2 1024
+#endif
+        constexpr int NT2 = W == 1 ? Cfg<W>::NTC : CDBG_NT_TIER2;
+        if (capped) CDBG_LAUNCH((k_count_fast<W, 2 * TS, NT2, 3>), std::min<uint64_t>(nretry, 256), NT2, s, fp2);
+        else CDBG_LAUNCH((k_count_fast<W, 2 * TS, NT2, 2>), std::min<uint64_t>(nretry, 256), NT2, s, fp2);
+        HIPCK(hipStreamSynchronize(s));
+        CK(read_u32(c->big_count.p + 2, &nretry));
+        retry_ptr = c->retry_list2.p;
+    }
+    c->st.n_multipass_partitions = nretry;
+    if (nretry) {
+        CountParams rp1 = cp;
+        rp1.part_list = retry_ptr; rp1.n_items = nretry;
+        // (multi-word k-mers: the table of the second tier and 1024 threads -- half the passes at 16 waves per CU: 45 -> 39 ms at the config-5 share)
+        constexpr int TSG = W == 1 ? TS : 2 * TS, NTG = W == 1 ? Cfg<W>::NTC : 1024;
+        CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(nretry, W == 1 ? PERSISTENT_GRID : 256), NTG, s, rp1);
+    }
+    if (n_spilled_parts) {                                   // spilled partitions: count their gathered copies
+        CountParams rp2 = cp;
+        rp2.records = c->repair_recs.p; rp2.item_off = c->repair_off.p; rp2.part_list = c->repair_part.p; rp2.part_stride = 0;
+        rp2.n_items = (uint32_t)n_spilled_parts; rp2.max_passes = 4096;
+        if (const char* ev = getenv("CDBG_REPAIR_MAX_PASSES")) rp2.max_passes = (uint32_t)std::max(1, atoi(ev));   // (tests: a spilled partition that is deferred as well)
+        constexpr int TSG = W == 1 ? TS : 2 * TS, NTG = W == 1 ? Cfg<W>::NTC : 1024;
+        CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(rp2.n_items, W == 1 ? PERSISTENT_GRID : 256), NTG, s, rp2);
+    }
+    uint32_t nbig = 0;
+    HIPCK(hipStreamSynchronize(s));
+    hm.mark("count: tier 2 + multi-pass");
+    CK(read_u32(c->big_count.p, &nbig));
+    DBuf<uint64_t> g_keys, big_off; DBuf<uint32_t> g_cnt;
+    if (nbig) {                                              // partitions whose distinct k-mers overflow LDS
+        std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list.p, bl.data(), nbig));
+        std::sort(bl.begin(), bl.end());
+        std::vector<uint64_t> offs(nbig + 1, 0);
+        const uint64_t nmax = (uint64_t)RecFmt<W>::CAPB - c->k + 1;
+        // (records of every listed partition: one bulk copy of the fill / offset array when the list is long -- a skewed input
+        //  lists 10^4 partitions, and a synchronous 4-byte copy each cost 77 ms per step at the hostile config-3 line)
+        std::vector<uint32_t> h_fill; std::vector<uint64_t> h_off;
+        if (nbig > 64) {
+            if (capped) { h_fill.resize(NPL); CK(read_u32(c->part_count.p, h_fill.data(), NPL)); }
+            else if (var) { h_off.resize(2 * NPL); CK(read_u64(c->var_pairs.p, h_off.data(), 2 * NPL)); }
+            else { h_off.resize(NPL + 1); CK(read_u64(c->part_off.p, h_off.data(), NPL + 1)); }
+        }
+        for (uint32_t i = 0; i < nbig; ++i) {
+            uint64_t nrec_p;
+            if (!h_fill.empty()) nrec_p = h_fill[bl[i]];
+            else if (!h_off.empty()) nrec_p = var ? h_off[2 * (size_t)bl[i] + 1] - h_off[2 * (size_t)bl[i]] : h_off[bl[i] + 1] - h_off[bl[i]];
+            else if (capped) { uint32_t f = 0; CK(read_u32(c->part_count.p + bl[i], &f)); nrec_p = f; }
+            else if (var) { uint64_t po[2]; CK(read_u64(c->var_pairs.p + 2 * (size_t)bl[i], po, 2)); nrec_p = po[1] - po[0]; }
+            else { uint64_t po[2]; CK(read_u64(c->part_off.p + bl[i], po, 2)); nrec_p = po[1] - po[0]; }
+            const uint64_t occ = nrec_p * nmax;
+            offs[i + 1] = offs[i] + pow2_at_least(2 * occ + 4 * 256);
+        }
+        CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_cnt.alloc(offs[nbig], false));
+        CK(big_off.alloc(nbig + 1, false));
+        HIPCK(hipMemcpy(big_off.p, offs.data(), (nbig + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
+        CountParams bp = cp;
+        bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_cnt = g_cnt.p; bp.big_off = big_off.p;
+        bp.n_items = nbig; bp.max_passes = 1;
+        // (grid bounded: every workgroup reserves whole output chunks, the slack is sized for PERSISTENT_GRID)
+        CDBG_LAUNCH((k_count<W, TS, 256, true>), std::min<uint64_t>(nbig, PERSISTENT_GRID), 256, s, bp);
+        c->st.n_big_partitions += nbig;
+    }
+    CK(t.stop(&c->st.ms_count));
+    hm.mark("count: HBM-table partitions");
+    CK(check_device_error(c, "count"));
+    uint64_t cs[4]; CK(read_u64(c->dstats.p, cs, 4));
+#ifdef CDBG_PROFILE_PHASES
+    { uint64_t ph[16]; CK(read_u64(c->dstats.p + 8, ph, 16));
+      for (int w = 0; w < 2; ++w) fprintf(stderr, "k_count_fast phase cycles, %s wave, summed over WGs: loop-end->top %llu | wait own records + stage %llu | insert %llu | barrier A %llu | sweep %llu | barrier B %llu\n", w ? "last" : "first",
+          (unsigned long long)ph[8 * w + 0], (unsigned long long)ph[8 * w + 1], (unsigned long long)ph[8 * w + 2], (unsigned long long)ph[8 * w + 3], (unsigned long long)ph[8 * w + 4], (unsigned long long)ph[8 * w + 5]); }
+#endif
+    c->st.n_distinct = cs[0]; c->st.n_occurrences = cs[1]; c->st.n_solid = cs[2]; c->st.n_solid_travellers = cs[3];
+    CK(read_u64(c->solid_cursor.p, &c->n_solid_entries));
+    if (getenv("CDBG_DEBUG_SEGHIST")) {                      // dev aid: solid entries per bucket, log2 bins (stderr)
+        std::vector<uint32_t> sn(NPL); CK(read_u32(c->seg_n.p, sn.data(), NPL));
+        uint64_t nb[32] = {0}, ne[32] = {0};
+        for (uint64_t p = 0; p < NPL; ++p) { int b = 0; while ((1u << b) <= sn[p] && b < 31) ++b; ++nb[b]; ne[b] += sn[p]; }
+        for (int b = 0; b < 32; ++b) if (nb[b]) fprintf(stderr, "[seghist] entries < 2^%-2d : %10llu buckets %12llu entries\n", b, (unsigned long long)nb[b], (unsigned long long)ne[b]);
+    }
+    c->st.input_bytes = c->nbytes;
+    float ms = 0; CK(t_total.stop(&ms)); c->st.ms_total = ms;
+    c->stage = 1;
+    return CDBG_OK;
+}
+
+}  // namespace

@@ -1,0 +1,247 @@
+// host_glue.h -- libcdbg.so, host side of stage 3 and of what follows it: junction join, list
+// ranking, emission; links (row a10 / f1); the device-side check of the unitig definition.  Included by cdbg_impl.cpp only.
+#pragma once
+
+namespace {
+
+// Glue, first half: hash-join the piece ends on their junction (k-1)-mers -> link[end] = partner end.
+// sharded (multi-GPU, after xchg_*): this rank joins only the junctions whose key hash selects it --
+// 1/world of the device atomics -- and leaves the other ends at NONE; the caller combines the link arrays of all
+// ranks with an element-wise MAX all-reduce (every end is set by exactly one rank) before cdbg_glue.
+template <int W>
+int glue_join_impl(cdbg_ctx* c, bool sharded) {
+    if (c->stage < 2) return fail(CDBG_E_STATE, "cdbg_glue before cdbg_compact");
+    hipStream_t s = c->stream;
+    const uint64_t NP = c->n_pieces;
+    if (2 * NP >= 0x7FFFFFF0ULL) return fail(CDBG_E_INTERNAL, "too many pieces for 31-bit end ids (%llu)", (unsigned long long)NP);
+    const uint32_t NS = (uint32_t)(2 * NP);
+    Timer t; CK(t.start(s));
+    CK(c->link.alloc(NS, false));
+    HIPCK(hipMemsetAsync(c->link.p, 0xFF, (size_t)std::max<uint32_t>(NS, 1) * sizeof(uint32_t), s));
+    HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+    HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
+    const uint32_t world = sharded ? (uint32_t)c->prm.world_size : 1u;
+    const uint64_t n_mine = c->n_glog / world + (world > 1 ? (c->n_glog >> 6) + 1024 : 0);      // records this rank joins (estimate when sharded)
+    bool bucketed = (getenv("CDBG_GLUE_TABLE") == nullptr || c->direct_join) && c->n_glog > 0;
+    if (bucketed && c->direct_join) {                        // the buckets were filled by the compaction kernels
+        const uint64_t JB = 1ull << c->join_log_jb;
+        JoinBucketParams bp{ c->jfill.p, c->jrecs.p, (uint32_t)JB, c->link.p, c->dstats.p, nullptr, nullptr, 0, nullptr };
+        CDBG_LAUNCH((k_join_bucket<W>), std::min<uint64_t>((JB + 3) / 4, 256 * 16), JB_THREADS, s, bp);
+    } else if (bucketed) {
+        // bucketed join (k_glue.h): scatter the log into buckets of ~JB_CAP / 2 records, one wave joins a bucket in LDS
+        int log_jb = 0; while (((uint64_t)(JB_CAP / 2) << log_jb) < n_mine && log_jb < 26) ++log_jb;
+        const uint64_t JB = 1ull << log_jb;
+        CK(c->jfill.alloc(JB, false)); CK(c->jrecs.alloc(JB * JB_CAP * (W + 1), false));
+        HIPCK(hipMemsetAsync(c->jfill.p, 0, JB * sizeof(uint32_t), s));
+        JoinScatterParams sp{ c->glog_keys.p, c->glog_tag.p, c->n_glog, log_jb, c->jfill.p, c->jrecs.p, c->derr.p,
+                              world - 1, world > 1 ? (uint32_t)c->prm.rank : 0u };
+        CDBG_LAUNCH((k_join_scatter<W>), std::min<uint64_t>((c->n_glog + GLUE_THREADS - 1) / GLUE_THREADS, 1u << 16), GLUE_THREADS, s, sp);
+        JoinBucketParams bp{ c->jfill.p, c->jrecs.p, (uint32_t)JB, c->link.p, c->dstats.p, nullptr, nullptr, 0, nullptr };
+        CDBG_LAUNCH((k_join_bucket<W>), std::min<uint64_t>((JB + 3) / 4, 256 * 16), JB_THREADS, s, bp);
+        HIPCK(hipStreamSynchronize(s));
+        uint32_t e = 0; CK(read_u32(c->derr.p, &e));
+        if (e == 8) {                                        // a bucket overflowed (cannot happen with a sound hash): global table instead
+            bucketed = false;
+            HIPCK(hipMemsetAsync(c->link.p, 0xFF, (size_t)std::max<uint32_t>(NS, 1) * sizeof(uint32_t), s));
+            HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+            HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
+        }
+    }
+    if (!bucketed && c->n_glog) {
+        // fallback: one junction table in HBM (at most one junction per glue record)
+        CK(glue_table_slots(n_mine + n_mine / 4 + 1024, &c->glue_cap));
+        CK(c->glue_keys.alloc((uint64_t)c->glue_cap * W, false));
+        CK(c->glue_a.alloc(c->glue_cap, false)); CK(c->glue_b.alloc(c->glue_cap, false)); CK(c->glue_conf.alloc(c->glue_cap, false));
+        HIPCK(hipMemsetAsync(c->glue_keys.p, 0xFF, (uint64_t)c->glue_cap * W * sizeof(uint64_t), s));
+        HIPCK(hipMemsetAsync(c->glue_a.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->glue_b.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
+        HIPCK(hipMemsetAsync(c->glue_conf.p, 0, (uint64_t)c->glue_cap * sizeof(uint32_t), s));
+        GlueBuildParams bp{ c->glog_keys.p, c->glog_tag.p, c->n_glog, c->glue_keys.p, c->glue_a.p, c->glue_b.p, c->glue_conf.p, c->glue_cap - 1,
+                            world - 1, world > 1 ? (uint32_t)c->prm.rank : 0u };
+        CDBG_LAUNCH((k_glue_build<W>), std::min<uint64_t>((c->n_glog + GLUE_THREADS - 1) / GLUE_THREADS, MAX_GRID), GLUE_THREADS, s, bp);
+        GlueResolveParams gp{};
+        gp.keys = c->glue_keys.p; gp.a = c->glue_a.p; gp.b = c->glue_b.p; gp.conf = c->glue_conf.p;
+        gp.cap = c->glue_cap; gp.W = W; gp.link = c->link.p; gp.stats = c->dstats.p;
+        CDBG_LAUNCH(k_glue_resolve, std::min<uint64_t>((c->glue_cap + GLUE_THREADS - 1) / GLUE_THREADS, GLUE_RESOLVE_GRID), GLUE_THREADS, s, gp);
+    }
+    float ms = 0; CK(t.stop(&ms));
+    CK(check_device_error(c, "glue join"));
+    uint64_t gs = 0; CK(read_u64(c->dstats.p, &gs));
+    c->n_join_local = gs; c->st.ms_glue = ms; c->joined = true;
+    return CDBG_OK;
+}
+
+
+template <int W>
+int glue_impl(cdbg_ctx* c) {
+    if (c->stage < 2) return fail(CDBG_E_STATE, "cdbg_glue before cdbg_compact");
+    if ((c->prm.world_size > 1 || c->force_multi) && c->have_tr && !c->xchg_done && !c->joined) {
+        // multi-GPU.  Every rank emits its own unitigs (emit_replicated = 0): the sharded glue of k_dglue.h -- every record and
+        // every piece travels once.  emit_replicated = 1 (the CLI's rank 0 writes one file and needs the whole graph for the
+        // links), or closed chains across ranks: the replicated exchange -- pieces + junction log of all ranks to every rank.
+        if (!c->prm.emit_replicated && getenv("CDBG_GLUE_REPLICATED") == nullptr) {
+            const int rc = glue_sharded<W>(c);
+            if (rc != DG_FALLBACK) return rc;
+        }
+        CK(glue_exchange(c));
+    }
+    if (!c->joined) CK(glue_join_impl<W>(c, false));         // (cdbg_glue_join ran it already in the sharded flow)
+    hipStream_t s = c->stream;
+    const uint64_t NP = c->n_pieces;
+    const uint32_t NS = (uint32_t)(2 * NP);
+    const float ms_join = c->st.ms_glue;
+    HostMarks hm;
+    Timer t; CK(t.start(s));
+    DBuf<uint32_t>& flag = c->rank_flag; DBuf<uint4>& st_a = c->rank_a; DBuf<uint4>& st_b = c->rank_b;
+    CK(st_a.alloc(NS, false)); CK(st_b.alloc(NS, false));
+    CK(flag.alloc(4, true));
+    HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+    HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
+    uint32_t* const link_p = c->link.p;
+
+    uint64_t n_cycles_cut = 0;
+    const uint32_t gridS = (NS + GLUE_THREADS - 1) / GLUE_THREADS;
+    RankParams rp{};
+    uint4* fa_st = nullptr;                                  // final state array of the 16-byte ranking
+    const uint2* st8 = nullptr; uint4* hinfo = nullptr;      // what heads / emit read: 8-byte states, and the array for the per-head records
+    bool ranked = false;
+    if (NS) {
+        // usual case (no closed chains): doubling on 8-byte states, expanded once at the end.  The 8-byte
+        // state array (updated in place) lives in st_b; st_a takes the per-head records of heads / emit.
+        int max_rounds8 = 2; while ((1ull << (max_rounds8 - 1)) < NS) ++max_rounds8;
+        Rank8Params r8{ NS, link_p, c->piece_n.p, reinterpret_cast<uint2*>(st_b.p), flag.p };
+        CDBG_LAUNCH(k_rank8_init, gridS, GLUE_THREADS, s, r8);
+        for (int r = 0; r < max_rounds8 && !ranked; ++r) {
+            HIPCK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), s));
+            CDBG_LAUNCH(k_rank8_jump, gridS, GLUE_THREADS, s, r8);
+            HIPCK(hipStreamSynchronize(s));
+            uint32_t ch = 0; CK(read_u32(flag.p, &ch));
+            if (!ch) ranked = true;
+        }
+        if (ranked) { st8 = r8.a; hinfo = st_a.p; }
+    }
+    if (NS && !ranked) {                                     // closed chains: the 16-byte version elects cut points
+        int max_rounds = 2; while ((1ull << (max_rounds - 1)) < NS) ++max_rounds;
+        for (int pass = 0; pass < 2; ++pass) {
+            rp.n_states = NS; rp.link = link_p; rp.piece_n = c->piece_n.p;
+            rp.st_a = st_a.p; rp.st_b = st_b.p; rp.changed = flag.p;
+            CDBG_LAUNCH(k_rank_init, gridS, GLUE_THREADS, s, rp);
+            bool converged = false;
+            for (int r = 0; r < max_rounds; ++r) {
+                HIPCK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), s));
+                CDBG_LAUNCH(k_rank_jump, gridS, GLUE_THREADS, s, rp);
+                std::swap(rp.st_a, rp.st_b);
+                HIPCK(hipStreamSynchronize(s));
+                uint32_t ch = 0; CK(read_u32(flag.p, &ch));
+                if (!ch) { converged = true; break; }
+            }
+            fa_st = rp.st_a;
+            if (converged) break;
+            if (pass == 1) return fail(CDBG_E_INTERNAL, "list ranking did not converge after cutting cycles");
+            // closed chains: cut each at its smallest piece, then rank again
+            HIPCK(hipMemsetAsync(flag.p, 0, sizeof(uint32_t), s));
+            CutParams cu{ NS, rp.st_a, link_p, flag.p };
+            CDBG_LAUNCH(k_cut_cycles, gridS, GLUE_THREADS, s, cu);
+            HIPCK(hipStreamSynchronize(s));
+            uint32_t nc = 0; CK(read_u32(flag.p, &nc)); n_cycles_cut += nc;
+        }
+    }
+    if (NS && !st8) {                                        // (16-byte ranking: narrow its final states into the other buffer)
+        uint4* const other = (fa_st == st_a.p) ? st_b.p : st_a.p;
+        RankNarrowParams np{ NS, fa_st, reinterpret_cast<uint2*>(other) };
+        CDBG_LAUNCH(k_rank_narrow, gridS, GLUE_THREADS, s, np);
+        st8 = reinterpret_cast<const uint2*>(other); hinfo = fa_st;
+    }
+    // unitig heads + emission
+    const uint64_t ucap = std::max<uint64_t>(NP, 1);
+    const uint64_t ocap = std::max<uint64_t>(c->n_piece_bases, 1);
+    CK(c->unitig_off.alloc(ucap, false)); CK(c->unitig_len.alloc(ucap, false)); CK(c->unitig_kc.alloc(ucap, false));
+    CK(c->unitig_bases.alloc(ocap + 64, false));             // (+ 64: the 2-bit packing pass reads whole 64-base chunks)
+    if (c->prm.all_abundance_counts) CK(c->unitig_ab.alloc(ocap, false));
+    HIPCK(hipMemsetAsync(c->cursors.p + 2, 0, 2 * sizeof(uint64_t), s));
+    if (NS) {
+        HeadParams hp{};
+        hp.n_states = NS; hp.k = c->k; hp.link = link_p; hp.st = st8; hp.hinfo = hinfo;
+        hp.unitig_off = c->unitig_off.p; hp.unitig_len = c->unitig_len.p; hp.unitig_kc = c->unitig_kc.p;
+        hp.unitig_cap = ucap; hp.out_cap = ocap; hp.n_unitigs = c->cursors.p + 2; hp.out_cursor = c->cursors.p + 3; hp.error = c->derr.p;
+        hp.own_lo = 0; hp.own_hi = NS;
+        if (c->prm.world_size > 1 && !c->prm.emit_replicated && c->xchg_done) { hp.own_lo = (uint32_t)(2 * c->piece_lo); hp.own_hi = (uint32_t)(2 * c->piece_hi); }
+        CDBG_LAUNCH(k_unitig_heads, (NS + HEADS_PER_WG - 1) / HEADS_PER_WG, GLUE_THREADS, s, hp);
+        EmitParams ep{};
+        ep.n_pieces = (uint32_t)NP; ep.k = c->k; ep.st = st8; ep.hinfo = hp.hinfo;
+        ep.piece_n = c->piece_n.p; ep.piece_kc = c->piece_kc.p; ep.piece_boff = c->piece_boff.p; ep.piece_bases = c->piece_bases.p;
+        ep.unitig_kc = c->unitig_kc.p; ep.out = c->unitig_bases.p;
+        ep.piece_ab = c->prm.all_abundance_counts ? c->piece_ab.p : nullptr; ep.unitig_ab = c->unitig_ab.p;
+        CDBG_LAUNCH(k_emit, (uint32_t)((NP + GLUE_THREADS - 1) / GLUE_THREADS), GLUE_THREADS, s, ep);
+    }
+    { uint64_t cur[2]; CK(read_u64(c->cursors.p + 2, cur, 2)); c->n_unitigs = cur[0]; c->unitig_total = cur[1]; }
+    CK(pack_unitigs(c));
+    float ms_fin = 0; CK(t.stop(&ms_fin));
+    hm.mark("glue: rank + heads + emit");
+    c->st.ms_glue = ms_join + ms_fin;
+    CK(check_device_error(c, "glue"));
+    c->joined = false;
+    c->st.n_glue_joined = c->n_join_local; c->st.n_unitigs = c->n_unitigs; c->st.unitig_bases = c->unitig_total; c->st.n_cycles += n_cycles_cut;
+    c->st.ms_total += c->st.ms_glue;
+    c->stage = 3;
+    return CDBG_OK;
+}
+
+template <int W>
+int link_impl(cdbg_ctx* c) {
+    if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_link before cdbg_glue");
+    hipStream_t s = c->stream;
+    const uint64_t U = c->n_unitigs, NE = 2 * U;
+    // (k_links.h packs a slot index with a flag in bit 30: the table may have at most 2^30 slots)
+    if (pow2_at_least(4 * U + 64) > (1ull << 30)) return fail(CDBG_E_INTERNAL, "too many unitigs (%llu) for the 30-bit slots of the link table", (unsigned long long)U);
+    const uint32_t cap = (uint32_t)pow2_at_least(4 * U + 64);
+    DBuf<uint64_t> lk_keys; DBuf<uint32_t> lk_cnt, lk_ends, end_slot, deg;
+    CK(lk_keys.alloc((uint64_t)cap * W, false)); CK(lk_cnt.alloc((uint64_t)cap * 2, true));
+    CK(lk_ends.alloc((uint64_t)cap * 2 * LINK_PER_FLAG, false)); CK(end_slot.alloc(NE, false)); CK(deg.alloc(NE, false));
+    HIPCK(hipMemsetAsync(lk_keys.p, 0xFF, (uint64_t)cap * W * sizeof(uint64_t), s));
+    CK(c->link_off.alloc(NE + 1, true));
+    LinkParams lp{};
+    lp.n_unitigs = U; lp.k = c->k; lp.unitig_off = c->unitig_off.p; lp.unitig_len = c->unitig_len.p; lp.bases = c->unitig_bases.p;
+    lp.lk_keys = lk_keys.p; lp.lk_cnt = lk_cnt.p; lp.lk_ends = lk_ends.p; lp.lk_mask = cap - 1;
+    lp.end_slot = end_slot.p; lp.deg = deg.p;
+    c->n_links = 0;
+    if (NE) {
+        const uint64_t grid = (NE + LINK_THREADS - 1) / LINK_THREADS;
+        CDBG_LAUNCH((k_link_insert<W>), grid, LINK_THREADS, s, lp);
+        CDBG_LAUNCH(k_link_count, grid, LINK_THREADS, s, lp);
+        const uint64_t nb = (NE + EXSCAN_BLOCK - 1) / EXSCAN_BLOCK;
+        CK(c->exscan_tmp.alloc(nb + 1, false));
+        const uint32_t* degp = deg.p;                        // (plain pointer: launch arguments are captured by value)
+        CDBG_LAUNCH(k_exscan_sums, nb, EXSCAN_THREADS, s, degp, c->exscan_tmp.p, NE);
+        CDBG_LAUNCH(k_exscan_top, 1, EXSCAN_THREADS, s, c->exscan_tmp.p, nb, c->link_off.p + NE);
+        CDBG_LAUNCH(k_exscan_apply, nb, EXSCAN_THREADS, s, degp, (const uint64_t*)c->exscan_tmp.p, c->link_off.p, NE);
+        CK(read_u64(c->link_off.p + NE, &c->n_links));
+        CK(c->link_to.alloc(c->n_links, false));
+        lp.link_off = c->link_off.p; lp.link_to = c->link_to.p;
+        CDBG_LAUNCH(k_link_fill, grid, LINK_THREADS, s, lp);
+        HIPCK(hipStreamSynchronize(s));
+    }
+    c->linked = true;
+    return CDBG_OK;
+}
+
+// the unitig definition checked on the resident result (k_verify.h)
+template <int W>
+int verify_impl(cdbg_ctx* c, uint64_t* out) {
+    if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_verify before cdbg_glue");
+    hipStream_t s = c->stream;
+    const bool sharded_set = (c->prm.world_size > 1 || c->force_multi) && !c->prm.emit_replicated;   // this rank holds a share of the unitigs: no links
+    if (!sharded_set && !c->linked) CK(link_impl<W>(c));
+    DBuf<uint64_t> d; CK(d.alloc(8, true));
+    VerifyParams vp{ c->n_unitigs, c->k, c->unitig_off.p, c->unitig_len.p, c->unitig_bases.p,
+                     c->seg_off.p, c->seg_n.p, c->solid_keys.p, c->solid_cnt.p, c->n_local_parts, c->link_off.p, c->link_to.p, d.p };
+    if (c->n_unitigs) CDBG_LAUNCH((k_verify_unitig_kmers<W>), std::min<uint64_t>((c->n_unitigs + 255) / 256, 1u << 16), 256, s, vp);
+    CDBG_LAUNCH((k_verify_solid<W>), std::min<uint64_t>((c->n_local_parts + 255) / 256, 1u << 16), 256, s, vp);
+    if (!sharded_set && c->n_unitigs) CDBG_LAUNCH(k_verify_maximal, (2 * c->n_unitigs + 255) / 256, 256, s, vp);
+    HIPCK(hipStreamSynchronize(s));
+    CK(read_u64(d.p, out, 8));
+    if (sharded_set) out[6] = out[7] = ~0ull;
+    return CDBG_OK;
+}
+
+}  // namespace
