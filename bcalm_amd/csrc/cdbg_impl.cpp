@@ -82,16 +82,16 @@ void cdbg_destroy(cdbg_ctx* c) {
 #ifndef CDBG_HOSTSIM
     if (c->rccl) { c->rccl->destroy(); delete c->rccl; c->rccl = nullptr; }
 #endif
-    (void)hipStreamSynchronize(c->stream);
-    stash_region(c->prm.device_id, c->records);
+    (void)hipStreamSynchronize(c->stream);               // (the buffers go back to the process's pool: nothing may still be writing them)
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
 int cdbg_release_cached(void) {
-    RegionStash& st = region_stash();
-    std::lock_guard<std::mutex> g(st.mu);
     int cur = 0; (void)hipGetDevice(&cur);
-    for (int d = 0; d < 64; ++d) if (st.p[d]) { (void)hipSetDevice(d); (void)hipFree(st.p[d]); st.p[d] = nullptr; st.cap[d] = 0; }
+    for (int d = 0; d < 64; ++d) {
+        bool any; { std::lock_guard<std::mutex> g(dev_pool().mu); any = !dev_pool().blocks[d].empty(); }
+        if (any) { (void)hipSetDevice(d); dev_pool().drain(d); }
+    }
     (void)hipSetDevice(cur);
     return CDBG_OK;
 }

@@ -197,7 +197,6 @@ int count_impl(cdbg_ctx* c) {
             else if (sample_max >= 32 && (double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && getenv("CDBG_SCAN_MODE") == nullptr) { fits = false; var = !multi; }
             if (fits) {
                 if (c->xrecs.cap > c->records.cap) c->records.swap(c->xrecs);   // (sharded reads: the previous step left the region buffer there)
-                adopt_region(c->prm.device_id, c->records, (uint64_t)part_cap * NPS * RW);   // (what an earlier context of this process left behind)
                 CK(c->records.alloc((uint64_t)part_cap * NPS * RW, false));
                 CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
                 HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));

@@ -21,6 +21,47 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 #define CK(expr) do { int rc_ = (expr); if (rc_ != CDBG_OK) return rc_; } while (0)
 
+// Device buffers outlive their context.  The scan's 1.6 G scattered 16-byte stores and as many far atomics are sensitive to WHERE
+// the 75 GB record region and the 16 MB of fill counters lie physically: every free + re-allocation handed back a less contiguous
+// set of pages, and five contexts created and destroyed in one process scanned in 66.7 -> 70.8 -> 68.9 -> 75.3 -> 77.9 ms
+// (profiles/r03_scan_variance_by_allocation.log).  Buffers of 1 MB and more therefore go back to a per-device POOL of the process
+// instead of the driver, and an allocation takes the smallest pooled block that is large enough (and not more than twice as large):
+// a second context of the same shape runs on the very pages of the first.  cdbg_release_cached() empties the pool; a pooled
+// volume beyond DevPool::LIMIT is freed at once.
+struct DevPool {
+    static constexpr size_t MIN_BYTES = 1u << 20, LIMIT = 160ull << 30;
+    struct Block { void* p; size_t bytes; };
+    std::mutex mu; std::vector<Block> blocks[64]; size_t held[64] = {};
+    static int device() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0; return d; }
+    void* take(size_t want, size_t* got) {
+        const int d = device();
+        std::lock_guard<std::mutex> g(mu);
+        int best = -1;
+        for (int i = 0; i < (int)blocks[d].size(); ++i)
+            if (blocks[d][i].bytes >= want && blocks[d][i].bytes <= 2 * want && (best < 0 || blocks[d][i].bytes < blocks[d][best].bytes)) best = i;
+        if (best < 0) return nullptr;
+        void* p = blocks[d][best].p; *got = blocks[d][best].bytes; held[d] -= *got;
+        blocks[d].erase(blocks[d].begin() + best);
+        return p;
+    }
+    void give(void* p, size_t bytes) {
+        const int d = device();
+        (void)hipDeviceSynchronize();                    // (what hipFree did: the block may be handed to a context that works on another stream)
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (bytes >= MIN_BYTES && held[d] + bytes <= LIMIT) { blocks[d].push_back({ p, bytes }); held[d] += bytes; return; }
+        }
+        (void)hipFree(p);
+    }
+    // everything back to the driver (an allocation failed, or the caller asked)
+    void drain(int d) {
+        std::vector<Block> bl;
+        { std::lock_guard<std::mutex> g(mu); bl.swap(blocks[d]); held[d] = 0; }
+        for (const Block& b : bl) (void)hipFree(b.p);
+    }
+};
+inline DevPool& dev_pool() { static DevPool p; return p; }
+
 template <class T>
 struct DBuf {                                   // owned device array
     T* p = nullptr; size_t n = 0, cap = 0;
@@ -36,44 +77,27 @@ struct DBuf {                                   // owned device array
             // re-allocated gigabytes in the middle of a step (measured: +230 ms in 3 of 26 steps at config 3).
             if (want > (1u << 16)) want += want / 32;
             want = std::max(want, floor_cap);
-            hipError_t e = hipMalloc(&p, want * sizeof(T));
-            if (e != hipSuccess) { p = nullptr; return fail(CDBG_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e)); }
-            cap = want;
+            size_t got = 0;
+            if (want * sizeof(T) >= DevPool::MIN_BYTES) p = (T*)dev_pool().take(want * sizeof(T), &got);
+            if (p) cap = got / sizeof(T);
+            else {
+                hipError_t e = hipMalloc(&p, want * sizeof(T));
+                if (e != hipSuccess) { dev_pool().drain(DevPool::device()); e = hipMalloc(&p, want * sizeof(T)); }   // (pooled blocks of other shapes may be in the way)
+                if (e != hipSuccess) { p = nullptr; return fail(CDBG_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e)); }
+                cap = want;
+            }
         }
         n = count;
         if (zero) { hipError_t e = hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)); if (e != hipSuccess) return fail(CDBG_E_NODEVICE, "hipMemset failed"); }
         return CDBG_OK;
     }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; cap = 0; } }
+    void release() { if (p) { dev_pool().give(p, cap * sizeof(T)); p = nullptr; n = 0; cap = 0; } }
     void swap(DBuf& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
     DBuf() = default;
     DBuf(const DBuf&) = delete;
     DBuf& operator=(const DBuf&) = delete;
     ~DBuf() { release(); }
 };
-
-// The record region outlives its context.  The scan's 1.6 G scattered 16-byte stores are sensitive to WHERE the 75 GB region
-// lies physically: every free + re-allocation handed back a less contiguous set of pages, and five contexts created and
-// destroyed in one process scanned in 66.7 -> 70.8 -> 68.9 -> 75.3 -> 77.9 ms (profiles/r03_scan_variance_by_allocation.log).
-// A destroyed context therefore leaves its region with the process (one per device); the next context on that device adopts
-// it when it is large enough.  cdbg_release_cached() gives it back to the driver.
-struct RegionStash { std::mutex mu; uint64_t* p[64] = {}; size_t cap[64] = {}; };
-RegionStash& region_stash() { static RegionStash st; return st; }
-void stash_region(int dev, DBuf<uint64_t>& b) {
-    if (dev < 0 || dev >= 64 || !b.p || b.cap < (1u << 24)) return;          // (small regions are not worth keeping)
-    RegionStash& st = region_stash();
-    std::lock_guard<std::mutex> g(st.mu);
-    if (st.cap[dev] >= b.cap) return;                    // (the larger one stays; the caller's buffer is freed by its destructor)
-    if (st.p[dev]) (void)hipFree(st.p[dev]);
-    st.p[dev] = b.p; st.cap[dev] = b.cap; b.p = nullptr; b.n = 0; b.cap = 0;
-}
-void adopt_region(int dev, DBuf<uint64_t>& b, size_t want) {
-    if (dev < 0 || dev >= 64 || b.cap >= want) return;
-    RegionStash& st = region_stash();
-    std::lock_guard<std::mutex> g(st.mu);
-    if (st.cap[dev] < want) return;
-    b.release(); b.p = st.p[dev]; b.cap = st.cap[dev]; b.n = 0; st.p[dev] = nullptr; st.cap[dev] = 0;
-}
 
 #ifndef CDBG_TSC1
 #define CDBG_TSC1 4096

@@ -78,6 +78,69 @@ int dg_a2a_blocks(cdbg_ctx* c, const void* send, const std::vector<uint64_t>& se
     return CDBG_OK;
 }
 
+// Closed chains in the distributed ranking (k_dglue.h): every rank's unfinished states, all-gathered; the same cut on every rank.
+// DG_FALLBACK when they are too many to handle this way (the replicated exchange then cuts them).
+constexpr uint64_t DG_CYCLE_MAX = 1ull << 22;
+int dg_cut_cycles(cdbg_ctx* c, const DRankParams& dp, uint64_t* n_cycles) {
+    const int world = c->prm.world_size, me = c->prm.rank; hipStream_t s = c->stream;
+    const uint32_t NSl = dp.n_local;
+    DBuf<uint2> mine, all; DBuf<uint64_t> cur; DBuf<uint32_t> cut;
+    CK(cur.alloc(1, true));
+    CK(mine.alloc(std::min<uint64_t>(NSl, DG_CYCLE_MAX) + 1, false));
+    DrOpenParams op{ NSl, dp.base, dp.st, dp.link, mine.p, cur.p, std::min<uint64_t>(NSl, DG_CYCLE_MAX) };
+    if (NSl) CDBG_LAUNCH(k_dr_collect_open, (NSl + 255) / 256, 256, s, op);
+    uint64_t n_mine = 0; CK(read_u64(cur.p, &n_mine));
+    std::vector<uint64_t> cnt(world);
+    if (c->tr.all_gather_u64(c->tr.user, &n_mine, cnt.data(), 1) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
+    uint64_t total = 0; std::vector<uint64_t> roff(world), rcnt(world);
+    for (int r = 0; r < world; ++r) { roff[r] = total * sizeof(uint2); rcnt[r] = cnt[r] * sizeof(uint2); total += cnt[r]; }
+    if (total > DG_CYCLE_MAX) return DG_FALLBACK;        // (every rank sees the same total)
+    CK(all.alloc(total + 1, false));
+    if (!c->tr_ordered) HIPCK(hipStreamSynchronize(s));
+    if (c->tr.all_gather_v(c->tr.user, mine.p, n_mine * sizeof(uint2), all.p, roff.data(), rcnt.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_v failed");
+    for (int r = 0; r < world; ++r) if (r != me) c->comm_bytes += n_mine * sizeof(uint2) + rcnt[r];
+    std::vector<uint2> h(total);
+    HIPCK(hipMemcpy(h.data(), all.p, total * sizeof(uint2), hipMemcpyDeviceToHost));
+    // state -> successor; every state of a closed chain is in the list (both directions of every piece of it)
+    std::sort(h.begin(), h.end(), [](const uint2& a, const uint2& b) { return a.x < b.x; });
+    auto next_of = [&](uint32_t e, uint32_t& nx) -> bool {
+        size_t lo = 0, hi = h.size();
+        while (lo < hi) { const size_t m = (lo + hi) / 2; if (h[m].x < e) lo = m + 1; else hi = m; }
+        if (lo == h.size() || h[lo].x != e) return false;
+        nx = h[lo].y; return true;
+    };
+    std::vector<uint8_t> seen(h.size(), 0);
+    std::vector<uint32_t> cuts; uint64_t ncyc = 0;
+    for (size_t i = 0; i < h.size(); ++i) {
+        if (seen[i]) continue;
+        uint32_t e = h[i].x, pmin = e >> 1; size_t steps = 0;
+        for (;;) {                                       // walk the cycle of states that starts at h[i]
+            size_t lo = 0, hi = h.size();
+            while (lo < hi) { const size_t m = (lo + hi) / 2; if (h[m].x < e) lo = m + 1; else hi = m; }
+            if (lo == h.size() || h[lo].x != e) return fail(CDBG_E_INTERNAL, "sharded glue: state %u of a closed chain is missing from the gathered list", e);
+            if (seen[lo]) break;
+            seen[lo] = 1; pmin = std::min(pmin, e >> 1);
+            e = h[lo].y;
+            if (e == NONE32 || ++steps > h.size()) return fail(CDBG_E_INTERNAL, "sharded glue: an unfinished state is not on a closed chain");
+        }
+        // the two directions of a piece cycle elect the same piece; the one that passes its left end as an EXIT names the junction
+        uint32_t partner = 0;
+        if (!next_of(2u * pmin + 1u, partner)) return fail(CDBG_E_INTERNAL, "sharded glue: closed chain without its reverse direction");
+        bool dup = false;
+        for (size_t j = 0; j + 1 < cuts.size(); j += 2) if (cuts[j] == 2u * pmin) { dup = true; break; }
+        if (!dup) { cuts.push_back(2u * pmin); cuts.push_back(partner); ++ncyc; }
+    }
+    if (!cuts.empty()) {
+        CK(cut.alloc(cuts.size(), false));
+        HIPCK(hipMemcpy(cut.p, cuts.data(), cuts.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        DrCutParams cp{ cut.p, (uint32_t)cuts.size(), dp.base, NSl, const_cast<uint32_t*>(dp.link) };
+        CDBG_LAUNCH(k_dr_cut, ((uint32_t)cuts.size() + 255) / 256, 256, s, cp);
+        HIPCK(hipStreamSynchronize(s));
+    }
+    *n_cycles = ncyc;
+    return CDBG_OK;
+}
+
 template <int W>
 int glue_sharded(cdbg_ctx* c) {
     const int world = c->prm.world_size, me = c->prm.rank, k = c->k;
@@ -166,10 +229,24 @@ int glue_sharded(cdbg_ctx* c) {
         uint64_t total_states = 2ull * own.b[world];
         int max_rounds = 4; while ((1ull << (max_rounds - 3)) < total_states) ++max_rounds;
         bool done = false;
+        uint64_t prev_open = ~0ull; int cuts_made = 0;
         for (int round = 0; round < max_rounds; ++round) {
             if (NSl) CDBG_LAUNCH(k_dr_jump, gridS, 256, s, dp);
             CK(dg_route(c, NSl, R));
             if (R.n_all == 0) { done = true; break; }                       // no rank has an unfinished state
+            if (R.n_all == prev_open && cuts_made < 2) {
+                // a round that finished nothing: only closed chains are left (every round finishes the states within reach of a
+                // tail).  Cut them where they are (k_dglue.h) and rank again -- every rank takes this branch together.
+                uint64_t ncyc = 0;
+                const int rc = dg_cut_cycles(c, dp, &ncyc);
+                if (rc == DG_FALLBACK) break;
+                CK(rc);
+                c->st.n_cycles += ncyc; ++cuts_made;
+                if (NSl) CDBG_LAUNCH(k_dr_init, gridS, 256, s, dp);
+                prev_open = ~0ull;
+                continue;
+            }
+            prev_open = R.n_all;
             ++c->st.n_glue_rounds;
             CK(c->dg_qs.alloc(R.n_send + 1, false)); CK(c->dg_qsrc.alloc(R.n_send + 1, false)); CK(c->dg_qr.alloc(R.n_recv + 1, false));
             CK(c->dg_rs.alloc(R.n_recv + 1, false)); CK(c->dg_rr.alloc(R.n_send + 1, false));

@@ -192,6 +192,25 @@ __global__ void k_dr_apply(DRankParams P) {
     }
 }
 
+// ---- closed chains.  Pointer jumping never finishes a state that lies on a cycle; once a round finishes no state at all, what
+// is left are exactly the cycles (isolated circular unitigs: plasmids, organelles).  They are few: every rank lists its
+// unfinished states with their original successor, the lists are all-gathered, every rank elects the same cut -- the junction
+// at the left end of the smallest piece of each cycle -- clears its own ends of those junctions and the ranking starts again.
+struct DrOpenParams { uint32_t n_local, base; const uint2* st; const uint32_t* link; uint2* out; uint64_t* cursor; uint64_t cap; };
+__global__ void k_dr_collect_open(DrOpenParams P) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.n_local || (P.st[e].x & RANK_TAIL)) return;
+    const uint64_t i = atomic_add_u64(P.cursor, 1ull);
+    if (i < P.cap) { uint2 v; v.x = e + P.base; v.y = P.link[e ^ 1u]; P.out[i] = v; }
+}
+struct DrCutParams { const uint32_t* ends; uint32_t n; uint32_t base, n_local; uint32_t* link; };
+__global__ void k_dr_cut(DrCutParams P) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const uint32_t e = P.ends[i];
+    if (e >= P.base && e - P.base < P.n_local) P.link[e - P.base] = NONE32;
+}
+
 // ---- 3. unitigs: size of what this rank will emit (its head states), then pieces -> head owners ----
 struct HeadMeasureParams { uint32_t n_states; int k; const uint32_t* link; const uint2* st; uint64_t* out; };   // out[0] unitigs, out[1] bases
 __global__ void k_heads_measure(HeadMeasureParams P) {

@@ -82,9 +82,10 @@ typedef struct cdbg_stats_t {
 
 int  cdbg_create(const cdbg_params* params, cdbg_ctx** out);
 void cdbg_destroy(cdbg_ctx* ctx);
-/* cdbg_destroy leaves the context's largest buffer (the super-k-mer record region, 75 GB at config 3) with the process, one per
- * device, and the next context on that device adopts it: the read scan is sensitive to the physical placement of that region, and
- * every free + re-allocation made it slower.  cdbg_release_cached returns it to the driver. */
+/* cdbg_destroy hands the context's device buffers of 1 MB and more (the super-k-mer record region: 75 GB at config 3) to a per-device
+ * pool of the process, and the next context of the same shape runs on the very same pages: the read scan is sensitive to the physical
+ * placement of its region and counters, and every free + re-allocation made it slower.  At most 160 GB are
+ * held per device; cdbg_release_cached returns everything to the driver. */
 int cdbg_release_cached(void);
 const char* cdbg_last_error(void);
 
@@ -208,7 +209,10 @@ int cdbg_fetch_links(cdbg_ctx* ctx, uint64_t* end_off, uint32_t* link_to);
 
 /* Environment variables read by the library -- test hooks that force paths an ordinary input does not reach (tests/), not
  * tuning knobs; results are identical with and without them:
- *   CDBG_SCAN_MODE=capped|exact   record layout (default: by input size)     CDBG_PART_CAP=<n>         capped region size (forces spills)
+ *   CDBG_SCAN_MODE=capped|exact|var  record layout (default: by input size and skew; var = one pass into per-partition regions sized
+ *                                 from a quarter-sample, what skewed inputs get)   CDBG_PART_CAP=<n>    capped region size (forces spills)
+ *   CDBG_VAR_SCALE=<f>            with var: capacity per sampled record (tiny values force spills)      CDBG_NO_SPLIT=1   overfull buckets through
+ *                                 the HBM-table compaction tier instead of the second-level split by sub-minimizer (k_split.h)
  *   CDBG_REPAIR_MAX_PASSES=<n>    LDS pass limit of the spill-repair launch   CDBG_NO_COUNT_TIER2=1     skip the second one-pass count tier
  *   CDBG_GLUE_LOG=1               junction records through the sequential log CDBG_GLUE_TABLE=1         global-table junction join
  *   CDBG_JOIN_LOG_JB=<n>          log2 of the join buckets (0 forces the overflow fallback)

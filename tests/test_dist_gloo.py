@@ -70,7 +70,14 @@ def _worker(rank, world, port, q, cases):
     for case in cases:
         k, amin, n_reads, read_len, cfg, kw = case
         kw = dict(kw)
-        text = oracle_lib.read_input(cfg).encode() if isinstance(cfg, str) else orc.synth_reads(n_reads, read_len, cfg)
+        if isinstance(cfg, str) and cfg.startswith("@circular"):
+            # isolated circular unitigs (plasmids): n_reads random circles of read_len bases each, every k-mer of a circle once
+            import random
+            rng = random.Random(n_reads * 1000 + read_len + k)
+            circles = ["".join(rng.choice("ACGT") for _ in range(read_len)) for _ in range(n_reads)]
+            text = ("\n".join(g + g[:k - 1] for g in circles) + "\n").encode()
+        else:
+            text = oracle_lib.read_input(cfg).encode() if isinstance(cfg, str) else orc.synth_reads(n_reads, read_len, cfg)
         exp = orc.run(text, k, amin)
         got = _run_sharded(api, cdist, lib, orc, text, k, amin, world, rank, steps=kw.pop("steps", 1), **kw)
         if kw.get("emit_replicated"):
@@ -81,8 +88,7 @@ def _worker(rank, world, port, q, cases):
             ok.append(got["union"] == exp["unitigs"])
         ok.append(got["distinct"] == exp["stats"]["distinct"] and got["solid"] == exp["stats"]["solid"] and got["occ"] == exp["stats"]["occurrences"])
         ok.append(got["comm_bytes"] > 0)
-        # which glue ran: the sharded one (distributed ranking rounds > 0) unless every rank emits everything, or -- the
-        # circular fixtures -- a closed chain crosses ranks and the replicated exchange takes over
+        # which glue ran: the sharded one (distributed ranking rounds > 0) unless every rank emits everything
         if "rounds" in got:
             ok.append((got["rounds"] > 0) == (not kw.get("emit_replicated") and not kw.get("expect_fallback")))
         if kw.get("all_abundance_counts"):
@@ -127,13 +133,16 @@ def test_two_rank_gloo():
                 (31, 2, 300, 150, 3, {"reads_replicated": True}), (31, 2, 300, 150, 3, {"scan_mode": "capped", "log2_partitions": 6}),
                 (55, 2, 200, 150, 4, {"scan_mode": "capped", "reads_replicated": True}), (31, 2, 200, 150, 3, {"empty_rank": 1}),
                 (30, 2, 250, 150, 3, {}), (64, 1, 100, 300, 5, {"log2_partitions": 4}),
-                # closed chains across ranks (example/circular_unitigs_unittests): the distributed ranking gives up, the replicated exchange cuts them
-                (7, 1, 0, 0, "circ_test1", {"log2_partitions": 3, "minimizer_size": 3, "expect_fallback": True}),
+                # closed chains across ranks (example/circular_unitigs_unittests): a ranking round that finishes nothing -> the unfinished
+                # states are gathered, every rank cuts the same junction, the sharded ranking starts again (no replicated fallback)
+                (7, 1, 0, 0, "circ_test1", {"log2_partitions": 3, "minimizer_size": 3}), (7, 1, 0, 0, "circ_test1", {"log2_partitions": 5, "minimizer_size": 4}),
                 (7, 1, 0, 0, "circ_test2", {"log2_partitions": 3, "minimizer_size": 3}), (9, 1, 0, 0, "pufferize_refs", {"log2_partitions": 4, "minimizer_size": 4})], 29500, 400)
 
 
 def test_four_rank_gloo():
     _launch(4, [(31, 2, 400, 150, 3, {}), (55, 1, 160, 150, 4, {"log2_partitions": 7}), (127, 2, 80, 500, 5, {"log2_partitions": 5}),
+                # three plasmid-like circles of 1500 bp next to ordinary reads' worth of chains: cut in place, ranking restarted
+                (31, 1, 3, 1500, "@circular", {"log2_partitions": 6}), (55, 1, 2, 900, "@circular", {"log2_partitions": 5}),
                 (31, 2, 400, 150, 3, {"reads_replicated": True}), (31, 2, 300, 150, 3, {"scan_mode": "capped", "empty_rank": 3})], 31500, 300)
 
 

@@ -158,7 +158,8 @@ def test_multi_gpu_path_single_rank_rccl(oracle, hip, monkeypatch):
     (2, 55, 2, 100000, 150, 4, {}), (2, 127, 2, 8000, 1000, 5, {}), (2, 31, 2, 100000, 150, 3, {"emit_replicated": True}),
     (2, 31, 2, 60000, 150, 3, {"all_abundance_counts": True}),
     (2, 31, 2, 200000, 150, 3, {"reads_replicated": True}), (4, 32, 2, 60000, 150, 4, {"reads_replicated": True}),
-    (2, 31, 2, 300000, 150, 3, {"scan_mode": "capped"}), (4, 77, 2, 6000, 1000, 5, {"scan_mode": "capped"})])
+    (2, 31, 2, 300000, 150, 3, {"scan_mode": "capped"}), (4, 77, 2, 6000, 1000, 5, {"scan_mode": "capped"}),
+    (2, 31, 1, 40, 5000, "circular", {}), (4, 55, 1, 25, 3000, "circular", {})])
 def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, read_len, cfg, kw, monkeypatch):
     """the complete N-rank data path on the real device: N contexts on GPU 0 driven by N host threads, reads sharded,
     records / pieces / junction log / partner ids moved by an in-process loop-back transport (tests/loopback.py: RCCL
@@ -169,7 +170,13 @@ def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, rea
     kw = dict(kw)
     if kw.pop("scan_mode", None):                # sharded reads through the single-pass capped scan + region packing
         monkeypatch.setenv("CDBG_SCAN_MODE", "capped")
-    text = oracle.synth_reads(n_reads, read_len, cfg)
+    if cfg == "circular":
+        # isolated circular unitigs (plasmids) among the ranks: closed chains, cut in place by the sharded glue (k_dglue.h)
+        rng = random.Random(n_reads + read_len)
+        circles = ["".join(rng.choice("ACGT") for _ in range(read_len)) for _ in range(n_reads)]
+        text = ("\n".join(g + g[:k - 1] for g in circles) + "\n").encode()
+    else:
+        text = oracle.synth_reads(n_reads, read_len, cfg)
     exp = oracle.run(text, k, amin)
     reads = [x for x in text.decode().split("\n") if x]
     hub = hip_loopback(world)
@@ -199,7 +206,7 @@ def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, rea
     else:
         union = sorted((oracle.canonical_unitig(s, k), int(kc)) for r in range(world) for s, kc in out[r][0])
         assert union == exp["unitigs"]
-        assert all(len(out[r][0]) > 0 for r in range(world))
+        assert cfg == "circular" or all(len(out[r][0]) > 0 for r in range(world))   # (a circle is cut at its smallest piece id: rank 0 owns most of those heads)
         assert all(out[r][1]["n_glue_rounds"] > 0 for r in range(world))        # the sharded glue ran (k_dglue.h), not the replicated fallback
     assert sum(out[r][1]["n_distinct"] for r in range(world)) == exp["stats"]["distinct"]
     assert sum(out[r][1]["n_solid"] for r in range(world)) == exp["stats"]["solid"]
