@@ -52,7 +52,7 @@ const char* cdbg_last_error(void) { return g_err.c_str(); }
 int cdbg_create(const cdbg_params* p, cdbg_ctx** out) {
     if (!p || !out) return fail(CDBG_E_PARAM, "null argument");
     *out = nullptr;
-    if (p->k < 3 || p->k > 127) return fail(CDBG_E_PARAM, "kmer-size %d out of range (3..127)", p->k);
+    if (p->k < 3 || p->k > 32 * CDBG_MAX_W - 1) return fail(CDBG_E_PARAM, "kmer-size %d out of range (3..%d)", p->k, 32 * CDBG_MAX_W - 1);
     if (p->abundance_min < 1) return fail(CDBG_E_PARAM, "abundance-min must be >= 1");
     const int ws = p->world_size <= 0 ? 1 : p->world_size;
     if (ws & (ws - 1)) return fail(CDBG_E_PARAM, "world_size must be a power of two");
@@ -68,7 +68,7 @@ int cdbg_create(const cdbg_params* p, cdbg_ctx** out) {
     c->prm = *p; c->prm.world_size = ws;
     // words per k-mer: the reference's span rule k < 32 W (README.md:91-99, Integer::apply at src/bcalm_1.cpp:95); the top word of a
     // multi-word key therefore always keeps its two top bits free for the slot-claim protocol (k_count.h), for even k as well
-    c->k = p->k; c->W = p->k <= 31 ? 1 : p->k <= 63 ? 2 : p->k <= 95 ? 3 : 4;
+    c->k = p->k; c->W = p->k / 32 + 1;
     c->rank_bits = 0; while ((1 << c->rank_bits) < ws) ++c->rank_bits;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return fail(CDBG_E_NODEVICE, "hipStreamCreate failed"); }
     *out = c;
@@ -146,13 +146,21 @@ int cdbg_read_text(cdbg_ctx* c, uint64_t first_byte, uint64_t nbytes, char* out)
     return CDBG_OK;
 }
 
-#define DISPATCH_W(fn)                                              \
+#if CDBG_MAX_W >= 8
+#define DISPATCH_WIDE(fn, ...) case 5: return fn<5>(__VA_ARGS__); case 6: return fn<6>(__VA_ARGS__); case 7: return fn<7>(__VA_ARGS__); case 8: return fn<8>(__VA_ARGS__);
+#else
+#define DISPATCH_WIDE(fn, ...)
+#endif
+#define DISPATCH_WA(fn, ...)                                         \
     switch (c->W) {                                                  \
-        case 1: return fn<1>(c);                                     \
-        case 2: return fn<2>(c);                                     \
-        case 3: return fn<3>(c);                                     \
-        default: return fn<4>(c);                                    \
+        case 1: return fn<1>(__VA_ARGS__);                           \
+        case 2: return fn<2>(__VA_ARGS__);                           \
+        case 3: return fn<3>(__VA_ARGS__);                           \
+        case 4: return fn<4>(__VA_ARGS__);                           \
+        DISPATCH_WIDE(fn, __VA_ARGS__)                               \
+        default: return fail(CDBG_E_PARAM, "k-mers of %d words: rebuild with CDBG_MAX_W", c->W);   \
     }
+#define DISPATCH_W(fn) DISPATCH_WA(fn, c)
 static int count_dispatch(cdbg_ctx* c) { DISPATCH_W(count_impl) }
 int cdbg_count(cdbg_ctx* c) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
@@ -357,7 +365,7 @@ int cdbg_digest(cdbg_ctx* c, uint64_t out[4]) {
 int cdbg_verify(cdbg_ctx* c, uint64_t out[8]) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
     (void)hipSetDevice(c->prm.device_id);
-    switch (c->W) { case 1: return verify_impl<1>(c, out); case 2: return verify_impl<2>(c, out); case 3: return verify_impl<3>(c, out); default: return verify_impl<4>(c, out); }
+    DISPATCH_WA(verify_impl, c, out)
 }
 int cdbg_stats(cdbg_ctx* c, cdbg_stats_t* out) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");

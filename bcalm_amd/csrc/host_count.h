@@ -94,7 +94,13 @@ int stream_scan_advance(cdbg_ctx* c) {
     return CDBG_OK;
 }
 int stream_scan_dispatch(cdbg_ctx* c) {
-    switch (c->W) { case 1: return stream_scan_advance<1>(c); case 2: return stream_scan_advance<2>(c); case 3: return stream_scan_advance<3>(c); default: return stream_scan_advance<4>(c); }
+    switch (c->W) {
+        case 1: return stream_scan_advance<1>(c); case 2: return stream_scan_advance<2>(c); case 3: return stream_scan_advance<3>(c); case 4: return stream_scan_advance<4>(c);
+#if CDBG_MAX_W >= 8
+        case 5: return stream_scan_advance<5>(c); case 6: return stream_scan_advance<6>(c); case 7: return stream_scan_advance<7>(c); case 8: return stream_scan_advance<8>(c);
+#endif
+        default: return fail(CDBG_E_PARAM, "k-mers of %d words: rebuild with CDBG_MAX_W", c->W);
+    }
 }
 
 template <int W>
@@ -424,7 +430,7 @@ int count_impl(cdbg_ctx* c) {
     hm.mark("count: tier 1");
     CK(read_u32(c->big_count.p + 1, &nretry));
     const uint32_t* retry_ptr = c->retry_list.p;
-    if (nretry && getenv("CDBG_NO_COUNT_TIER2") == nullptr) {
+    if constexpr (W <= 4) if (nretry && getenv("CDBG_NO_COUNT_TIER2") == nullptr) {   // (wider keys: a table twice the size does not fit the LDS)
         // second tier: the same one-pass kernel with a table twice the size (one workgroup per CU) over the retry list; at the
         // config-5 share 6 % of the partitions -- a minimizer locus of long reads -- cost 250 of 590 ms in the multi-pass kernel
         CK(c->retry_list2.alloc(nretry, false));

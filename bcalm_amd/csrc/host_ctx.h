@@ -120,7 +120,13 @@ constexpr int TS_COUNT_1 = CDBG_TSC1, TS_COUNT_2 = CDBG_TSC2, TS_COUNT_4 = CDBG_
 // config 3 / config 4 shapes: W = 2 gains from the small first tier (7 instead of 3 workgroups per CU: 133 -> 84 ms),
 // W = 1 does not (its kernel is VALU bound and the denser table costs probes: 84 -> 96 ms), so W = 1 starts at 1024
 constexpr int TS_COMPACT_1 = CDBG_TSK1, TS_COMPACT_2 = 512, TS_COMPACT_4 = 512;
-template <int W> struct Cfg;
+// k-mers wider than four words (k = 128 .. 255: the reference's KSIZE_LIST is open-ended, README.md:91-99 -- "must contain 32", larger
+// spans are a build option there as here: CDBG_MAX_W).  Same kernels, tables a quarter / half the slots of the four-word geometry so that
+// keys of 40 - 64 bytes still fit the CU's LDS; not tuned (no BASELINE config lives there), parity-tested at k = 128, 191 and 255.
+#ifndef CDBG_MAX_W
+#define CDBG_MAX_W 8
+#endif
+template <int W> struct Cfg { static constexpr int TSC = 1024, TSK = 256, TSK2 = 512, NTC = 512, TSW = 128, TSW2 = 256; };
 // TSW: slots of the wave-per-bucket compaction tier (buckets of at most TSW / 2 entries; k_compact_wave.h)
 template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1, TSK2 = 2 * TS_COMPACT_1, NTC = CDBG_NTC1, TSW = 512, TSW2 = 512; };   // (TSW2 == TSW: no second wave tier)
 #ifndef CDBG_TSW2

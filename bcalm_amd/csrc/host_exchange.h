@@ -183,7 +183,13 @@ int xchg_glue_join(cdbg_ctx* c, uint64_t* n_ends) {
     if (!c || !n_ends) return fail(CDBG_E_PARAM, "null argument");
     if (c->stage != 2) return fail(CDBG_E_STATE, "xchg_glue_join needs a compacted, not yet glued context");
     int rc;
-    switch (c->W) { case 1: rc = glue_join_impl<1>(c, true); break; case 2: rc = glue_join_impl<2>(c, true); break; case 3: rc = glue_join_impl<3>(c, true); break; default: rc = glue_join_impl<4>(c, true); }
+    switch (c->W) {
+        case 1: rc = glue_join_impl<1>(c, true); break; case 2: rc = glue_join_impl<2>(c, true); break; case 3: rc = glue_join_impl<3>(c, true); break; case 4: rc = glue_join_impl<4>(c, true); break;
+#if CDBG_MAX_W >= 8
+        case 5: rc = glue_join_impl<5>(c, true); break; case 6: rc = glue_join_impl<6>(c, true); break; case 7: rc = glue_join_impl<7>(c, true); break; case 8: rc = glue_join_impl<8>(c, true); break;
+#endif
+        default: rc = fail(CDBG_E_PARAM, "k-mers of %d words: rebuild with CDBG_MAX_W", c->W);
+    }
     if (rc == CDBG_OK) *n_ends = 2 * c->n_pieces;
     return rc;
 }

@@ -45,7 +45,7 @@ constexpr int SCAN_GRID = 256 * 2;                     // fallback grid of the p
 constexpr int SCAN_TILE = 4096;                       // junctions per workgroup
 constexpr int SCAN_PKW = (SCAN_TILE + 16 + 256) / 16 + 11;   // packed words (16 bases each) incl. halo/over-read; EVEN
 static_assert(SCAN_PKW % 2 == 0, "validity halves must fill whole 32-bit words");
-constexpr int SCAN_NKEY = SCAN_TILE + 192;
+constexpr int SCAN_NKEY = SCAN_TILE + 256;                  // keys of a tile: k - m <= 254 (k <= 255)
 
 template <int W> struct RecFmt {
     static constexpr int RW = 2 * W;
@@ -241,24 +241,31 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     }
     __syncthreads();
     // (b) one wave, lane w = the 64 junctions jq = 64 w + 1 .. 64 w + 64: validity of a junction = its k-1 bases all valid, for 64
-    // junctions at once by AND-doubling over a 256-bit window of the validity bits (a 126-bit window test per junction and lane was
+    // junctions at once by AND-doubling over a 320-bit window of the validity bits (a 126-bit window test per junction and lane was
     // 29 % of the kernel at k = 127); then continue / break / start words, and the run starts compacted into a list (walking all
     // junctions for the ~70 runs of a tile kept 98 % of the lanes idle through 16 divergent iterations: another 35 %).
     uint16_t* const sl = reinterpret_cast<uint16_t*>(oth);                       // [SCAN_TILE] run starts (jq - 1), ascending
     if (tid < 64) {
         const int K1 = k - 1, q0 = 16 + 64 * tid;                               // junction jq <-> tile base index q = 15 + jq
-        uint64_t X[4];
+        constexpr int NXW = 5;                                                   // 320-bit window: 64 junctions + k - 1 <= 254 further bases
+        uint64_t X[NXW];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NXW; ++j) {
             const int bit = q0 + 64 * j, w = bit >> 5, sh = bit & 31;
             const uint64_t lo = ((uint64_t)vm[w + 1] << 32) | vm[w];
             X[j] = sh ? ((lo >> sh) | ((uint64_t)vm[w + 2] << (64 - sh))) : lo;
         }
-        auto shr_and = [&](int sft) {                                           // X &= X >> sft (256-bit, zero fill), sft wave-uniform, 1 .. 127
+        auto xw = [&](int i) -> uint64_t {                                      // X[i] without a runtime index (a select chain keeps the words in registers)
+            uint64_t r = 0;
+#pragma unroll
+            for (int j = 0; j < NXW; ++j) r = (i == j) ? X[j] : r;
+            return r;
+        };
+        auto shr_and = [&](int sft) {                                           // X &= X >> sft (320-bit, zero fill), sft wave-uniform, 1 .. 254
             const int ws = sft >> 6, bs = sft & 63;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint64_t a0 = i + ws < 4 ? X[(i + ws) & 3] : 0ULL, a1 = i + ws + 1 < 4 ? X[(i + ws + 1) & 3] : 0ULL;
+            for (int i = 0; i < NXW; ++i) {                                      // ascending: X[i] only reads words at or above i
+                const uint64_t a0 = xw(i + ws), a1 = xw(i + ws + 1);
                 X[i] &= bs ? ((a0 >> bs) | (a1 << (64 - bs))) : a0;
             }
         };
@@ -283,7 +290,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     CDBG_SPH(3);
 
     // ---- 5. one lane per run start: find the run end, apply the boundary rules, emit ----
-    const int NMAX = CAPB - k + 1;                     // member k-mers per record
+    const int NMAX = CAPB - k + 1 < 255 ? CAPB - k + 1 : 255;   // member k-mers per record (the count is an 8-bit field of the meta word: eight-word records have room for more)
     const uint32_t rank_mask = (1u << P.rank_bits) - 1u;
     const int nstart = (int)s_nstart;
     for (int si = tid; si < nstart; si += SCAN_THREADS) {                       // one lane per run

@@ -30,7 +30,8 @@ extern "C" {
 typedef struct cdbg_ctx cdbg_ctx;
 
 typedef struct cdbg_params {
-    int k;                    /* -kmer-size (README.md:17-19,99): any k in 3..127, even or odd */
+    int k;                    /* -kmer-size (README.md:17-19,99): any k in 3..255, even or odd (the reference's KSIZE_LIST "32 64 96 128" and the
+                                 larger spans it takes as a build option, README.md:91-99; here: CDBG_MAX_W words of 32 bases, default 8) */
     int abundance_min;        /* -abundance-min (README.md:21-25): keep k-mers seen >= this many times */
     int minimizer_size;       /* -minimizer-size (example/circular_unitigs_unittests/CMD:4); 0 = auto */
     int log2_partitions;      /* minimizer partitions = 1 << this; -1 = auto from the input volume */

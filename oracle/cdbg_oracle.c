@@ -118,15 +118,34 @@ struct orc_result {
 #define ORC_W 4
 #include "oracle_impl.h"
 #undef ORC_W
+/* wider spans (the reference's KSIZE_LIST is open-ended, README.md:91-99): k = 128 .. 255 */
+#define ORC_W 5
+#include "oracle_impl.h"
+#undef ORC_W
+#define ORC_W 6
+#include "oracle_impl.h"
+#undef ORC_W
+#define ORC_W 7
+#include "oracle_impl.h"
+#undef ORC_W
+#define ORC_W 8
+#include "oracle_impl.h"
+#undef ORC_W
 
 orc_result* orc_build(const char* seq, uint64_t n, int k, int abundance_min) {
-    /* any k in 3..127, even or odd (README.md:99 "any k value up to the largest one"); the word count follows the
+    /* any k in 3..255, even or odd (README.md:99 "any k value up to the largest one"); the word count follows the
      * reference's span rule k < 32 W (README.md:91-99) */
-    if (k < 3 || k > 127 || abundance_min < 1) return NULL;
-    if (k <= 31) return build_w1(seq, n, k, abundance_min);
-    if (k <= 63) return build_w2(seq, n, k, abundance_min);
-    if (k <= 95) return build_w3(seq, n, k, abundance_min);
-    return build_w4(seq, n, k, abundance_min);
+    if (k < 3 || k > 255 || abundance_min < 1) return NULL;
+    switch (k / 32 + 1) {
+        case 1: return build_w1(seq, n, k, abundance_min);
+        case 2: return build_w2(seq, n, k, abundance_min);
+        case 3: return build_w3(seq, n, k, abundance_min);
+        case 4: return build_w4(seq, n, k, abundance_min);
+        case 5: return build_w5(seq, n, k, abundance_min);
+        case 6: return build_w6(seq, n, k, abundance_min);
+        case 7: return build_w7(seq, n, k, abundance_min);
+        default: return build_w8(seq, n, k, abundance_min);
+    }
 }
 void orc_free(orc_result* r) {
     if (!r) return;
@@ -269,7 +288,7 @@ int main(int argc, char** argv) {
     struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
     orc_result* r = orc_build(seq, n, k, amin);
     clock_gettime(CLOCK_MONOTONIC, &t1);
-    if (!r) { fprintf(stderr, "bad parameters (k must be odd, 3..127)\n"); return 1; }
+    if (!r) { fprintf(stderr, "bad parameters (k: 3..255)\n"); return 1; }
     double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     fprintf(stderr, "oracle: occ=%llu distinct=%llu solid=%llu unitigs=%llu bases=%llu digest=%016llx  %.3fs  %.3f Mkmers/s\n",
             (unsigned long long)r->n_occ, (unsigned long long)r->n_distinct, (unsigned long long)r->n_solid,

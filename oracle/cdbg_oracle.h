@@ -6,7 +6,7 @@
 extern "C" {
 #endif
 typedef struct orc_result orc_result;
-/* seq: ASCII bases; any byte outside ACGTacgt separates reads.  k odd, 3..127. */
+/* seq: ASCII bases; any byte outside ACGTacgt separates reads.  any k in 3..255. */
 orc_result* orc_build(const char* seq, uint64_t n, int k, int abundance_min);
 void orc_free(orc_result*);
 uint64_t orc_n_occurrences(const orc_result*);

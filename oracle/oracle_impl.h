@@ -1,7 +1,7 @@
 /* oracle_impl.h -- body of the CPU oracle, instantiated once per k-mer width.
  *
  * TEST INFRASTRUCTURE ONLY (see cdbg_oracle.c header).  Included three times by
- * cdbg_oracle.c with ORC_W = 1, 2, 3, 4 (k <= 31, 63, 95, 127), the analogue of the
+ * cdbg_oracle.c with ORC_W = 1 .. 8 (k <= 31, 63, 95, 127, ... 255), the analogue of the
  * reference's KSIZE_LIST spans (/root/reference/README.md:91-99,
  * /root/reference/src/bcalm_1.cpp:95 Integer::apply).
  *

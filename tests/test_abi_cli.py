@@ -150,7 +150,7 @@ def test_cli_errors(cli, tmp_path):
     assert r.returncode == 1 and "EXCEPTION: Specifiy -in" in r.stdout          # main.cpp:44-48, bcalm_1.cpp:61
     r = subprocess.run([cli, "-in", "/nonexistent.fa"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "EXCEPTION:" in r.stdout
-    r = subprocess.run([cli, "-in", os.path.join(ROOT, "tests", "golden", "inputs", "tiny_read.fa"), "-kmer-size", "128"], cwd=tmp_path, capture_output=True, text=True)
+    r = subprocess.run([cli, "-in", os.path.join(ROOT, "tests", "golden", "inputs", "tiny_read.fa"), "-kmer-size", "256"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "out of range" in r.stdout
     r = subprocess.run([cli, "-in", os.path.join(ROOT, "tests", "golden", "inputs", "tiny_read.fa"), "-kmer-size", "20"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout                                       # even k runs (README.md:99)

@@ -379,3 +379,20 @@ def test_repartition_when_buckets_overflow(oracle, hip):
     assert got == exp["unitigs"] and st["n_solid"] == exp["stats"]["solid"] == st["n_distinct"]
     assert (st["n_solid"] + st["n_solid_travellers"]) / (1 << st["log2_partitions"]) <= 300
     assert st["n_big_partitions"] < 50
+
+
+@pytest.mark.parametrize("k,n_reads,read_len", [(128, 30000, 1000), (191, 20000, 1000), (255, 20000, 1000)])
+def test_wide_kmers_gpu(oracle, hip, k, n_reads, read_len):
+    """k = 128 .. 255 on the device (five-, six- and eight-word k-mers: /root/reference/README.md:91-99, spans beyond the default
+    list): config-5-like reads against the oracle, automatic partitioning and one forced bucket, plus the device-side definition check"""
+    import bcalm_amd
+    from parity import assert_verified
+    text = oracle.synth_reads(n_reads, read_len, 5)
+    for kw in ({}, {"log2_partitions": 0}):
+        exp = oracle.run(text, k, 2)
+        g = bcalm_amd.Graph(k, 2, lib=hip, **kw)
+        g.push_text(text); g.run()
+        st = g.stats(); got = oracle_lib.canonical_set(oracle, g.unitigs(), k); assert_verified(g); g.close()
+        assert st["kmer_words"] == k // 32 + 1
+        assert st["n_distinct"] == exp["stats"]["distinct"] and st["n_solid"] == exp["stats"]["solid"]
+        assert got == exp["unitigs"]

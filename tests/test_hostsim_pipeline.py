@@ -215,6 +215,31 @@ def test_count_tiers(oracle, sim, k, glen, mode, monkeypatch):
     assert got["stats"]["n_multipass_partitions"] == (0 if small else 1)
 
 
+@pytest.mark.parametrize("k,amin,log_np,m", [(128, 1, 0, 0), (128, 2, 3, 0), (160, 1, 2, 12), (191, 2, 3, 16), (192, 1, 1, 0), (224, 1, 0, 0), (255, 1, 4, 16), (255, 2, 2, 0)])
+def test_wide_kmers_beyond_the_default_span_list(oracle, sim, k, amin, log_np, m):
+    """k = 128 .. 255 (five- to eight-word k-mers: the KSIZE_LIST entries beyond 128 that the reference takes as a build option,
+    /root/reference/README.md:91-99): reads of both strands with errors and an N, against the oracle; the definition check on top"""
+    from bcalm_amd import api
+    from parity import assert_verified
+    rng = random.Random(k)
+    g = "".join(rng.choice("ACGT") for _ in range(5000))
+    reads = []
+    for i in range(100):
+        L = rng.randrange(200, 900); s0 = rng.randrange(0, len(g) - L)
+        r = g[s0:s0 + L]
+        if rng.random() < 0.5:
+            r = r[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        r = "".join((rng.choice("ACGT") if rng.random() < 0.004 else c) for c in r)
+        if rng.random() < 0.2:
+            r = r[:len(r) // 2] + "N" + r[len(r) // 2:]
+        reads.append(r)
+    text = "\n".join(reads) + "\n"
+    got = assert_parity(oracle, sim, text, k, amin, log2_partitions=log_np, minimizer_size=m)
+    assert got["stats"]["kmer_words"] == k // 32 + 1
+    gg = api.Graph(k, amin, lib=sim, log2_partitions=log_np, minimizer_size=m)
+    gg.push_text(text); gg.run(); assert_verified(gg); gg.close()
+
+
 @pytest.mark.parametrize("k,cfg,n_reads,read_len,log_np,part_min", [(31, 3 | 0x100, 3000, 150, 6, None), (31, 3, 3000, 150, 5, None), (55, 4 | 0x100, 1500, 150, 4, None),
                                                                      (127, 5 | 0x100, 200, 1000, 3, None), (21, 3 | 0x100, 3000, 150, 6, 1), (64, 4 | 0x100, 1500, 150, 4, 1)])
 def test_single_pass_scan_into_estimated_regions(oracle, sim, k, cfg, n_reads, read_len, log_np, part_min, monkeypatch):
