@@ -4,12 +4,24 @@
 
 namespace {
 
+// the register-window scan (k_scan_fast.h): k <= 63 with a window of at most SCANF_WNMAX keys, or k <= 127 through its two-level window
+// minimum (windows of 17 .. 111 keys); the LDS-doubling scan of k_scan.h otherwise
+inline bool scan_is_fast(const cdbg_ctx* c) {
+    const int wn = c->k - c->m;
+    if (getenv("CDBG_GENERIC_SCAN")) return false;          // (test knob: the generic kernel for every shape)
+    return (c->k <= 63 && wn <= SCANF_WNMAX) || (c->k <= 127 && wn > SCANF_WNMAX && wn >= 17);
+}
 // the scan kernel for this k / m / mode on the context's stream (persistent grid: resident workgroups)
 template <int W, int MODE>
 void launch_scan_mode(cdbg_ctx* c, ScanParams& sp, uint64_t grid) {
     hipStream_t s = c->stream;
-    const bool fast_scan = c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX;
+    const bool fast_scan = scan_is_fast(c);
     sp.n_tiles = grid;
+    if (fast_scan && c->k - c->m > SCANF_WNMAX) {           // the two-level window minimum (k_scan_fast.h, WNT = -1): k <= 127 with a long minimizer window
+        if (grid == 0) return;
+        CDBG_LAUNCH((k_scan_fast<W, MODE, -1>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, -1>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);
+        return;
+    }
     if (grid == 0) return;                                   // (a rank without reads)
     // compile-time minimizer windows (k - m): the k = 31 family m = 16 .. 12 and k = 55, m = 16 (config 4)
 #define CDBG_SCAN_WNT(WW, WNT_)                                                                                                  \
@@ -22,7 +34,7 @@ void launch_scan_mode(cdbg_ctx* c, ScanParams& sp, uint64_t grid) {
     if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE, 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);
     else CDBG_LAUNCH((k_scan<W, MODE>), std::min<uint64_t>(grid, resident_grid(k_scan<W, MODE>, SCAN_THREADS, SCAN_GRID)), SCAN_THREADS, s, sp);
 }
-inline uint64_t scan_tile_bytes(const cdbg_ctx* c) { return (c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX) ? (uint64_t)SCANF_TILE : (uint64_t)SCAN_TILE; }
+inline uint64_t scan_tile_bytes(const cdbg_ctx* c) { return scan_is_fast(c) ? (uint64_t)SCANF_TILE : (uint64_t)SCAN_TILE; }
 void scan_params_base(cdbg_ctx* c, ScanParams& sp) {
     sp.reads = c->reads.p; sp.nbytes = c->nbytes; sp.nbytes_padded = c->nbytes_padded;
     sp.k = c->k; sp.m = c->m; sp.log_np = c->log_np; sp.rank_bits = c->rank_bits; sp.rank = c->prm.rank;
@@ -150,7 +162,7 @@ int count_impl(cdbg_ctx* c) {
     scan_params_base(c, sp);
     sp.emit_all = multi ? 1u : 0u; sp.npl = (uint32_t)NPL;
     // instruction-lean scan when the window fits registers; generic LDS-doubling scan otherwise
-    const bool fast_scan = c->k <= 63 && (c->k - c->m) <= SCANF_WNMAX;
+    const bool fast_scan = scan_is_fast(c);
     const uint64_t tiles = fast_scan ? (c->nbytes + SCANF_TILE - 1) / SCANF_TILE : (c->nbytes + SCAN_TILE - 1) / SCAN_TILE;
     c->st.n_launch_scan = tiles;
 #define LAUNCH_SCAN(MODE, GRID) launch_scan_mode<W, MODE>(c, sp, (GRID))

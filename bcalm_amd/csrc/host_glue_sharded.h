@@ -22,24 +22,36 @@ struct DgRoute { std::vector<uint64_t> scnt, soff, rcnt, roff, all; uint64_t n_s
 // positions of the n items whose destinations are in c->dg_dest: send-block counts / offsets, receive counts / offsets
 // (extra: n_extra more words of this rank ride in the same small all-gather -- extra_all[r * n_extra + i] = word i of rank r: the
 //  piece counts and the status words that used to cost a host-synchronous collective of their own)
-int dg_route(cdbg_ctx* c, uint64_t n, DgRoute& R, const uint64_t* extra = nullptr, int n_extra = 0, std::vector<uint64_t>* extra_all = nullptr) {
+// `pending`: a rank-local failure of the caller since the last exchange (an allocation, a consistency check).  It travels with the counts -- as does
+// a failure inside the routing itself -- so that every rank leaves together instead of one rank returning while its peers wait in the transport.
+int dg_route(cdbg_ctx* c, uint64_t n, DgRoute& R, const uint64_t* extra = nullptr, int n_extra = 0, std::vector<uint64_t>* extra_all = nullptr, int pending = CDBG_OK) {
     const int world = c->prm.world_size, me = c->prm.rank; hipStream_t s = c->stream;
-    CK(c->dg_cnt.alloc(3 * DG_MAX_WORLD, true)); CK(c->dg_pos.alloc(n, false));
-    RouteParams rp{ n, c->dg_dest.p, c->dg_cnt.p, c->dg_cnt.p + DG_MAX_WORLD, c->dg_cnt.p + 2 * DG_MAX_WORLD, c->dg_pos.p, world };
-    if (n) CDBG_LAUNCH(k_route_count, std::min<uint64_t>((n + DG_THREADS - 1) / DG_THREADS, 256 * 8), DG_THREADS, s, rp);
     R.scnt.assign(world, 0); R.soff.assign(world + 1, 0); R.rcnt.assign(world, 0); R.roff.assign(world + 1, 0); R.all.assign((size_t)world * world, 0);
-    CK(read_u64(c->dg_cnt.p, R.scnt.data(), world));
-    for (int d = 0; d < world; ++d) R.soff[d + 1] = R.soff[d] + R.scnt[d];
+    auto local = [&]() -> int {                          // this rank's part: counts per destination, positions of the items in the send buffer
+        CK(pending);
+        CK(c->dg_cnt.alloc(3 * DG_MAX_WORLD, true)); CK(c->dg_pos.alloc(n, false));
+        RouteParams rp{ n, c->dg_dest.p, c->dg_cnt.p, c->dg_cnt.p + DG_MAX_WORLD, c->dg_cnt.p + 2 * DG_MAX_WORLD, c->dg_pos.p, world };
+        if (n) CDBG_LAUNCH(k_route_count, std::min<uint64_t>((n + DG_THREADS - 1) / DG_THREADS, 256 * 8), DG_THREADS, s, rp);
+        CK(read_u64(c->dg_cnt.p, R.scnt.data(), world));
+        for (int d = 0; d < world; ++d) R.soff[d + 1] = R.soff[d] + R.scnt[d];
+        HIPCK(hipMemcpy(c->dg_cnt.p + DG_MAX_WORLD, R.soff.data(), world * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (n) CDBG_LAUNCH(k_route_place, std::min<uint64_t>((n + DG_THREADS * DG_ITEMS - 1) / (DG_THREADS * DG_ITEMS), 256 * 8), DG_THREADS, s, rp);
+        return CDBG_OK;
+    };
+    const int rc_local = local();
+    const std::string my_err = rc_local != CDBG_OK ? g_err : std::string();
+    if (rc_local != CDBG_OK) { R.scnt.assign(world, 0); R.soff.assign(world + 1, 0); }      // (a failed rank sends nothing)
     R.n_send = R.soff[world];
-    HIPCK(hipMemcpy(c->dg_cnt.p + DG_MAX_WORLD, R.soff.data(), world * sizeof(uint64_t), hipMemcpyHostToDevice));
-    if (n) CDBG_LAUNCH(k_route_place, std::min<uint64_t>((n + DG_THREADS * DG_ITEMS - 1) / (DG_THREADS * DG_ITEMS), 256 * 8), DG_THREADS, s, rp);
     {
-        const int row = world + n_extra;
+        const int row = world + n_extra + 1;             // counts, the caller's words, this rank's status
         std::vector<uint64_t> mine(row), got((size_t)row * world);
         for (int d = 0; d < world; ++d) mine[d] = R.scnt[d];
         for (int i = 0; i < n_extra; ++i) mine[world + i] = extra[i];
+        mine[row - 1] = (uint64_t)(int64_t)rc_local;
         if (c->tr.all_gather_u64(c->tr.user, mine.data(), got.data(), row) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
+        if (rc_local != CDBG_OK) { g_err = my_err; return rc_local; }
         for (int r = 0; r < world; ++r) {
+            if (got[(size_t)r * row + row - 1]) return fail(CDBG_E_INTERNAL, "sharded glue: rank %d reported error %lld; all ranks stop", r, (long long)(int64_t)got[(size_t)r * row + row - 1]);
             for (int d = 0; d < world; ++d) R.all[(size_t)r * world + d] = got[(size_t)r * row + d];
             if (extra_all) for (int i = 0; i < n_extra; ++i) (*extra_all)[(size_t)r * n_extra + i] = got[(size_t)r * row + world + i];
         }
@@ -278,7 +290,7 @@ int glue_sharded(cdbg_ctx* c) {
     hp.unitig_off = c->unitig_off.p; hp.unitig_len = c->unitig_len.p; hp.unitig_kc = c->unitig_kc.p;
     hp.unitig_cap = ucap; hp.out_cap = ocap; hp.n_unitigs = c->cursors.p + 2; hp.out_cursor = c->cursors.p + 3; hp.error = c->derr.p; hp.own_lo = 0; hp.own_hi = NSl;
     if (NSl) CDBG_LAUNCH(k_unitig_heads, (NSl + HEADS_PER_WG - 1) / HEADS_PER_WG, GLUE_THREADS, s, hp);
-    uint64_t NR = 0;
+    uint64_t NR = 0; int rc_late = CDBG_OK;              // a rank-local failure behind the last exchange: agreed on before the ranks part
     {
         PieceRouteParams pr{}; pr.n_pieces = (uint32_t)NP; pr.k = k; pr.own = own; pr.st = st; pr.piece_n = c->piece_n.p; pr.piece_kc = c->piece_kc.p; pr.piece_boff = c->piece_boff.p; pr.dest = c->dg_dest.p;
         const uint32_t gridP = std::max<uint32_t>((uint32_t)((NP + 255) / 256), 1);
@@ -318,11 +330,12 @@ int glue_sharded(cdbg_ctx* c) {
         for (int r = 0; r < world; ++r) {
             CK(exscan_u32(c, c->dg_rlens.p + R.roff[r], c->dg_rboff.p + R.roff[r], R.rcnt[r]));
             CK(read_u64(c->dg_rboff.p + R.roff[r] + R.rcnt[r], &rtot[r]));
-            if ((rtot[r] + 63) / 64 * 16 != rbytes[r]) return fail(CDBG_E_INTERNAL, "sharded glue: rank %d sent %llu packed bytes for %llu bases", r, (unsigned long long)rbytes[r], (unsigned long long)rtot[r]);
+            if ((rtot[r] + 63) / 64 * 16 != rbytes[r] && rc_late == CDBG_OK) rc_late = fail(CDBG_E_INTERNAL, "sharded glue: rank %d sent %llu packed bytes for %llu bases", r, (unsigned long long)rbytes[r], (unsigned long long)rtot[r]);
             rbase[r + 1] = rbase[r] + (rtot[r] + 63) / 64 * 64;
         }
-        CK(c->dg_rdense.alloc(rbase[world] + 64, false));
-        for (int r = 0; r < world; ++r) {
+        // (an inconsistent stream: nothing of it is unpacked; the ranks learn of it together -- the abundance exchange's status word, or the stage's last one)
+        if (rc_late == CDBG_OK) { const int rc_a = c->dg_rdense.alloc(rbase[world] + 64, false); if (rc_a != CDBG_OK) rc_late = rc_a; }
+        for (int r = 0; r < world && rc_late == CDBG_OK; ++r) {
             if (!R.rcnt[r]) continue;
             if (rbase[r]) CDBG_LAUNCH(k_add_u64, (R.rcnt[r] + 255) / 256, 256, s, c->dg_rboff.p + R.roff[r], R.rcnt[r], rbase[r]);
             const uint64_t ch = (rtot[r] + 63) / 64;
@@ -330,6 +343,7 @@ int glue_sharded(cdbg_ctx* c) {
         }
         // -all-abundance-counts: one u32 per k-mer of every piece, same routing
         if (c->prm.all_abundance_counts) {
+            CK(agree(c, rc_late, "glue: pieces"));
             CK(c->dg_aoff.alloc(ns + world + 1, false));
             std::vector<uint64_t> abase(world + 1, 0), atot(world, 0), ab_sb(world), ab_so(world);
             for (int d = 0; d < world; ++d) {
@@ -351,7 +365,7 @@ int glue_sharded(cdbg_ctx* c) {
                 if (!R.rcnt[r]) continue;
                 CK(exscan_u32(c, c->dg_rn.p + R.roff[r], c->dg_raoff.p + R.roff[r], R.rcnt[r]));
                 uint64_t tot = 0; CK(read_u64(c->dg_raoff.p + R.roff[r] + R.rcnt[r], &tot));
-                if (tot * 4 != ab_rb[r]) return fail(CDBG_E_INTERNAL, "sharded glue: abundance stream of rank %d does not match its pieces", r);
+                if (tot * 4 != ab_rb[r]) { rc_late = fail(CDBG_E_INTERNAL, "sharded glue: abundance stream of rank %d does not match its pieces", r); break; }
                 AbStreamParams ap{ R.rcnt[r], k, 1, c->dg_rn.p + R.roff[r], c->dg_raoff.p + R.roff[r], nullptr, c->dg_rboff.p + R.roff[r], 0, c->dg_rab.p, reinterpret_cast<uint32_t*>(rbuf.p + ab_ro[r]) };
                 CDBG_LAUNCH(k_ab_stream, (R.rcnt[r] + 255) / 256, 256, s, ap);
                 HIPCK(hipStreamSynchronize(s));                             // (the next source's prefix sums reuse dg_raoff's boundary word)
@@ -359,7 +373,7 @@ int glue_sharded(cdbg_ctx* c) {
         }
     }
     // ---- emit what this rank owns ----
-    if (NR) {
+    if (NR && rc_late == CDBG_OK) {
         EmitParams ep{};
         ep.n_pieces = (uint32_t)NR; ep.k = k; ep.st = reinterpret_cast<const uint2*>(c->dg_rst.p); ep.hinfo = c->rank_a.p;
         ep.piece_n = c->dg_rn.p; ep.piece_kc = c->dg_rkc.p; ep.piece_boff = c->dg_rboff.p; ep.piece_bases = c->dg_rdense.p;
@@ -371,7 +385,7 @@ int glue_sharded(cdbg_ctx* c) {
     CK(pack_unitigs(c));
     float ms = 0; CK(t.stop(&ms));
     c->st.ms_glue = ms;
-    CK(agree(c, check_device_error(c, "sharded glue"), "glue: emit"));
+    CK(agree(c, rc_late != CDBG_OK ? rc_late : check_device_error(c, "sharded glue"), "glue: emit"));
     c->joined = false; c->xchg_done = true;
     c->st.n_glue_joined = c->n_join_local; c->st.n_unitigs = c->n_unitigs; c->st.unitig_bases = c->unitig_total;
     c->st.ms_total += c->st.ms_glue;

@@ -9,8 +9,10 @@
 //   D  validity / run-break bits from a 64-bit validity window, written as 16-bit words
 //   E  run starts are compacted into an LDS list (popcount prefix over the workgroup), then
 //      every lane handles ONE run: end search, boundary (home / traveller) rules, records.
-// Used when k-m <= SCANF_WNMAX and k <= 63 (all W=1 cases, W=2 with m >= k-48); k_scan remains
-// the generic path (k > 63, or a longer minimizer window).  Tile-local index q: byte (tile_start - 16 + q); junction jq <-> q = 15+jq.
+// Used when k <= 127: k - m <= SCANF_WNMAX from a register window; longer windows (k = 127, m = 16: 111 keys) through the TWO-LEVEL
+// window minimum (WNT = -1: a lane's 16 window minima = suffix minima of its own 16 keys, the minima of the whole 16-key blocks in
+// between -- one LDS word per block, written with the keys -- and prefix minima of the one or two blocks the windows end in) and a
+// 192-bit validity window.  k_scan remains the generic path (k > 127).  The generic scan spent 7.4 ps per base at k = 127, this one 3 - 4.  Tile-local index q: byte (tile_start - 16 + q); junction jq <-> q = 15+jq.
 #pragma once
 #include "k_scan.h"
 
@@ -41,12 +43,13 @@ CDBG_DEV uint32_t scanf_enc4(uint32_t x, uint32_t& vbits) {
 #define CDBG_SCAN_WAVES0 3
 #endif
 template <int W, int MODE, int WNT>
-__global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : WNT == 15 ? 1 : 4) k_scan_fast(ScanParams P) {
+__global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : WNT == 15 ? 1 : WNT < 0 ? 2 : 4) k_scan_fast(ScanParams P) {
     constexpr int RW = RecFmt<W>::RW;
     constexpr int CAPB = RecFmt<W>::CAPB;
     CDBG_SHARED uint32_t pk[SCANF_PKW];
     CDBG_SHARED uint32_t vm[SCANF_PKW / 2 + 4];
     CDBG_SHARED uint32_t kg[SCANF_NQ + SCANF_NQ / 16 + 32];   // keys, then g (padded layout)
+    CDBG_SHARED uint32_t blk[WNT < 0 ? SCANF_NQ / 16 + 8 : 1];   // two-level window: minimum of every 16-key block
     CDBG_SHARED uint32_t brk[SCANF_NQ / 32 + 4];              // bit q: junction q does not continue a run
     CDBG_SHARED uint32_t stt[SCANF_NQ / 32 + 4];              // bit q: junction q starts a run
     CDBG_SHARED uint16_t sl[SCANF_TILE + 16];                 // compacted run starts
@@ -97,13 +100,18 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : WN
         const uint64_t RX = ~(((uint64_t)rev2_32(w1) << 32) | rev2_32(w0));
         const int fsh = 64 - 2 * m;
         uint32_t* dst = kg + 17 * c;                       // scanf_pad(16c + s) = 17c + s for s < 16
+        uint32_t bmin = 0xFFFFFFFFu;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const uint32_t fw = (uint32_t)(X >> (fsh - 2 * s)) & mmask;
             const uint32_t rc = (uint32_t)(RX >> (2 * s)) & mmask;
-            dst[s] = mix32(rc < fw ? rc : fw) | (((xv >> s) & 1u) - 1u);      // invalid m-mer -> 0xFFFFFFFF
+            const uint32_t key = mix32(rc < fw ? rc : fw) | (((xv >> s) & 1u) - 1u);      // invalid m-mer -> 0xFFFFFFFF
+            dst[s] = key;
+            if (WNT < 0) bmin = key < bmin ? key : bmin;
         }
+        if (WNT < 0) blk[c] = bmin;
     }
+    if (WNT < 0) { for (int c = (nq_keys + 15) / 16 + tid; c < SCANF_NQ / 16 + 8; c += SCAN_THREADS) blk[c] = 0xFFFFFFFFu; }   // (blocks past the keys: never the minimum)
     __syncthreads();
     CDBG_SPH(1);
 
@@ -112,7 +120,30 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : WN
     uint32_t gq[16];
     const int nchunk_g = (15 + SCANF_TILE + 2 + 15) / 16;   // chunks containing junction q <= TILE+16
     for (int c = tid; c < nchunk_g; c += SCAN_THREADS) {    // (one iteration: nchunk_g <= 256)
-        if (WNT == 15) {
+        if (WNT < 0) {
+            // two-level: window of junction 16c + j = keys [16c + j, 16c + j + WN).  With E = (WN - 1) / 16, R = (WN - 1) % 16 it ends in block
+            // c + E at offset j + R (j + R < 16) or in block c + E + 1 at offset j + R - 16; blocks c + 1 .. c + E - 1 are covered whole
+            // (and block c + E as well in the second case).  WN >= 17 (E >= 1).
+            const int E = (WN - 1) >> 4, R = (WN - 1) & 15;
+            uint32_t a[16], pe[16], pf[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { a[i] = kg[17 * c + i]; pe[i] = kg[17 * (c + E) + i]; pf[i] = kg[17 * (c + E + 1) + i]; }
+            uint32_t mid = 0xFFFFFFFFu;                           // whole blocks c + 1 .. c + E - 1
+            for (int b = 1; b < E; ++b) { const uint32_t v = blk[c + b]; mid = v < mid ? v : mid; }
+            const uint32_t full_e = blk[c + E];
+#pragma unroll
+            for (int i = 14; i >= 0; --i) a[i] = a[i] < a[i + 1] ? a[i] : a[i + 1];          // suffix minima of the own block
+#pragma unroll
+            for (int i = 1; i < 16; ++i) { pe[i] = pe[i] < pe[i - 1] ? pe[i] : pe[i - 1]; pf[i] = pf[i] < pf[i - 1] ? pf[i] : pf[i - 1]; }   // prefix minima
+            // tail[j] = (pe ++ pf)[j + R], and the whole block c + E joins where the window runs past it: R is wave-uniform, so one of
+            // sixteen fully unrolled cases runs (constant register indices; a select chain over 32 registers per junction otherwise)
+#define CDBG_TL_CASE(RR) case RR: { _Pragma("unroll") for (int j = 0; j < 16; ++j) { const int idx = j + RR; uint32_t v = a[j] < mid ? a[j] : mid;   \
+                if (idx >= 16) v = v < full_e ? v : full_e;                                                                                    \
+                const uint32_t tv = idx < 16 ? pe[idx < 16 ? idx : 0] : pf[idx >= 16 ? idx - 16 : 0]; gq[j] = v < tv ? v : tv; } } break;
+            switch (R) { CDBG_TL_CASE(0) CDBG_TL_CASE(1) CDBG_TL_CASE(2) CDBG_TL_CASE(3) CDBG_TL_CASE(4) CDBG_TL_CASE(5) CDBG_TL_CASE(6) CDBG_TL_CASE(7)
+                         CDBG_TL_CASE(8) CDBG_TL_CASE(9) CDBG_TL_CASE(10) CDBG_TL_CASE(11) CDBG_TL_CASE(12) CDBG_TL_CASE(13) CDBG_TL_CASE(14) default: CDBG_TL_CASE(15) }
+#undef CDBG_TL_CASE
+        } else if (WNT == 15) {
             // window of exactly 15 keys (k = 31, m = 16): g[j] = min(a[j..14]) min min(a[15..j+14]), i.e. a
             // suffix minimum of the first 15 keys and a prefix minimum of the next 15: 42 min instead of 224
             uint32_t a[30];
@@ -168,13 +199,29 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : WN
         uint32_t brk16 = 0, stt16 = 0;
         if (c >= 1 && c <= SCANF_TILE / 16) {               // own junctions: q in [16, 16+TILE)
             const uint16_t* v16 = reinterpret_cast<const uint16_t*>(vm);
+            uint32_t vj, vp;
+            if (WNT < 0) {
+                // k - 1 up to 126 bases behind each of the 17 junctions: a 192-bit window (three words), the same AND-doubling
+                auto h4 = [&](int i) -> uint64_t { return (uint64_t)v16[i] | ((uint64_t)v16[i + 1] << 16) | ((uint64_t)v16[i + 2] << 32) | ((uint64_t)v16[i + 3] << 48); };
+                const uint64_t w0 = h4(c - 1), w1 = h4(c + 3), w2 = h4(c + 7), w3 = (uint64_t)v16[c + 11];
+                uint64_t Y[3] = { (w0 >> 15) | (w1 << 49), (w1 >> 15) | (w2 << 49), (w2 >> 15) | (w3 << 49) };
+                auto yw = [&](int i) -> uint64_t { uint64_t r = 0; _Pragma("unroll") for (int j = 0; j < 3; ++j) r = (i == j) ? Y[j] : r; return r; };
+                auto shr_and = [&](int sft) {                                   // Y &= Y >> sft (zero fill), sft wave-uniform, 1 .. 126
+                    const int ws = sft >> 6, bs = sft & 63;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) { const uint64_t a0 = yw(i + ws), a1 = yw(i + ws + 1); Y[i] &= bs ? ((a0 >> bs) | (a1 << (64 - bs))) : a0; }
+                };
+                { const int K1 = k - 1; int len = 1; while (2 * len <= K1) { shr_and(len); len *= 2; } if (K1 > len) shr_and(K1 - len); }
+                vj = (uint32_t)(Y[0] >> 1) & 0xFFFFu; vp = (uint32_t)Y[0] & 0xFFFFu;
+            } else {
             const uint64_t lo = (uint64_t)v16[c - 1] | ((uint64_t)v16[c] << 16) | ((uint64_t)v16[c + 1] << 32) | ((uint64_t)v16[c + 2] << 48);
             const uint64_t hi = (uint64_t)v16[c + 3] | ((uint64_t)v16[c + 4] << 16);
             // bit t of Y <- the k-1 bases starting at window bit 15+t are all valid (AND by doubling): bit j+1 is
             // junction q = 16c+j, bit j is junction q-1
             unsigned __int128 Y = (((unsigned __int128)hi << 64) | lo) >> 15;
             { const int K1 = k - 1; int len = 1; while (2 * len <= K1) { Y &= Y >> len; len *= 2; } Y &= Y >> (K1 - len); }
-            const uint32_t vj = (uint32_t)(Y >> 1) & 0xFFFFu, vp = (uint32_t)Y & 0xFFFFu;
+            vj = (uint32_t)(Y >> 1) & 0xFFFFu; vp = (uint32_t)Y & 0xFFFFu;
+            }
             const uint32_t gprev = kg[scanf_pad(16 * c - 1)];
             uint32_t eq = gq[0] == gprev ? 1u : 0u;
 #pragma unroll

@@ -381,7 +381,7 @@ def test_repartition_when_buckets_overflow(oracle, hip):
     assert st["n_big_partitions"] < 50
 
 
-@pytest.mark.parametrize("k,n_reads,read_len", [(128, 30000, 1000), (191, 20000, 1000), (255, 20000, 1000)])
+@pytest.mark.parametrize("k,n_reads,read_len", [(128, 12000, 1000), (191, 8000, 1000), (255, 8000, 1000)])
 def test_wide_kmers_gpu(oracle, hip, k, n_reads, read_len):
     """k = 128 .. 255 on the device (five-, six- and eight-word k-mers: /root/reference/README.md:91-99, spans beyond the default
     list): config-5-like reads against the oracle, automatic partitioning and one forced bucket, plus the device-side definition check"""

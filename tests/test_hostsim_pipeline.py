@@ -117,7 +117,7 @@ def test_errors(sim):
     from bcalm_amd import api
     api.Graph(30, 1, lib=sim).close()             # even k is accepted (README.md:99)
     with pytest.raises(api.CdbgError):
-        api.Graph(128, 1, lib=sim)
+        api.Graph(256, 1, lib=sim)
     with pytest.raises(api.CdbgError):
         api.Graph(2, 1, lib=sim)
     g = api.Graph(21, 1, lib=sim)
