@@ -33,7 +33,7 @@ class Stats(C.Structure):
         "unitig_bases", "n_big_partitions", "n_cycles")] + [
         ("minimizer_size", C.c_int), ("log2_partitions", C.c_int), ("kmer_words", C.c_int)] + [
         (n, C.c_float) for n in ("ms_scan_hist", "ms_scan_emit", "ms_count", "ms_compact", "ms_glue", "ms_total", "ms_exchange")] + [
-        (n, C.c_uint64) for n in ("n_launch_scan", "n_launch_count", "n_launch_compact", "n_multipass_partitions", "n_tiles_overlapped", "n_split_buckets", "n_glue_rounds")]
+        (n, C.c_uint64) for n in ("n_launch_scan", "n_launch_count", "n_launch_compact", "n_multipass_partitions", "n_tiles_overlapped", "n_split_buckets", "n_glue_rounds", "n_walked_unitigs")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

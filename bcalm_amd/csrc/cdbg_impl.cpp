@@ -27,6 +27,7 @@
 #include "k_links.h"
 #include "k_verify.h"
 #include "k_dglue.h"
+#include "k_walk.h"
 #include "comm.h"
 #include "k_count_fast.h"
 #include "k_compact_wave.h"

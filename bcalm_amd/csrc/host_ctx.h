@@ -237,6 +237,7 @@ struct cdbg_ctx {
     DBuf<uint32_t> piece_ab, unitig_ab;          // -all-abundance-counts
     DBuf<uint64_t> link_off; DBuf<uint32_t> link_to; uint64_t n_links = 0; bool linked = false;
     DBuf<uint4> rank_a, rank_b; DBuf<uint32_t> rank_flag;
+    DBuf<uint4> walk_rec; DBuf<uint32_t> walk_heads, walk_hlen; DBuf<uint64_t> walk_hoff; bool walk_off = false;   // chains walked from their heads (k_walk.h); walk_off: a run of this context had a chain the walk does not take
     // multi-GPU: transport (RCCL or caller-supplied) and the record exchange buffers
     cdbg_transport tr{}; bool have_tr = false; uint64_t comm_bytes = 0;
     bool tr_ordered = false;                             // the transport enqueues on the context's stream (built-in RCCL): no host sync around a device-buffer collective

@@ -72,6 +72,49 @@ int glue_join_impl(cdbg_ctx* c, bool sharded) {
 }
 
 
+// Glue, second half on one GPU: the chains walked from their heads (k_walk.h).  *done = false: some chain was too long or
+// closed -- the caller ranks (link[] is untouched).
+int glue_walk(cdbg_ctx* c, bool* done) {
+    hipStream_t s = c->stream;
+    const uint64_t NP = c->n_pieces, NS = 2 * NP;
+    *done = false;
+    if (!NP) return CDBG_OK;
+    const uint64_t ucap = std::max<uint64_t>(NP, 1);
+    const uint64_t ocap = std::max<uint64_t>(c->n_piece_bases, 1);
+    CK(c->unitig_off.alloc(ucap, false)); CK(c->unitig_len.alloc(ucap, false)); CK(c->unitig_kc.alloc(ucap, false));
+    CK(c->unitig_bases.alloc(ocap + 64, false));             // (+ 64: the 2-bit packing pass reads whole 64-base chunks)
+    if (c->prm.all_abundance_counts) CK(c->unitig_ab.alloc(ocap, false));
+    CK(c->rank_flag.alloc(4, true));
+    CK(c->walk_rec.alloc(NS, false)); CK(c->walk_heads.alloc(NS, false)); CK(c->walk_hlen.alloc(NS, false)); CK(c->walk_hoff.alloc(NS, false));
+    HIPCK(hipMemsetAsync(c->cursors.p + 2, 0, 2 * sizeof(uint64_t), s));
+    HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+    HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
+    HIPCK(hipMemsetAsync(c->rank_flag.p, 0, sizeof(uint32_t), s));
+    uint32_t max_steps = 4096;
+    if (const char* e = getenv("CDBG_WALK_MAX")) max_steps = (uint32_t)strtoul(e, nullptr, 10);
+    // dstats: [4] live pieces, [5] pieces the kept walks visited, [6] head states (stays on the device: the launches cover the upper bound)
+    uint64_t* const n_heads = c->dstats.p + 6;
+    WalkInitParams ip{ (uint32_t)NP, c->piece_n.p, c->piece_kc.p, c->piece_boff.p, c->link.p, c->walk_rec.p, c->walk_heads.p, n_heads, c->dstats.p + 4 };
+    CDBG_LAUNCH(k_walk_init, (NP + WALK_PIECES - 1) / WALK_PIECES, WALK_THREADS, s, ip);
+    const uint64_t spans = (NS + WALK_SPAN - 1) / WALK_SPAN, wave_grid = (spans + WALK_THREADS / 64 - 1) / (WALK_THREADS / 64);
+    WalkMeasureParams mp{ c->walk_rec.p, c->walk_heads.p, n_heads, c->walk_hlen.p, max_steps, c->rank_flag.p };
+    CDBG_LAUNCH(k_walk_measure, wave_grid, WALK_THREADS, s, mp);
+    WalkPlaceParams pp{ n_heads, c->walk_hlen.p, c->walk_hoff.p, c->k, c->cursors.p + 2, c->cursors.p + 3, ucap, ocap, c->derr.p };
+    CDBG_LAUNCH(k_walk_place, spans, WALK_THREADS, s, pp);
+    WalkCopyParams wp{};
+    wp.k = c->k; wp.rec = c->walk_rec.p; wp.piece_bases = c->piece_bases.p;
+    wp.heads = c->walk_heads.p; wp.n_heads = n_heads; wp.hlen = c->walk_hlen.p; wp.hoff = c->walk_hoff.p;
+    wp.unitig_off = c->unitig_off.p; wp.unitig_len = c->unitig_len.p; wp.unitig_kc = c->unitig_kc.p; wp.out = c->unitig_bases.p; wp.visited = c->dstats.p + 5;
+    wp.piece_ab = c->prm.all_abundance_counts ? c->piece_ab.p : nullptr; wp.unitig_ab = c->unitig_ab.p;
+    CDBG_LAUNCH(k_walk_copy, wave_grid, WALK_THREADS, s, wp);
+    HIPCK(hipStreamSynchronize(s));
+    uint64_t d[2]; CK(read_u64(c->dstats.p + 4, d, 2));      // live, visited
+    uint32_t gave_up = 0; CK(read_u32(c->rank_flag.p, &gave_up));
+    if (gave_up || d[1] != d[0]) { c->walk_off = true; return CDBG_OK; }    // a chain beyond max_steps, or closed chains (no head, never visited)
+    *done = true;
+    return CDBG_OK;
+}
+
 template <int W>
 int glue_impl(cdbg_ctx* c) {
     if (c->stage < 2) return fail(CDBG_E_STATE, "cdbg_glue before cdbg_compact");
@@ -92,6 +135,22 @@ int glue_impl(cdbg_ctx* c) {
     const float ms_join = c->st.ms_glue;
     HostMarks hm;
     Timer t; CK(t.start(s));
+    // one GPU: walk the chains from their heads; chains the walk does not take (too long, closed) -> list ranking below, for the rest of this context's life
+    bool walked = false;
+    if (c->prm.world_size <= 1 && !c->force_multi && !c->xchg_done && !c->walk_off && getenv("CDBG_GLUE_RANK") == nullptr) CK(glue_walk(c, &walked));
+    if (walked) {
+        { uint64_t cur[2]; CK(read_u64(c->cursors.p + 2, cur, 2)); c->n_unitigs = cur[0]; c->unitig_total = cur[1]; }
+        CK(pack_unitigs(c));
+        float ms_fin = 0; CK(t.stop(&ms_fin));
+        hm.mark("glue: walk + copy");
+        c->st.ms_glue = ms_join + ms_fin;
+        CK(check_device_error(c, "glue"));
+        c->joined = false;
+        c->st.n_glue_joined = c->n_join_local; c->st.n_unitigs = c->n_unitigs; c->st.unitig_bases = c->unitig_total; c->st.n_walked_unitigs = c->n_unitigs;
+        c->st.ms_total += c->st.ms_glue;
+        c->stage = 3;
+        return CDBG_OK;
+    }
     DBuf<uint32_t>& flag = c->rank_flag; DBuf<uint4>& st_a = c->rank_a; DBuf<uint4>& st_b = c->rank_b;
     CK(st_a.alloc(NS, false)); CK(st_b.alloc(NS, false));
     CK(flag.alloc(4, true));

@@ -71,6 +71,8 @@ typedef struct cdbg_stats_t {
     uint64_t n_split_buckets;        /* buckets that no LDS tier of the compaction could take and that were split by sub-minimizer (k_split.h) */
     uint64_t n_glue_rounds;          /* multi-GPU sharded glue: query / reply rounds of the distributed list ranking (0: single GPU, or
                                         the replicated exchange -- emit_replicated, or closed chains across ranks) */
+    uint64_t n_walked_unitigs;       /* unitigs written by walks from the chain heads (k_walk.h: one GPU, no chain beyond the step limit, no
+                                        closed chain); 0: the list-ranking path of k_glue.h glued this run */
 } cdbg_stats_t;
 
 /* error codes */

@@ -219,13 +219,17 @@ def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, rea
                 assert a == [solid[min(s[i:i + k], s[i:i + k].translate(comp)[::-1])] for i in range(len(s) - k + 1)] and sum(a) == kc
 
 
-@pytest.mark.parametrize("mode", ["log", "table", "overflow"])
+@pytest.mark.parametrize("mode", ["log", "table", "overflow", "rank", "walkmax"])
 @pytest.mark.parametrize("k,n_reads,read_len,cfg", [(31, 100000, 150, 3), (55, 40000, 150, 4), (127, 4000, 1000, 5)])
 def test_glue_record_paths_gpu(oracle, hip, mode, k, n_reads, read_len, cfg, monkeypatch):
-    """the default single-rank path puts the glue records straight into the join buckets from the compaction kernels;
-    the sequential log + scatter pass, the global-table join and the bucket-overflow fallback must give the same graph"""
-    monkeypatch.setenv({"log": "CDBG_GLUE_LOG", "table": "CDBG_GLUE_TABLE", "overflow": "CDBG_JOIN_LOG_JB"}[mode], "0" if mode == "overflow" else "1")
-    assert_parity(oracle, hip, oracle.synth_reads(n_reads, read_len, cfg), k, 2)
+    """the default single-rank path puts the glue records straight into the join buckets from the compaction kernels and walks
+    the chains from their heads; the sequential log + scatter pass, the global-table join, the bucket-overflow fallback, the
+    list-ranking path (rank) and the walk that gives up on a chain of more than one piece and hands over to the ranking
+    (walkmax) must give the same graph"""
+    monkeypatch.setenv({"log": "CDBG_GLUE_LOG", "table": "CDBG_GLUE_TABLE", "overflow": "CDBG_JOIN_LOG_JB", "rank": "CDBG_GLUE_RANK", "walkmax": "CDBG_WALK_MAX"}[mode],
+                       "0" if mode in ("overflow", "walkmax") else "1")
+    st = assert_parity(oracle, hip, oracle.synth_reads(n_reads, read_len, cfg), k, 2)["stats"]
+    assert st["n_walked_unitigs"] == (0 if mode in ("rank", "walkmax") else st["n_unitigs"])
 
 
 @pytest.mark.parametrize("k", [55, 127])

@@ -141,7 +141,7 @@ def test_capped_single_pass_scan(oracle, sim, key, part_cap, monkeypatch):
 
 
 @pytest.mark.parametrize("key", ["rand_a/15/2", "rand_w2/55/2", "rand_w4/127/1", "circ_test3/7/1"])
-@pytest.mark.parametrize("mode", ["log", "table", "overflow"])
+@pytest.mark.parametrize("mode", ["log", "table", "overflow", "rank", "walkmax"])
 def test_glue_record_paths(oracle, sim, key, mode, monkeypatch):
     """single-rank contexts put the glue records straight into the join buckets (the default, every other test);
     here the other paths: the sequential log + scatter pass (what multi-rank contexts exchange), the global-table join,
@@ -150,13 +150,19 @@ def test_glue_record_paths(oracle, sim, key, mode, monkeypatch):
         monkeypatch.setenv("CDBG_GLUE_LOG", "1")
     elif mode == "table":
         monkeypatch.setenv("CDBG_GLUE_TABLE", "1")
+    elif mode == "rank":                                   # list ranking instead of the walk from the heads (k_walk.h)
+        monkeypatch.setenv("CDBG_GLUE_RANK", "1")
+    elif mode == "walkmax":                                # the walk gives up on any chain of more than one piece: link[] rebuilt, ranking
+        monkeypatch.setenv("CDBG_WALK_MAX", "0")
     else:
         monkeypatch.setenv("CDBG_JOIN_LOG_JB", "0")
     name, k, amin = _case(key)
     text = oracle_lib.read_input(name)
     if mode == "overflow":
         text = text + oracle.synth_reads(400, 150, 3).decode() if isinstance(text, str) else text + oracle.synth_reads(400, 150, 3)
-    assert_parity(oracle, sim, text, k, amin, log2_partitions=5)
+    st = assert_parity(oracle, sim, text, k, amin, log2_partitions=5)["stats"]
+    walked = not (mode in ("rank", "walkmax") or st["n_cycles"])        # (closed chains have no head: the walk hands over to the ranking)
+    assert st["n_walked_unitigs"] == (st["n_unitigs"] if walked else 0)
 
 
 def test_spilled_and_deferred_partition_is_reported(sim, monkeypatch):

@@ -121,7 +121,7 @@ def test_even_k_palindromic_kmer_is_its_own_unitig(oracle):
     assert got["stats"]["unitigs"] == 3 and sorted(len(s) for s in seqs) == [12, 12 + len(left) - 1, 12 + len(right) - 1]
     assert op.unitigs(read + "\n", 12, 1)[0] == got["unitigs"]
     with pytest.raises(ValueError):
-        oracle.run("ACGTACGTACGT\n", 128, 1)
+        oracle.run("ACGTACGTACGT\n", 256, 1)
 
 
 EVAL = os.path.join(ROOT, "oracle", "_ref", "unitigEvaluator")
