@@ -442,7 +442,26 @@ int count_impl(cdbg_ctx* c) {
     hm.mark("count: tier 1");
     CK(read_u32(c->big_count.p + 1, &nretry));
     const uint32_t* retry_ptr = c->retry_list.p;
-    if constexpr (W <= 4) if (nretry && getenv("CDBG_NO_COUNT_TIER2") == nullptr) {   // (wider keys: a table twice the size does not fit the LDS)
+    // second tier, k-mers of three words and more under an abundance filter: the sifting tier (k_count_fast.h) -- fingerprints first,
+    // exact counts only for what was seen again; two workgroups per CU instead of one, and partitions of up to 6000 distinct k-mers
+    // fit: config-5 share 67 (4096-slot tier) + 52 (multi-pass) -> 82 + 17 ms.  Two-word k-mers keep the 4096-slot tier (k = 55: more
+    // than half of the occurrences are of k-mers seen again, and reading them twice costs more than the small table saves: 141 -> 149 ms)
+    const bool sift = W >= 3 && c->prm.abundance_min >= 2 && getenv("CDBG_NO_SIFT") == nullptr;
+    if constexpr (W >= 3) if (nretry && sift && getenv("CDBG_NO_COUNT_TIER2") == nullptr) {
+        CK(c->retry_list2.alloc(nretry, false));
+        HIPCK(hipMemsetAsync(c->big_count.p + 2, 0, sizeof(uint32_t), s));
+        CountParams c2 = cp; c2.part_list = c->retry_list.p; c2.n_items = nretry;
+        CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2, count_fast_record_limit<W>(c->k), 192u };   // (admission: predicted distinct k-mers beyond 3/4 of the fingerprint words -> multi-pass kernel untried)
+        if (const char* e = getenv("CDBG_FAST_SKIP2_Q8")) fp2.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
+        constexpr int TSS = 512, FSS = 8192, NTS = 512;       // (exact table: a quarter of tier 1's slots)
+        const uint64_t grid = std::min<uint64_t>(nretry, 256 * 2);
+        if (capped) CDBG_LAUNCH((k_count_fast<W, TSS, NTS, 3, FSS>), grid, NTS, s, fp2);
+        else CDBG_LAUNCH((k_count_fast<W, TSS, NTS, 2, FSS>), grid, NTS, s, fp2);
+        HIPCK(hipStreamSynchronize(s));
+        CK(read_u32(c->big_count.p + 2, &nretry));
+        retry_ptr = c->retry_list2.p;
+    }
+    if constexpr (W <= 4) if (nretry && !sift && getenv("CDBG_NO_COUNT_TIER2") == nullptr) {   // (wider keys: a table twice the size does not fit the LDS)
         // second tier: the same one-pass kernel with a table twice the size (one workgroup per CU) over the retry list; at the
         // config-5 share 6 % of the partitions -- a minimizer locus of long reads -- cost 250 of 590 ms in the multi-pass kernel
         CK(c->retry_list2.alloc(nretry, false));

@@ -72,10 +72,12 @@ template <int W> struct CountGeom {
 //                plus the record's four boundary facts in the top bits (see where it is written)
 //   smask        per wave: bit g set <=> a record of the batch starts at member position g
 //   emask        per wave: bit g set <=> the member at position g is the last of a record that has something to say about it
-template <int W, int TS, int NT>
+//   fp           sifting tier only (FS > 0, below): FS fingerprint words
+template <int W, int TS, int NT, int FS = 0>
 struct CountFastLds {
     uint64_t keys[TS * W];
     uint32_t cnt[TS];
+    uint32_t fp[FS > 0 ? FS : 1]; uint32_t fpfill;       // fpfill: distinct fingerprints of the partition
     uint64_t stage[(NT / 64) * CountCb<W>::V * RecFmt<W>::RW + 2];   // + 2: the dword window of the last record may over-read (up to 4 dwords)
     uint64_t smask[(NT / 64) * CountGeom<W>::MASKW];
     uint64_t emask[(NT / 64) * CountGeom<W>::MASKW];
@@ -186,10 +188,22 @@ CDBG_DEV void count_issue_ahead(const CountParams& P, CountAhead<W, CAPPED>& A, 
     A.issued = true;
 }
 
+// Sifting tier (FS > 0; multi-word k-mers, abundance-min >= 2).  At k = 127 and 1 % errors 95 % of the distinct k-mers of a
+// partition occur once and are dropped by the abundance filter -- yet each of them takes a slot of 8 W + 4 bytes, and the
+// partitions they overfill went through a 4096-slot tier that leaves room for ONE workgroup per CU and then through the
+// multi-pass kernel (config-5 share: 67 + 52 of 201 ms of counting for 7 % of the partitions).  Here a partition is read
+// twice: the first pass leaves a 30-bit fingerprint of every k-mer in a table of FS 4-byte words, with "seen again" in bit 1;
+// the second pass gives the exact table only the k-mers whose fingerprint was seen again.  Exact all the same: a fingerprint
+// seen once IS one occurrence of one k-mer (counted as a distinct k-mer of abundance 1 on the spot), and k-mers that share
+// a fingerprint are told apart by their keys in the exact table as before.  The exact table is a quarter of tier 1's.
 // returns false when the partition did not fit one pass (table left dirty)
-template <int W, int TS, int NT, int CAPPED>
-CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>& L, const CountRange& rg, CountAhead<W, CAPPED>& A,
+template <int W, int TS, int NT, int CAPPED, int FS = 0>
+CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT, FS>& L, const CountRange& rg, CountAhead<W, CAPPED>& A,
                                    const uint32_t par, uint64_t& chunk_base, uint32_t& chunk_left, CountAcc& acc) {
+    constexpr bool SIFT = FS > 0;
+    static_assert(!SIFT || W > 1, "the sifting tier is written for multi-word k-mers");
+    constexpr int LOG_FS = FS == 16384 ? 14 : FS == 8192 ? 13 : FS == 4096 ? 12 : FS == 2048 ? 11 : 0;
+    static_assert(!SIFT || LOG_FS > 0, "fingerprint table size");
     constexpr int RW = RecFmt<W>::RW;
     constexpr int NW = NT / 64;
     constexpr int MASKW = CountGeom<W>::MASKW;
@@ -208,9 +222,12 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
 
     uint64_t w0, w1; count_share<W, NW>(rg, wave, w0, w1);
     CDBG_FPH(0);
-    uint32_t n_new = 0;                                                       // wave-uniform: keys this wave added
+    uint32_t n_new = 0, n_fp = 0;                                             // wave-uniform: keys / fingerprints this wave added
+    uint32_t n_once = 0;                                                      // (sifting tier) this lane's home k-mers of abundance 1: counted when the partition has fitted
     constexpr uint32_t LCAP = (uint32_t)(TS / NW);                             // list entries of a wave (CountList)
     const uint32_t lbase = (uint32_t)wave * LCAP;
+#pragma clang loop unroll(disable)
+    for (int phase = SIFT ? 0 : 1; phase < 2; ++phase) {                       // (sifting tier: 0 = fingerprints, 1 = exact counts of what was seen again)
     RecView<W> R = A.cur->R;
     for (uint64_t c0 = w0; c0 < w1; c0 += 64) {                               // wave-uniform
         if (c0 != w0) count_load_chunk<W>(P, c0, w1, lane, R);                 // (the first 64 records came prefetched)
@@ -296,8 +313,40 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
                     // the key carries the foreign-junction flags (KEY_FOREIGN_*, k_count.h): the same for every occurrence
                     // (bits 31 / 30 of `facts`: right / left junction foreign in read orientation; bits 29 / 28: the same two swapped)
                     const uint64_t ktop = can.w[W - 1] | ((uint64_t)((rev ? facts << 2 : facts) & 0xC0000000u) << 32);
-                    uint32_t s = can.hash_lds() >> (32 - LOG_TS);
-                    bool hit;
+                    const uint32_t hh = can.hash_lds();
+                    uint32_t s = hh >> (32 - LOG_TS);
+                    bool hit = true, go = true;
+                    if constexpr (SIFT) {
+                        // the fingerprint's slot: the hash's top bits; its 30-bit tag: a mix of all of them (bit 0 set: never 0 = free)
+                        uint32_t fs = hh >> (32 - LOG_FS);
+                        const uint32_t tag = (((hh ^ (hh >> 15)) * 0x2C1B3C6Du) & ~3u) | 1u;
+                        uint32_t probes = 0;
+                        if (phase == 0) {
+                            go = false;
+#pragma clang loop unroll(disable)
+                            for (;;) {
+                                const uint32_t old = atomic_cas_u32(&L.fp[fs], 0u, tag);
+                                if (old == 0u) { is_new = true; break; }
+                                if ((old & ~2u) == tag) { if (!(old & 2u)) atomic_or_u32(&L.fp[fs], 2u); break; }
+                                fs = (fs + 1) & (FS - 1);
+                                if (++probes == 64u) { hit = false; break; }
+                            }
+                        } else {
+                            uint32_t old;
+#pragma clang loop unroll(disable)
+                            for (;;) {                                         // (the tag is there: pass 0 put it -- unless the table overflowed, and then the partition is given up)
+                                old = L.fp[fs];
+                                if ((old & ~2u) == tag || old == 0u || ++probes == 64u) break;
+                                fs = (fs + 1) & (FS - 1);
+                            }
+                            if (!(old & 2u)) {                                 // seen once: one k-mer of abundance 1
+                                go = false;
+                                if (!trav) ++n_once;
+                            }
+                        }
+                    }
+                    if (!go) { if (!hit) L.over = 1; }
+                    else {
                     if (W == 1) {
                         // only `old` and `s` live out of the probe loop: every flag carried across its back edge costs three
                         // scalar mask operations per probe, and the longest probe sequence of the 64 lanes sets the trip count
@@ -349,8 +398,10 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
                         if (trav) atomic_or_u32(&L.cnt[s], CountList<W>::ON ? CF_TRAV16 : TRAV_FLAG);
                     }
                     if (CountList<W>::ON) slot_new = s;
+                    }
                 }
                 const uint64_t nb = __ballot(is_new);
+                if (SIFT && phase == 0) { n_fp += (uint32_t)__popcll(nb); continue; }
                 if (CountList<W>::ON) {
                     // used-slot list: the wave's j-th new key leaves its slot in the upper half of count word wave * LCAP + j
                     const uint32_t pos = n_new + (uint32_t)__popcll(nb & (lane_le >> 1));
@@ -363,6 +414,13 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
             CDBG_WAVE_SYNC();
         }
     }
+    if (SIFT && phase == 0) {
+        if (!A.issued) count_issue_ahead<W, NW, CAPPED>(P, A, wave, lane);
+        if (lane == 0 && n_fp) atomic_add_u32(&L.fpfill, n_fp);
+        CDBG_LDS_BARRIER();                                                       // ---- every fingerprint is in ----
+        if (uni_u32(L.over) || uni_u32(L.fpfill) > (uint32_t)(FS - FS / 4)) { acc.last_fill = uni_u32(L.fpfill); return false; }   // uniform
+    }
+    }
     if (!A.issued) count_issue_ahead<W, NW, CAPPED>(P, A, wave, lane);                // (a wave without records of this partition)
     if (lane == 0 && n_new) atomic_add_u32(&L.fill[par], n_new);
     if (CountList<W>::ON && n_new > LCAP && lane == 0) L.over = 1;             // (more new keys than the wave's list holds: next tier)
@@ -370,8 +428,9 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
     CDBG_LDS_BARRIER();                                                           // ---- barrier A: all inserts done ----
     CDBG_FPH(3);
     const uint32_t need = uni_u32(L.fill[par]);
-    if (W > 1) acc.last_fill = need;                                           // (what the admission rule of the caller learns from)
+    if (W > 1) acc.last_fill = SIFT ? uni_u32(L.fpfill) : need;                // (what the admission rule of the caller learns from)
     if (uni_u32(L.over) || need > (uint32_t)(TS - TS / 4)) return false;       // uniform
+    if (SIFT) { acc.dist += n_once; acc.occ += n_once; }
     if (need > chunk_left) {                                                   // uniform: new chunk (one device atomic per COUNT_CHUNK entries)
         if (tid == 0) L.cbase = atomic_add_u64(P.solid_cursor, (uint64_t)COUNT_CHUNK);
         CDBG_LDS_BARRIER();
@@ -444,6 +503,11 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
             L.cnt[sl] = 0;
         }
     }
+    if constexpr (SIFT) {                                                      // the fingerprints go: 16 bytes per store
+        uint4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
+        for (int i = tid; i < FS / 4; i += NT) reinterpret_cast<uint4*>(L.fp)[i] = z;
+        if (tid == 0) L.fpfill = 0;
+    }
     if (tid == 0) { L.fill[par ^ 1u] = 0; L.wr[par ^ 1u] = 0; }               // the next partition's counters (nobody touches them now)
     CDBG_FPH(4);
     CDBG_LDS_BARRIER();                                                           // ---- barrier B: sweep done, table clean ----
@@ -456,9 +520,11 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT>
 
 // the rare path's table reset, kept out of line so that its address arithmetic is not hoisted into (and spilled
 // around) the partition loop
-template <int W, int TS, int NT>
-CDBG_NOINLINE CDBG_DEV_NOINL void count_fast_clear(CountFastLds<W, TS, NT>& L) {
+template <int W, int TS, int NT, int FS>
+CDBG_NOINLINE CDBG_DEV_NOINL void count_fast_clear(CountFastLds<W, TS, NT, FS>& L) {
     const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < (uint32_t)(FS > 0 ? FS : 1); i += NT) L.fp[i] = 0;
+    if (tid == 0) L.fpfill = 0;
     for (uint32_t i = tid; i < (uint32_t)TS; i += NT) { L.keys[(uint64_t)i * W + (W - 1)] = KEY_EMPTY; L.cnt[i] = 0; }
     for (uint32_t i = tid; i < (uint32_t)((NT / 64) * CountGeom<W>::MASKW); i += NT) { L.smask[i] = 0; L.emask[i] = 0; }
     if (tid == 0) { L.fill[0] = L.fill[1] = 0; L.wr[0] = L.wr[1] = 0; L.over = 0; }
@@ -471,9 +537,9 @@ CDBG_NOINLINE CDBG_DEV_NOINL void count_fast_clear(CountFastLds<W, TS, NT>& L) {
 #ifndef CDBG_CF_WAVES2
 #define CDBG_CF_WAVES2 6
 #endif
-template <int W, int TS, int NT, int CAPPED>
-__global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, TS, NT>), NT, W == 1 ? 6 : W == 2 ? CDBG_CF_WAVES2 : 3)) k_count_fast(CountFastParams FP) {   // waves per SIMD that the LDS tables allow: 3 workgroups x 2 waves (W = 1)
-    CDBG_SHARED CountFastLds<W, TS, NT> L;
+template <int W, int TS, int NT, int CAPPED, int FS = 0>
+__global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, TS, NT, FS>), NT, W == 1 ? 6 : W == 2 ? CDBG_CF_WAVES2 : 3)) k_count_fast(CountFastParams FP) {   // waves per SIMD that the LDS tables allow: 3 workgroups x 2 waves (W = 1)
+    CDBG_SHARED CountFastLds<W, TS, NT, FS> L;
     const CountParams& P = FP.c;
     constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)uni_u32((uint32_t)tid >> 6);
@@ -483,7 +549,7 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, 
     ca.t_prev = clock64();
 #endif
     uint64_t chunk_base = 0; uint32_t chunk_left = 0;
-    count_fast_clear<W, TS, NT>(L);
+    count_fast_clear<W, TS, NT, FS>(L);
     CDBG_LDS_BARRIER();
     // software pipeline: range words two partitions ahead, this wave's records one partition ahead
     const uint32_t stride = gridDim.x;
@@ -514,10 +580,10 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, 
             if (W > 1 && FP.skip_fill_q8) {              // (uniform; one-word k-mers never use the rule)
                 if (CountBal<W>::ON && rg_cur.n <= 64u) size = wave_readlane_u32(wave_incl_sum_u32((uint32_t)cur.R.n()), 63);   // (lanes without a record hold zeros)
                 else if (CountBal<W>::ON) size = rg_cur.n * 64u;   // (more than one chunk of records: big; any large number will do)
-                if ((((uint64_t)size * dpu_q8) >> 8) * 256u > (uint64_t)TS * FP.skip_fill_q8) try_fast = false;
+                if ((((uint64_t)size * dpu_q8) >> 8) * 256u > (uint64_t)(FS > 0 ? FS : TS) * FP.skip_fill_q8) try_fast = false;
             }
             if (try_fast && rg_cur.n < FP.fast_max_records) {   // (a partition that could carry a count to the 31-bit ceiling goes to the saturating kernels)
-                done = count_partition_fast<W, TS, NT, CAPPED>(P, L, rg_cur, A, par, chunk_base, chunk_left, ca);
+                done = count_partition_fast<W, TS, NT, CAPPED, FS>(P, L, rg_cur, A, par, chunk_base, chunk_left, ca);
                 if (W > 1 && FP.skip_fill_q8) {          // (a partition that did not fit still says: at least this many distinct k-mers)
                     const uint32_t sample = (uint32_t)((float)ca.last_fill * 256.0f / (float)(size ? size : 1u));
                     dpu_q8 = dpu_q8 ? (uint32_t)((int32_t)dpu_q8 + (((int32_t)sample - (int32_t)dpu_q8) >> 4)) : sample;
@@ -525,7 +591,7 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(sizeof(CountFastLds<W, 
                 if (done) { par ^= 1u; misses = 0; deferred = 0; }
                 else {                                   // leave a clean table and known counters behind
                     CDBG_LDS_BARRIER();
-                    count_fast_clear<W, TS, NT>(L);
+                    count_fast_clear<W, TS, NT, FS>(L);
                     par = 0; ++misses;
                     CDBG_LDS_BARRIER();
                 }

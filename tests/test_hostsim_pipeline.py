@@ -221,6 +221,25 @@ def test_count_tiers(oracle, sim, k, glen, mode, monkeypatch):
     assert got["stats"]["n_multipass_partitions"] == (0 if small else 1)
 
 
+@pytest.mark.parametrize("k", [64, 96, 127, 160])
+@pytest.mark.parametrize("case", ["sifted", "solid_overflow", "fingerprint_overflow"])
+def test_count_sift_tier(oracle, sim, k, case):
+    """k-mers of three words and more under an abundance filter: ONE partition of mostly once-seen k-mers overflows the one-pass table and
+    goes to the sifting tier (fingerprints first, exact counts for what was seen again: k_count_fast.h); too many k-mers seen
+    again for its small exact table, or too many fingerprints, and the multi-pass kernel takes the partition"""
+    import random
+    rng = random.Random(k * 7 + len(case))
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    solid_len = {"sifted": 250, "solid_overflow": 1500, "fingerprint_overflow": 250}[case] + k
+    noise = {"sifted": 26, "solid_overflow": 8, "fingerprint_overflow": 90}[case]
+    g = rnd(solid_len)
+    reads = [g, g, g[5:], g[::-1].translate(str.maketrans("ACGT", "TGCA"))] + [rnd(k + 99) for _ in range(noise)]
+    # a k-mer seen once inside an otherwise repeated read, and a once-seen k-mer whose reverse complement comes from another read
+    reads.append(g[:k + 10] + rnd(1) + g[k + 11:2 * k + 30])
+    got = assert_parity(oracle, sim, "\n".join(reads) + "\n", k, 2, log2_partitions=0)
+    assert got["stats"]["n_multipass_partitions"] == (0 if case == "sifted" else 1), got["stats"]
+
+
 @pytest.mark.parametrize("k,amin,log_np,m", [(128, 1, 0, 0), (128, 2, 3, 0), (160, 1, 2, 12), (191, 2, 3, 16), (192, 1, 1, 0), (224, 1, 0, 0), (255, 1, 4, 16), (255, 2, 2, 0)])
 def test_wide_kmers_beyond_the_default_span_list(oracle, sim, k, amin, log_np, m):
     """k = 128 .. 255 (five- to eight-word k-mers: the KSIZE_LIST entries beyond 128 that the reference takes as a build option,
