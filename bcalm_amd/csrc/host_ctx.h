@@ -379,7 +379,12 @@ void configure(cdbg_ctx* c, uint64_t total_bytes) {
     //  must hold fewer occurrences for its distinct k-mers to fit the one-pass table.  0.3 tables' worth until the count
     //  tiers learned to send a partition that will not fit straight to the bigger table; with that, twice the partition size
     //  halves the per-partition fixed costs for less than it adds to the second tier: 316 -> 307 ms at the config-5 share)
-    const uint64_t target_occ = W >= 3 ? (uint64_t)ts * 6 / 10 : (uint64_t)ts * CDBG_OCC_NUM / CDBG_OCC_DEN;
+    //  Round 4: behind the sifting tier (k_count_fast.h: abundance-min >= 2) an overfull partition costs two reads of its records
+    //  instead of the 4096-slot tier and the multi-pass kernel, and twice the partition size again wins: the config-5 share holds
+    //  3.7 M minimizer loci, i.e. 0.44 per partition at 2^23 (64 % of the partitions empty) -- 2^22: count 175.8 -> 162.8 ms, step
+    //  231.6 -> 222.9 ms; 2^21: 281.6 ms, 2^24: 279.0 ms (profiles/r04_ab_cfg5_partitions.log))
+    const bool sifted = W >= 3 && c->prm.abundance_min >= 2;
+    const uint64_t target_occ = W >= 3 ? (uint64_t)ts * (sifted ? 12 : 6) / 10 : (uint64_t)ts * CDBG_OCC_NUM / CDBG_OCC_DEN;
     int log_np = c->log_np_override >= 0 ? c->log_np_override : c->prm.log2_partitions;
     if (log_np < 0) {
         log_np = 0;

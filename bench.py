@@ -47,7 +47,7 @@ def lib_srchash():
         return None
 
 
-GLUE_LABEL = "glue(k_join_bucket+k_rank8_*+k_unitig_heads+k_emit)"
+GLUE_LABEL = "glue(k_join_bucket+k_walk_init+k_walk_measure+k_walk_place+k_walk_copy)"
 
 
 def pmc_traffic(kernel_key, cfg):
@@ -432,9 +432,9 @@ def main():
         gpu_ms = acc["ms_total"] / a.steps
         Wk = W_OF(a.k)
         pmc_keys = {"k_count_fast": "k_count_fast<%d, %d, " % (Wk, {1: 4096}.get(Wk, 2048)), "k_compact_wave": "k_compact_wave<",
-                    "k_scan<emit>": "k_scan_fast<%d, 2" % Wk if a.k <= 63 else "k_scan<%d, 2" % Wk,
-                    "k_scan<hist>": "k_scan_fast<%d, 0" % Wk if a.k <= 63 else "k_scan<%d, 0" % Wk,
-                    GLUE_LABEL: ["k_join_bucket", "k_rank8", "k_unitig_heads", "k_emit"]}
+                    "k_scan<emit>": "k_scan_fast<%d, 2" % Wk if a.k <= 127 else "k_scan<%d, 2" % Wk,
+                    "k_scan<hist>": "k_scan_fast<%d, 0" % Wk if a.k <= 127 else "k_scan<%d, 0" % Wk,
+                    GLUE_LABEL: ["k_join_bucket", "k_walk_", "k_rank8", "k_unitig_heads", "k_emit"]}   # (k_rank8 / k_unitig_heads / k_emit: only when the walk handed over to the ranking)
         # every stage kernel with its own roofline numbers; the PMC table is quoted only while it was taken from THESE kernels
         # (its header carries the content hash of the sources libcdbg.so was built from)
         cur_hash = lib_srchash()
@@ -480,7 +480,7 @@ def main():
                                      if sharded else "independent read sets per rank (no collective)"),
                        "exchange": xinfo,
                        "minimizer_size": st["minimizer_size"], "log2_partitions": st["log2_partitions"]},
-            "counts": {x: st[x] for x in ("n_occurrences", "n_distinct", "n_solid", "n_pieces", "n_unitigs", "n_records", "n_big_partitions", "n_multipass_partitions", "n_cycles")},
+            "counts": {x: st[x] for x in ("n_occurrences", "n_distinct", "n_solid", "n_pieces", "n_unitigs", "n_records", "n_big_partitions", "n_multipass_partitions", "n_cycles", "n_walked_unitigs")},
             "checks": checks, "checks_passed": all(checks.values()),
             "digest": {"set_digest": "%016x" % dig_last["set_digest"], "kc_sum": dig_last["kc_sum"], "kmers_in_unitigs": dig_last["kmers_in_unitigs"]},
             "verify": verify_info,

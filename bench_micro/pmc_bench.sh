@@ -17,7 +17,7 @@ done
 CFG=$cfg python - <<PY
 import csv, collections, glob, os, subprocess
 root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out"; cfg = os.environ["CFG"]
-GATHER = ("k_rank8_jump", "k_rank_jump", "k_emit", "k_unitig_heads", "k_dr_jump", "k_dr_reply", "k_dr_apply", "k_pair_apply", "k_link_", "k_heads_measure")
+GATHER = ("k_walk_measure", "k_walk_copy", "k_rank8_jump", "k_rank_jump", "k_emit", "k_unitig_heads", "k_dr_jump", "k_dr_reply", "k_dr_apply", "k_pair_apply", "k_link_", "k_heads_measure")
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.defaultdict(collections.Counter)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"{root}/pmc{cfg}_{c}/**/*counter_collection.csv", recursive=True):
