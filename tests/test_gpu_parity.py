@@ -232,6 +232,23 @@ def test_glue_record_paths_gpu(oracle, hip, mode, k, n_reads, read_len, cfg, mon
     assert st["n_walked_unitigs"] == (0 if mode in ("rank", "walkmax") else st["n_unitigs"])
 
 
+@pytest.mark.parametrize("k", [64, 127, 160])
+@pytest.mark.parametrize("case", ["sifted", "solid_overflow", "fingerprint_overflow"])
+def test_count_sift_tier_gpu(oracle, hip, k, case):
+    """k-mers of three words and more under an abundance filter, ONE partition of mostly once-seen k-mers that overflows the
+    one-pass table: the sifting tier (fingerprints first, exact counts for what was seen again: k_count_fast.h) takes it; too
+    many k-mers seen again for its small exact table, or too many fingerprints, and the multi-pass kernel does"""
+    rng = random.Random(k * 7 + len(case))
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    solid_len = {"sifted": 250, "solid_overflow": 1500, "fingerprint_overflow": 250}[case] + k
+    noise = {"sifted": 26, "solid_overflow": 8, "fingerprint_overflow": 90}[case]
+    g = rnd(solid_len)
+    reads = [g, g, g[5:], g[::-1].translate(str.maketrans("ACGT", "TGCA"))] + [rnd(k + 99) for _ in range(noise)]
+    reads.append(g[:k + 10] + rnd(1) + g[k + 11:2 * k + 30])
+    got = assert_parity(oracle, hip, "\n".join(reads) + "\n", k, 2, log2_partitions=0)
+    assert got["stats"]["n_multipass_partitions"] == (0 if case == "sifted" else 1), got["stats"]
+
+
 @pytest.mark.parametrize("k", [55, 127])
 def test_identical_multiword_keys_in_one_wave_gpu(oracle, hip, k):
     """the same multi-word k-mers from every lane of a wave (2000 copies of one read, both strands) on the device: a wave has
