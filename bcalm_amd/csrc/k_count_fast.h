@@ -51,6 +51,18 @@ template <int W> struct CountCb { static constexpr int V = W >= 3 ? CDBG_CB_WIDE
 // read.  A wave that claims more than its TS / waves entries flags the partition for the next tier (at three quarters of
 // the slots the partition is refused anyway).  Multi-word k-mers keep the full sweep: 4 slots per thread there.
 template <int W> struct CountList { static constexpr bool ON = W == 1; };
+// Shared stage (two-word k-mers; CDBG_COUNT_SHARED).  With a share of the RECORDS per wave (87 records of 1 .. 66 members over 8
+// waves at the config-4 share) a wave holds 194 +- 46 member k-mers: 3.03 steps of 64 lanes on average -- four steps, the last
+// one nearly empty -- and the workgroup waits for its fullest wave: the wait at the insert barrier was 28 - 32 % of a wave's time
+// (CDBG_PROFILE_PHASES, round 4).  A partition of at most COUNT_SHARED_RECORDS records is instead staged ONCE for the whole
+// workgroup (the per-wave stages, masks and record words are one pool of exactly that size), member positions run through the
+// partition, and the 64-member steps are dealt out round robin: every step full but the last, every wave within one step of
+// the others, for two more LDS barriers per partition: count 141.5 -> 137.2 ms at the config-4 share.  Larger partitions take the per-wave path below.
+#ifndef CDBG_COUNT_SHARED
+#define CDBG_COUNT_SHARED 1
+#endif
+template <int W> struct CountShared { static constexpr bool ON = W == 2 && CDBG_COUNT_SHARED; };
+constexpr uint32_t COUNT_SHARED_MEMBERS = 4096;          // 64 mask words: one lane each in the prefix popcount
 constexpr uint32_t CF_TRAV16 = 0x8000u;                  // the traveller flag in a 16-bit count
 // (host) partitions of at least this many records are not tried by the one-pass kernel: a k-mer occurs at most once per member
 // position, so below it no count reaches 2^15 (CountList) / the saturation threshold of the 31-bit counts
@@ -82,6 +94,7 @@ struct CountFastLds {
     uint64_t smask[(NT / 64) * CountGeom<W>::MASKW];
     uint64_t emask[(NT / 64) * CountGeom<W>::MASKW];
     uint32_t rinfo[(NT / 64) * CountCb<W>::V];
+    uint32_t wsum[NT / 64];                              // (shared stage) member k-mers of every wave's records
     uint32_t fill[2], wr[2];                             // per partition parity: new keys / solid entries written
     uint32_t over;
     uint64_t cbase;                                      // chunk hand-out broadcast
@@ -226,6 +239,108 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT,
     uint32_t n_once = 0;                                                      // (sifting tier) this lane's home k-mers of abundance 1: counted when the partition has fitted
     constexpr uint32_t LCAP = (uint32_t)(TS / NW);                             // list entries of a wave (CountList)
     const uint32_t lbase = (uint32_t)wave * LCAP;
+    bool shared_done = false;
+    if constexpr (CountShared<W>::ON && FS == 0) {
+        constexpr uint32_t SREC = (uint32_t)(NW * COUNT_CB);                   // records the pooled stage holds
+        static_assert(NW * MASKW >= (int)(COUNT_SHARED_MEMBERS / 64), "the pooled masks must cover COUNT_SHARED_MEMBERS positions");
+        if (rg.n <= SREC) {                                                   // uniform; every wave's share is in its prefetched registers (<= 64 records)
+            const RecView<W>& R = A.cur->R;
+            const uint32_t nrec_w = (uint32_t)(w1 - w0);
+            const uint32_t nfull = (uint32_t)lane < nrec_w ? (uint32_t)R.n() : 0u;
+            const uint32_t incl = wave_incl_sum_u32(nfull);
+            const bool odd = __any((uint32_t)lane < nrec_w && nfull == 0u);     // (a record without members would shift the ranks: per-wave path)
+            const uint32_t wtot = wave_readlane_u32(incl, 63);
+            if (lane == 0) L.wsum[wave] = odd ? COUNT_SHARED_MEMBERS + 1u : wtot;
+            CDBG_LDS_BARRIER();                                                   // ---- every wave's member count is known ----
+            uint32_t base = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const uint32_t v = uni_u32(L.wsum[w]); if (w < wave) base += v; total += v; }
+            if (total <= COUNT_SHARED_MEMBERS) {                              // uniform
+                shared_done = true;
+                if ((uint32_t)lane < nrec_w) {
+                    const uint32_t gi = (uint32_t)(w0 - rg.rec0) + (uint32_t)lane;   // the record's index in the partition = its rank among the start bits
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) L.stage[gi * RW + i] = R.r[i];
+                    const uint32_t excl = base + incl - nfull, meta = (uint32_t)R.r[0];
+                    const uint32_t f0 = (meta >> 10) & 1u, f1 = (meta >> 11) & 1u, ft = (meta >> 8) & 1u, lt = (meta >> 9) & 1u;
+                    L.rinfo[gi] = (RBITS - 2u * (uint32_t)k + 2u * excl) | (f1 << 31) | (f0 << 30) | (f0 << 29) | (f1 << 28) | (ft << 27) | (lt << 26);   // (low 14 bits: < 256 + 2 * 4096)
+                    atomic_or_u64(&L.smask[excl >> 6], 1ULL << (excl & 63u));
+                    const uint32_t last = excl + nfull - 1u;
+                    if (f1 | lt) atomic_or_u64(&L.emask[last >> 6], 1ULL << (last & 63u));
+                }
+                if (!A.issued) { CDBG_FPH(1); count_issue_ahead<W, NW, CAPPED>(P, A, wave, lane); }
+                CDBG_LDS_BARRIER();                                               // ---- stage, record words and masks are complete ----
+                // records that start before each 64-member word: prefix popcount, one mask word per lane
+                const uint32_t words = (total + 63u) >> 6;
+                const uint32_t pc = (uint32_t)lane < words ? (uint32_t)__popcll(L.smask[lane]) : 0u;
+                const uint32_t before_word = wave_incl_sum_u32(pc) - pc;
+                // (steps TAKEN one by one from an LDS counter instead of dealt round robin: 138.2 against 137.2 ms at the config-4 share)
+                for (uint32_t g0 = 64u * (uint32_t)wave; g0 < total; g0 += 64u * (uint32_t)NW) {   // wave-uniform
+                    const uint32_t wi = g0 >> 6;
+                    const uint64_t M = uni_u64(L.smask[wi]), E = uni_u64(L.emask[wi]);
+                    const uint32_t started = wave_readlane_u32(before_word, (int)wi);
+                    const uint32_t g = g0 + (uint32_t)lane;
+                    bool is_new = false;
+                    if (g < total) {
+                        const uint32_t slot = started + (uint32_t)__popcll(M & lane_le) - 1u;
+                        const uint32_t ri = L.rinfo[slot];
+                        const uint32_t sh = (ri & 0x3FFFu) - 2u * g;
+                        const uint32_t as_first = lane_pick_u32(M, ri, lane), as_last = lane_pick_u32(E, ri, lane);
+                        const uint32_t facts = (as_first & 0x68000000u) | (as_last & ~0x68000000u);
+                        const bool trav = (facts & 0x0C000000u) != 0u;
+                        const uint32_t* dw = reinterpret_cast<const uint32_t*>(L.stage + slot * RW) + (sh >> 5);
+                        uint32_t in[2 * W + 1];
+#pragma unroll
+                        for (int j = 0; j < 2 * W + 1; ++j) in[j] = dw[j];
+                        Kmer<W> fw;
+#pragma unroll
+                        for (int i = 0; i < W; ++i)
+                            fw.w[i] = ((uint64_t)alignbit_u32(in[2 * i + 2], in[2 * i + 1], sh) << 32) | alignbit_u32(in[2 * i + 1], in[2 * i], sh);
+                        fw.mask(k);
+                        const Kmer<W> rc = fw.rc(k);
+                        const bool rev = rc < fw;
+                        const Kmer<W>& can = rev ? rc : fw;
+                        const uint64_t ktop = can.w[W - 1] | ((uint64_t)((rev ? facts << 2 : facts) & 0xC0000000u) << 32);
+                        uint32_t s = can.hash_lds() >> (32 - LOG_TS);
+                        const uint64_t top = ktop, ptop = key_pending(ktop);
+                        uint32_t probes = 0;
+                        bool hit = false;
+#pragma clang loop unroll(disable)
+                        do {                                                   // (the claim protocol of the per-wave path below)
+                            uint64_t* const slotp = &L.keys[(uint64_t)s * W];
+                            const uint64_t old = atomic_cas_u64(slotp + (W - 1), KEY_EMPTY, ptop);
+                            bool eq = true;
+                            if (W == 2) {
+                                CDBG_COMPILER_BARRIER();
+                                eq = slotp[0] == can.w[0];
+                            } else if (old == top) {
+#pragma unroll
+                                for (int i = 0; i < W - 1; ++i) eq &= (slotp[i] == can.w[i]);
+                            }
+                            const bool mine = old == KEY_EMPTY, same = (old == top) & eq, wait = old == ptop;
+                            if (wait) CDBG_SPIN_YIELD();
+                            if (mine) {
+#pragma unroll
+                                for (int i = 0; i < W - 1; ++i) slotp[i] = can.w[i];
+                                CDBG_LDS_FENCE();
+                                atomic_exch_u64(slotp + (W - 1), top);
+                            }
+                            is_new = is_new | mine; hit = mine | same;
+                            const bool advance = !(hit | wait);
+                            s = advance ? ((s + 1) & (TS - 1)) : s; probes += advance ? 1u : 0u;
+                        } while (!hit && probes < 64u);
+                        if (!hit) L.over = 1;
+                        else {
+                            atomic_add_u32(&L.cnt[s], 1u);
+                            if (trav) atomic_or_u32(&L.cnt[s], TRAV_FLAG);
+                        }
+                    }
+                    n_new += (uint32_t)__popcll(__ballot(is_new));
+                }
+            }
+        }
+    }
+    if (!shared_done)
 #pragma clang loop unroll(disable)
     for (int phase = SIFT ? 0 : 1; phase < 2; ++phase) {                       // (sifting tier: 0 = fingerprints, 1 = exact counts of what was seen again)
     RecView<W> R = A.cur->R;
@@ -507,6 +622,9 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT,
         uint4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
         for (int i = tid; i < FS / 4; i += NT) reinterpret_cast<uint4*>(L.fp)[i] = z;
         if (tid == 0) L.fpfill = 0;
+    }
+    if (CountShared<W>::ON && FS == 0 && shared_done) {                        // (uniform) the pooled masks go back clean
+        for (int i = tid; i < (int)(COUNT_SHARED_MEMBERS / 64) + 1 && i < NW * MASKW; i += NT) { L.smask[i] = 0; L.emask[i] = 0; }
     }
     if (tid == 0) { L.fill[par ^ 1u] = 0; L.wr[par ^ 1u] = 0; }               // the next partition's counters (nobody touches them now)
     CDBG_FPH(4);
