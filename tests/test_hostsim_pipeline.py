@@ -249,7 +249,7 @@ def test_wide_kmers_beyond_the_default_span_list(oracle, sim, k, amin, log_np, m
     rng = random.Random(k)
     g = "".join(rng.choice("ACGT") for _ in range(5000))
     reads = []
-    for i in range(100):
+    for i in range(40):
         L = rng.randrange(200, 900); s0 = rng.randrange(0, len(g) - L)
         r = g[s0:s0 + L]
         if rng.random() < 0.5:
@@ -265,8 +265,8 @@ def test_wide_kmers_beyond_the_default_span_list(oracle, sim, k, amin, log_np, m
     gg.push_text(text); gg.run(); assert_verified(gg); gg.close()
 
 
-@pytest.mark.parametrize("k,cfg,n_reads,read_len,log_np,part_min", [(31, 3 | 0x100, 3000, 150, 6, None), (31, 3, 3000, 150, 5, None), (55, 4 | 0x100, 1500, 150, 4, None),
-                                                                     (127, 5 | 0x100, 200, 1000, 3, None), (21, 3 | 0x100, 3000, 150, 6, 1), (64, 4 | 0x100, 1500, 150, 4, 1)])
+@pytest.mark.parametrize("k,cfg,n_reads,read_len,log_np,part_min", [(31, 3 | 0x100, 1500, 150, 6, None), (31, 3, 1500, 150, 5, None), (55, 4 | 0x100, 700, 150, 4, None),
+                                                                     (127, 5 | 0x100, 60, 1000, 3, None), (21, 3 | 0x100, 1500, 150, 6, 1), (64, 4 | 0x100, 700, 150, 4, 1)])
 def test_single_pass_scan_into_estimated_regions(oracle, sim, k, cfg, n_reads, read_len, log_np, part_min, monkeypatch):
     """CDBG_SCAN_MODE=var: the record layout of skewed inputs -- one scan pass into regions of their own size per partition,
     estimated from a sampled histogram; with CDBG_PART_CAP=1 the estimate is made useless on purpose (every busy partition
@@ -355,7 +355,7 @@ def test_result_digest_matches_formula(oracle, sim):
     """cdbg_digest (what bench.py asserts at full size) against the same formula evaluated on the ORACLE's unitigs"""
     from bcalm_amd import api
     from parity import set_digest
-    for k, amin, n, L, cfg in ((31, 2, 3000, 150, 3), (55, 1, 1500, 150, 4)):
+    for k, amin, n, L, cfg in ((31, 2, 1200, 150, 3), (55, 1, 600, 150, 4)):
         text = oracle.synth_reads(n, L, cfg)
         exp = oracle.run(text, k, amin, want_solid=True)
         g = api.Graph(k, amin, lib=sim)
