@@ -32,14 +32,21 @@ namespace cdbg {
 // records per wave batch (W >= 3: CDBG_CB_WIDE -- records of up to 122-153 members fill the 64-lane steps with far fewer of them)
 // Member-capped batches (one-word k-mers).  A batch of 16 records of k = 31 holds 120 +- 20 members: a third of the batches
 // spilled a handful of members into a third 64-lane step, and the wave's steps ran at 80 % of their lanes (the kernel is
-// bound by VALU issue).  A batch is now the longest run of records with at most CF_BATCH_MEMBERS = 128 members (and at most
-// COUNT_CB = 24 records): exactly two steps, the second one nearly full; the position masks shrink from 14 words to 2 per
-// wave, which pays for the larger stage.
+// bound by VALU issue).  A batch is now the longest run of records with at most CF_BATCH_MEMBERS members (and at most
+// COUNT_CB = 24 records): whole steps, the last one nearly full; the position masks shrink from 14 words to 3 per wave, which
+// pays for the larger stage.  128 members (two steps): count 67.4 -> 61.5 ms at config 3; 192 (three steps, a wave's ~400
+// members in 3 batches instead of 4): 64.1 -> 59.0 ms on one box, 63.8 -> 58.7 on another (profiles/r04_ab_cfg3_count_batch_members.log;
+// 256: 59.7; 20 / 26 / 28 / 32 records per batch: 60.9 / 70.8 / 70.5 / 70.8 -- beyond 24 the workgroup's LDS no longer fits
+// three to a CU).
 #ifndef CDBG_CB1
 #define CDBG_CB1 24
 #endif
 template <int W> struct CountCap { static constexpr bool ON = W == 1; };
-constexpr uint32_t CF_BATCH_MEMBERS = 128;
+#ifndef CDBG_CF_BATCH
+#define CDBG_CF_BATCH 192
+#endif
+constexpr uint32_t CF_BATCH_MEMBERS = CDBG_CF_BATCH;
+static_assert(CF_BATCH_MEMBERS % 64 == 0, "whole 64-lane steps (and mask words)");
 template <int W> struct CountCb { static constexpr int V = W >= 3 ? CDBG_CB_WIDE : W == 1 ? CDBG_CB1 : 16; };
 // Used-slot list (one-word k-mers).  The sweep of a 4096-slot table for the ~960 keys of a config-3 partition was 19 of the
 // kernel's 67 ms.  Every wave now notes the slots its own lanes claimed and sweeps exactly those.  The list costs no LDS: a
