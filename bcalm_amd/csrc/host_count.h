@@ -403,8 +403,12 @@ int count_impl(cdbg_ctx* c) {
 
     // count
     // (slack: every persistent workgroup of every launch of the stage may strand one partly used chunk)
-    // (launches of the stage: one-pass tier 1, tier 2 of at most 256 workgroups, multi-pass retry, spill repair, HBM tables)
-    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + (4 * std::min<uint64_t>(NPL, PERSISTENT_GRID) + 256 + 5) * (uint64_t)COUNT_CHUNK;
+    // (launches of the stage: one-pass tier 1 of COUNT_GRID workgroups, tier 2 of at most SIFT_GRID, multi-pass retry, spill repair, HBM tables)
+#ifndef CDBG_SIFT_GRID
+#define CDBG_SIFT_GRID (256 * 16)
+#endif
+    constexpr uint64_t SIFT_GRID = CDBG_SIFT_GRID;
+    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + (std::min<uint64_t>(NPL, COUNT_GRID) + 3 * std::min<uint64_t>(NPL, PERSISTENT_GRID) + SIFT_GRID + 768 + 5) * (uint64_t)COUNT_CHUNK;
     CK(c->solid_keys.alloc(solid_cap * W, false));
     CK(c->solid_cnt.alloc(solid_cap, false));
     CK(c->solid_cursor.alloc(4, true));
@@ -433,8 +437,8 @@ int count_impl(cdbg_ctx* c) {
         CountFastParams fp{ cp, c->retry_list.p, c->big_count.p + 1, count_fast_record_limit<W>(c->k), W == 1 ? 0u : W == 2 ? 177u : 200u };
         if (const char* e = getenv("CDBG_FAST_SKIP_Q8")) fp.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
         if (const char* e = getenv("CDBG_FAST_MAX_RECORDS")) fp.fast_max_records = std::min<uint32_t>(count_fast_record_limit<W>(c->k), (uint32_t)std::max(1, atoi(e)));   // dev knob
-        if (capped) CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, true>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, fp);
-        else CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(NPL, PERSISTENT_GRID), Cfg<W>::NTC, s, fp);
+        if (capped) CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, true>), std::min<uint64_t>(NPL, COUNT_GRID), Cfg<W>::NTC, s, fp);
+        else CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(NPL, COUNT_GRID), Cfg<W>::NTC, s, fp);
     }
     c->st.n_launch_count = NPL;
     uint32_t nretry = 0;
@@ -454,7 +458,7 @@ int count_impl(cdbg_ctx* c) {
         CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2, count_fast_record_limit<W>(c->k), 192u };   // (admission: predicted distinct k-mers beyond 3/4 of the fingerprint words -> multi-pass kernel untried)
         if (const char* e = getenv("CDBG_FAST_SKIP2_Q8")) fp2.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
         constexpr int TSS = 512, FSS = 8192, NTS = 512;       // (exact table: a quarter of tier 1's slots)
-        const uint64_t grid = std::min<uint64_t>(nretry, 256 * 2);
+        const uint64_t grid = std::min<uint64_t>(nretry, SIFT_GRID);    // (two workgroups per CU are resident; the rest take turns: COUNT_GRID, host_ctx.h)
         if (capped) CDBG_LAUNCH((k_count_fast<W, TSS, NTS, 3, FSS>), grid, NTS, s, fp2);
         else CDBG_LAUNCH((k_count_fast<W, TSS, NTS, 2, FSS>), grid, NTS, s, fp2);
         HIPCK(hipStreamSynchronize(s));

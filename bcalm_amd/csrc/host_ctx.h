@@ -153,6 +153,13 @@ template <> struct Cfg<3> { static constexpr int TSC = TS_COUNT_4, TSK = TS_COMP
 #define CDBG_PGRID (256 * 12)
 #endif
 constexpr uint64_t PERSISTENT_GRID = CDBG_PGRID;     // persistent workgroups for the per-partition kernels (256 CUs)
+// the one-pass count kernel: 768 workgroups are resident (3 per CU); the more take turns, the shorter the tail in which the last ones
+// run alone -- count at config 3: 63.8 / 61.2 / 58.7 / 57.7 / 57.1 / 56.6 ms with 768 / 1536 / 3072 / 6144 / 12288 / 24576 workgroups
+// (profiles/r04_ab_cfg3_count_grid.log); every workgroup may strand one output chunk, hence the smaller COUNT_CHUNK (k_count.h)
+#ifndef CDBG_COUNT_GRID
+#define CDBG_COUNT_GRID (256 * 48)
+#endif
+constexpr uint64_t COUNT_GRID = CDBG_COUNT_GRID;
 // workgroups of `kern` that are resident at once on the whole device: the grid of a persistent kernel whose
 // workgroups stride over equal work items must be exactly this (a partial extra generation would run alone)
 template <class K>

@@ -25,7 +25,7 @@ namespace cdbg {
 // per-wave member map entries (records of a batch x members per record).  Kept small on purpose: with
 // 416 B per wave the W=1 kernel stays under 53 KB of LDS = 3 workgroups (24 waves) per CU, which
 // measured 13 % faster than 64-record batches at 2 workgroups per CU.
-constexpr uint32_t COUNT_CHUNK = 32768;                // solid entries a workgroup reserves per device atomic
+constexpr uint32_t COUNT_CHUNK = 8192;                 // solid entries a workgroup reserves per device atomic (>= 3/4 of the largest one-pass table)
 constexpr uint32_t TRAV_FLAG = 0x80000000u;          // in a count word: this entry is a traveller copy
 // Abundances are 31-bit and SATURATE (gatb-core's own ceiling is its `-abundance-max` default 2147483647 [UPSTREAM-RECALL]):
 // exact below COUNT_SAT, reported as COUNT_MAX = 2^31 - 1 from there on.  The one-pass kernel (k_count_fast.h) cannot
