@@ -408,7 +408,17 @@ int count_impl(cdbg_ctx* c) {
 #define CDBG_SIFT_GRID (256 * 16)
 #endif
     constexpr uint64_t SIFT_GRID = CDBG_SIFT_GRID;
-    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + (std::min<uint64_t>(NPL, COUNT_GRID) + 3 * std::min<uint64_t>(NPL, PERSISTENT_GRID) + SIFT_GRID + 768 + 5) * (uint64_t)COUNT_CHUNK;
+#ifndef CDBG_T2_GRID
+#define CDBG_T2_GRID 256
+#endif
+#ifndef CDBG_MP_GRID_W
+#define CDBG_MP_GRID_W 256
+#endif
+#ifndef CDBG_MP_GRID_1
+#define CDBG_MP_GRID_1 (256 * 48)                          // (one-word multi-pass kernel on the hostile line: count 92.4 -> 86.9 ms with 12288 instead of 3072 workgroups;
+#endif                                                   //  2048 instead of 256 for the wider kernels: neutral at k = 55, + 3 ms at k = 127 -- profiles/r04_ab_cfg3_count_grid.log)
+    constexpr uint64_t T2_GRID = CDBG_T2_GRID, MP_GRID_W = CDBG_MP_GRID_W, MP_GRID_1 = CDBG_MP_GRID_1;
+    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + (std::min<uint64_t>(NPL, COUNT_GRID) + 3 * std::min<uint64_t>(NPL, PERSISTENT_GRID) + SIFT_GRID + T2_GRID + 2 * (MP_GRID_1 > MP_GRID_W ? MP_GRID_1 : MP_GRID_W) + 768 + 5) * (uint64_t)COUNT_CHUNK;
     CK(c->solid_keys.alloc(solid_cap * W, false));
     CK(c->solid_cnt.alloc(solid_cap, false));
     CK(c->solid_cursor.alloc(4, true));
@@ -481,8 +491,8 @@ int count_impl(cdbg_ctx* c) {
 #define CDBG_NT_TIER2 1024
 #endif
         constexpr int NT2 = W == 1 ? Cfg<W>::NTC : CDBG_NT_TIER2;
-        if (capped) CDBG_LAUNCH((k_count_fast<W, 2 * TS, NT2, 3>), std::min<uint64_t>(nretry, 256), NT2, s, fp2);
-        else CDBG_LAUNCH((k_count_fast<W, 2 * TS, NT2, 2>), std::min<uint64_t>(nretry, 256), NT2, s, fp2);
+        if (capped) CDBG_LAUNCH((k_count_fast<W, 2 * TS, NT2, 3>), std::min<uint64_t>(nretry, T2_GRID), NT2, s, fp2);
+        else CDBG_LAUNCH((k_count_fast<W, 2 * TS, NT2, 2>), std::min<uint64_t>(nretry, T2_GRID), NT2, s, fp2);
         HIPCK(hipStreamSynchronize(s));
         CK(read_u32(c->big_count.p + 2, &nretry));
         retry_ptr = c->retry_list2.p;
@@ -493,7 +503,7 @@ int count_impl(cdbg_ctx* c) {
         rp1.part_list = retry_ptr; rp1.n_items = nretry;
         // (multi-word k-mers: the table of the second tier and 1024 threads -- half the passes at 16 waves per CU: 45 -> 39 ms at the config-5 share)
         constexpr int TSG = W == 1 ? TS : 2 * TS, NTG = W == 1 ? Cfg<W>::NTC : 1024;
-        CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(nretry, W == 1 ? PERSISTENT_GRID : 256), NTG, s, rp1);
+        CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(nretry, W == 1 ? MP_GRID_1 : MP_GRID_W), NTG, s, rp1);
     }
     if (n_spilled_parts) {                                   // spilled partitions: count their gathered copies
         CountParams rp2 = cp;
@@ -501,7 +511,7 @@ int count_impl(cdbg_ctx* c) {
         rp2.n_items = (uint32_t)n_spilled_parts; rp2.max_passes = 4096;
         if (const char* ev = getenv("CDBG_REPAIR_MAX_PASSES")) rp2.max_passes = (uint32_t)std::max(1, atoi(ev));   // (tests: a spilled partition that is deferred as well)
         constexpr int TSG = W == 1 ? TS : 2 * TS, NTG = W == 1 ? Cfg<W>::NTC : 1024;
-        CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(rp2.n_items, W == 1 ? PERSISTENT_GRID : 256), NTG, s, rp2);
+        CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(rp2.n_items, W == 1 ? MP_GRID_1 : MP_GRID_W), NTG, s, rp2);
     }
     uint32_t nbig = 0;
     HIPCK(hipStreamSynchronize(s));
