@@ -11,6 +11,9 @@ inline bool scan_is_fast(const cdbg_ctx* c) {
     if (getenv("CDBG_GENERIC_SCAN")) return false;          // (test knob: the generic kernel for every shape)
     return (c->k <= 63 && wn <= SCANF_WNMAX) || (c->k <= 127 && wn > SCANF_WNMAX && wn >= 17);
 }
+#ifndef CDBG_SCAN_GEN
+#define CDBG_SCAN_GEN 8                                   // workgroups per resident place of the register-window scan: 1 -> 4 / 16: scan 69.3 -> 66.0 / 65.6 ms at config 3 (profiles/r04_ab_cfg3_scan_grid.log)
+#endif
 // the scan kernel for this k / m / mode on the context's stream (persistent grid: resident workgroups)
 template <int W, int MODE>
 void launch_scan_mode(cdbg_ctx* c, ScanParams& sp, uint64_t grid) {
@@ -19,19 +22,19 @@ void launch_scan_mode(cdbg_ctx* c, ScanParams& sp, uint64_t grid) {
     sp.n_tiles = grid;
     if (fast_scan && c->k - c->m > SCANF_WNMAX) {           // the two-level window minimum (k_scan_fast.h, WNT = -1): k <= 127 with a long minimizer window
         if (grid == 0) return;
-        CDBG_LAUNCH((k_scan_fast<W, MODE, -1>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, -1>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);
+        CDBG_LAUNCH((k_scan_fast<W, MODE, -1>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, -1>, SCAN_THREADS, SCANF_GRID) * CDBG_SCAN_GEN), SCAN_THREADS, s, sp);
         return;
     }
     if (grid == 0) return;                                   // (a rank without reads)
     // compile-time minimizer windows (k - m): the k = 31 family m = 16 .. 12 and k = 55, m = 16 (config 4)
 #define CDBG_SCAN_WNT(WW, WNT_)                                                                                                  \
     if (fast_scan && W == WW && c->k - c->m == WNT_) {                                                                           \
-        CDBG_LAUNCH((k_scan_fast<W, MODE, W == WW ? WNT_ : 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, W == WW ? WNT_ : 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp); \
+        CDBG_LAUNCH((k_scan_fast<W, MODE, W == WW ? WNT_ : 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, W == WW ? WNT_ : 0>, SCAN_THREADS, SCANF_GRID) * CDBG_SCAN_GEN), SCAN_THREADS, s, sp); \
         return;                                                                                                                  \
     }
     CDBG_SCAN_WNT(1, 15) CDBG_SCAN_WNT(1, 16) CDBG_SCAN_WNT(1, 17) CDBG_SCAN_WNT(1, 18) CDBG_SCAN_WNT(1, 19) CDBG_SCAN_WNT(2, 39)
 #undef CDBG_SCAN_WNT
-    if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE, 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, 0>, SCAN_THREADS, SCANF_GRID)), SCAN_THREADS, s, sp);
+    if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE, 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, 0>, SCAN_THREADS, SCANF_GRID) * CDBG_SCAN_GEN), SCAN_THREADS, s, sp);
     else CDBG_LAUNCH((k_scan<W, MODE>), std::min<uint64_t>(grid, resident_grid(k_scan<W, MODE>, SCAN_THREADS, SCAN_GRID)), SCAN_THREADS, s, sp);
 }
 inline uint64_t scan_tile_bytes(const cdbg_ctx* c) { return scan_is_fast(c) ? (uint64_t)SCANF_TILE : (uint64_t)SCAN_TILE; }
