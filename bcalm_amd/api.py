@@ -39,9 +39,11 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-EXPORTS = ["cdbg_create", "cdbg_destroy", "cdbg_release_cached", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
-           "cdbg_generate_reads", "cdbg_expect_input", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
+ABI_VERSION = 5                                        # include/cdbg.h CDBG_ABI_VERSION this binding was written for
+EXPORTS = ["cdbg_abi_version", "cdbg_stats_sizeof", "cdbg_create", "cdbg_destroy", "cdbg_release_cached", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
+           "cdbg_generate_reads", "cdbg_expect_input", "cdbg_stage_acquire", "cdbg_stage_commit", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
            "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats", "cdbg_digest", "cdbg_verify",
+           "cdbg_verify_edges", "cdbg_verify_unitigs",
            "cdbg_fetch_unitigs_packed", "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", 
            "cdbg_set_transport", "cdbg_comm_unique_id", "cdbg_comm_init_rccl", "cdbg_comm_bytes"]
 
@@ -72,6 +74,10 @@ def load(path: str | None = None) -> C.CDLL:
         _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    lib.cdbg_stats_sizeof.restype = u64
+    if lib.cdbg_abi_version() != ABI_VERSION or lib.cdbg_stats_sizeof() != C.sizeof(Stats):
+        raise CdbgError(-1, f"{path}: ABI version {lib.cdbg_abi_version()} / cdbg_stats_t of {lib.cdbg_stats_sizeof()} bytes, "
+                            f"this binding expects version {ABI_VERSION} / {C.sizeof(Stats)} bytes")
     lib.cdbg_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
     lib.cdbg_destroy.argtypes = [vp]
     lib.cdbg_destroy.restype = None
@@ -80,6 +86,8 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_push_text.argtypes = [vp, C.c_char_p, u64]
     lib.cdbg_generate_reads.argtypes = [vp, u64, u64, u64, u64, i32]
     lib.cdbg_expect_input.argtypes = [vp, u64]
+    lib.cdbg_stage_acquire.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    lib.cdbg_stage_commit.argtypes = [vp, vp, u64]
     lib.cdbg_read_text.argtypes = [vp, u64, u64, C.c_char_p]
     for f in ("cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset"):
         getattr(lib, f).argtypes = [vp]
@@ -91,6 +99,9 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.cdbg_digest.argtypes = [vp, C.POINTER(u64)]
     lib.cdbg_verify.argtypes = [vp, C.POINTER(u64)]
+    lib.cdbg_verify_edges.argtypes = [vp, C.POINTER(u64)]
+    lib.cdbg_verify_unitigs.argtypes = [vp, C.c_char_p, C.POINTER(u64), u64, C.POINTER(u64)]
+    lib.cdbg_release_cached.argtypes = []
     lib.cdbg_fetch_unitig_abundances.argtypes = [vp, u64, u64, C.POINTER(C.c_uint32), C.POINTER(u64)]
     lib.cdbg_link.argtypes = [vp]
     lib.cdbg_num_links.argtypes = [vp, C.POINTER(u64)]
@@ -143,6 +154,25 @@ class Graph:
     def push_text(self, text):
         b = text if isinstance(text, (bytes, bytearray)) else text.encode()
         self._ck(self.lib.cdbg_push_text(self._h, bytes(b), len(b)))
+
+    def stage_text(self, text):
+        """push_text through the zero-copy staging calls (cdbg_stage_acquire / cdbg_stage_commit): `text` is cut at sequence
+        boundaries into pieces that fit a staging buffer"""
+        b = text if isinstance(text, (bytes, bytearray)) else text.encode()
+        pos = 0
+        while pos < len(b):
+            buf, cap = C.c_void_p(), C.c_uint64()
+            self._ck(self.lib.cdbg_stage_acquire(self._h, C.byref(buf), C.byref(cap)))
+            end = min(len(b), pos + cap.value - 1)
+            if end < len(b):
+                cut = b.rfind(b"\n", pos, end)
+                if cut <= pos:
+                    self.lib.cdbg_stage_commit(self._h, buf, 0)
+                    raise ValueError("a sequence longer than a staging buffer: split it with a k-1 overlap")
+                end = cut + 1
+            C.memmove(buf, bytes(b[pos:end]), end - pos)
+            self._ck(self.lib.cdbg_stage_commit(self._h, buf, end - pos))
+            pos = end
 
     def expect_input(self, nbytes):
         self._ck(self.lib.cdbg_expect_input(self._h, nbytes))
@@ -247,9 +277,46 @@ class Graph:
         other's only link (maximality).  mergeable_ends is None on a rank that holds a share of the unitigs."""
         out = (C.c_uint64 * 8)()
         self._ck(self.lib.cdbg_verify(self._h, out))
+        return self._verify_dict(out, self.verify_edges())
+
+    @staticmethod
+    def _verify_dict(out, edges):
         none = 0xFFFFFFFFFFFFFFFF
         return {"unitig_kmers": (out[0], out[1], out[2]), "solid_kmers": (out[3], out[4], out[5]),
-                "mergeable_ends": None if out[6] == none else out[6], "closed_chains": None if out[7] == none else out[7]}
+                "mergeable_ends": None if out[6] == none else out[6], "closed_chains": None if out[7] == none else out[7],
+                "edges": edges}
+
+    def verify_edges(self):
+        """edge conservation (cdbg_verify_edges): {graph: D, links: L, inner: 2 sum(LN - k), junctions}; a unitig set whose every
+        inner junction is 1-in / 1-out has graph == links + inner.  None on a multi-rank job."""
+        out = (C.c_uint64 * 4)()
+        self._ck(self.lib.cdbg_verify_edges(self._h, out))
+        if out[0] == 0xFFFFFFFFFFFFFFFF:
+            return None
+        return {"graph": out[0], "links": out[1], "inner": out[2], "junctions": out[3]}
+
+    def verify_unitigs(self, seqs):
+        """the checks of verify() for a unitig set supplied by the caller (sequences as str / bytes) against the resident solid k-mers"""
+        bs = [x if isinstance(x, bytes) else x.encode() for x in seqs]
+        off = (C.c_uint64 * (len(bs) + 1))()
+        acc = 0
+        for i, b in enumerate(bs):
+            off[i] = acc
+            acc += len(b)
+        off[len(bs)] = acc
+        out = (C.c_uint64 * 12)()
+        self._ck(self.lib.cdbg_verify_unitigs(self._h, b"".join(bs), off, len(bs), out))
+        return self._verify_dict(out, {"graph": out[8], "links": out[9], "inner": out[10], "junctions": out[11]})
+
+    @staticmethod
+    def edges_conserved(v):
+        e = v["edges"]
+        return e is None or e["graph"] == e["links"] + e["inner"]
+
+    def release_cached(self):
+        """hand the process-wide pool of device buffers back to the driver (cdbg_release_cached): call after close() when torch,
+        RCCL or another library of the same process needs the HBM"""
+        self.lib.cdbg_release_cached()
 
     def solid_kmers(self):
         n = C.c_uint64()

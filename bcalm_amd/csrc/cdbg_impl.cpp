@@ -67,6 +67,7 @@ int cdbg_create(const cdbg_params* p, cdbg_ctx** out) {
     HIPCK(hipSetDevice(p->device_id));
     cdbg_ctx* c = new cdbg_ctx();
     c->prm = *p; c->prm.world_size = ws;
+    c->knobs.snapshot();
     // words per k-mer: the reference's span rule k < 32 W (README.md:91-99, Integer::apply at src/bcalm_1.cpp:95); the top word of a
     // multi-word key therefore always keeps its two top bits free for the slot-claim protocol (k_count.h), for even k as well
     c->k = p->k; c->W = p->k / 32 + 1;
@@ -87,6 +88,8 @@ void cdbg_destroy(cdbg_ctx* c) {
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
+int cdbg_abi_version(void) { return CDBG_ABI_VERSION; }
+uint64_t cdbg_stats_sizeof(void) { return sizeof(cdbg_stats_t); }
 int cdbg_release_cached(void) {
     int cur = 0; (void)hipGetDevice(&cur);
     for (int d = 0; d < 64; ++d) {
@@ -101,6 +104,7 @@ int cdbg_push_reads(cdbg_ctx* c, const char* bases, const uint64_t* offsets, uin
     if (!c || !bases || !offsets) return fail(CDBG_E_PARAM, "null argument");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 0 || c->reads_final) return fail(CDBG_E_STATE, "reads must be pushed before the first stage");
+    std::lock_guard<std::mutex> lk(c->ingest_mu);
     for (uint64_t i = 0; i < n_reads; ++i) {
         if (offsets[i + 1] < offsets[i]) return fail(CDBG_E_PARAM, "offsets not monotone at read %llu", (unsigned long long)i);
         CK(ingest_append(c, bases + offsets[i], offsets[i + 1] - offsets[i]));
@@ -112,9 +116,24 @@ int cdbg_push_text(cdbg_ctx* c, const char* text, uint64_t nbytes) {
     if (!c || (!text && nbytes)) return fail(CDBG_E_PARAM, "null argument");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 0 || c->reads_final) return fail(CDBG_E_STATE, "reads must be pushed before the first stage");
+    std::lock_guard<std::mutex> lk(c->ingest_mu);
     CK(ingest_append(c, text, nbytes));
     CK(ingest_append(c, "\n", 1));
     return CDBG_OK;
+}
+int cdbg_stage_acquire(cdbg_ctx* c, char** buf, uint64_t* capacity) {
+    if (!c || !buf || !capacity) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);                 // (any host thread: one parser thread per slice of the input)
+    if (c->stage != 0 || c->reads_final) return fail(CDBG_E_STATE, "reads must be pushed before the first stage");
+    std::lock_guard<std::mutex> lk(c->ingest_mu);
+    return stage_acquire(c, buf, capacity);
+}
+int cdbg_stage_commit(cdbg_ctx* c, char* buf, uint64_t nbytes) {
+    if (!c || !buf) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);
+    if (c->stage != 0 || c->reads_final) return fail(CDBG_E_STATE, "reads must be pushed before the first stage");
+    std::lock_guard<std::mutex> lk(c->ingest_mu);
+    return stage_commit(c, buf, nbytes);
 }
 int cdbg_expect_input(cdbg_ctx* c, uint64_t text_bytes) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
@@ -322,7 +341,7 @@ int cdbg_fetch_unitig_abundances(cdbg_ctx* c, uint64_t first, uint64_t n, uint32
 int cdbg_set_transport(cdbg_ctx* c, const cdbg_transport* t) {
     if (!c || !t || !t->all_gather_u64 || !t->all_to_all_v || !t->all_gather_v || !t->all_reduce_max_i32) return fail(CDBG_E_PARAM, "null transport");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
-    c->tr = *t; c->have_tr = true; c->tr_ordered = false; c->force_multi = getenv("CDBG_FORCE_MULTI") != nullptr; return CDBG_OK;
+    c->tr = *t; c->have_tr = true; c->tr_ordered = false; c->force_multi = c->knobs.get("CDBG_FORCE_MULTI") != nullptr; return CDBG_OK;
 }
 int cdbg_comm_unique_id(void* out) {
     if (!out) return fail(CDBG_E_PARAM, "null argument");
@@ -345,7 +364,7 @@ int cdbg_comm_init_rccl(cdbg_ctx* c, const void* uid) {
     if (c->rccl) { c->rccl->destroy(); delete c->rccl; c->rccl = nullptr; }
     c->rccl = new RcclComm();
     if (!c->rccl->init(uid, c->prm.world_size, c->prm.rank, c->stream)) { const std::string e = c->rccl->err; c->rccl->destroy(); delete c->rccl; c->rccl = nullptr; return fail(CDBG_E_NODEVICE, "RCCL: %s", e.c_str()); }
-    c->tr = c->rccl->transport(); c->have_tr = true; c->tr_ordered = true; c->force_multi = getenv("CDBG_FORCE_MULTI") != nullptr;
+    c->tr = c->rccl->transport(); c->have_tr = true; c->tr_ordered = true; c->force_multi = c->knobs.get("CDBG_FORCE_MULTI") != nullptr;
     return CDBG_OK;
 #endif
 }
@@ -367,6 +386,16 @@ int cdbg_verify(cdbg_ctx* c, uint64_t out[8]) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
     (void)hipSetDevice(c->prm.device_id);
     DISPATCH_WA(verify_impl, c, out)
+}
+int cdbg_verify_edges(cdbg_ctx* c, uint64_t out[4]) {
+    if (!c || !out) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);
+    DISPATCH_WA(verify_edges_impl, c, out)
+}
+int cdbg_verify_unitigs(cdbg_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_unitigs, uint64_t out[12]) {
+    if (!c || !out || !offsets || (!bases && n_unitigs)) return fail(CDBG_E_PARAM, "null argument");
+    (void)hipSetDevice(c->prm.device_id);
+    DISPATCH_WA(verify_unitigs_impl, c, bases, offsets, n_unitigs, out)
 }
 int cdbg_stats(cdbg_ctx* c, cdbg_stats_t* out) {
     if (!c || !out) return fail(CDBG_E_PARAM, "null argument");

@@ -20,10 +20,10 @@ int compact_impl(cdbg_ctx* c) {
     // sequential log that a scatter pass re-reads; contexts that exchange the log with other ranks, and the global-table
     // join (CDBG_GLUE_TABLE), keep the log.  Observed 1.8-2.0 records per solid traveller (bound: 3): buckets sized for
     // a mean fill of at most 96 of JB_CAP = 256 at 2.2, 131 at the bound.
-    bool direct = !(c->prm.world_size > 1 || c->force_multi) && getenv("CDBG_GLUE_TABLE") == nullptr && getenv("CDBG_GLUE_LOG") == nullptr;
+    bool direct = !(c->prm.world_size > 1 || c->force_multi) && c->knobs.get("CDBG_GLUE_TABLE") == nullptr && c->knobs.get("CDBG_GLUE_LOG") == nullptr;
     int log_jb = 0;
     { const uint64_t est = c->st.n_solid_travellers * 22 / 10 + 1024; while ((96ull << log_jb) < est && log_jb < 26) ++log_jb; }
-    if (const char* ev = getenv("CDBG_JOIN_LOG_JB")) log_jb = std::max(0, std::min(26, atoi(ev)));   // (tests: force the overflow fallback)
+    if (const char* ev = c->knobs.get("CDBG_JOIN_LOG_JB")) log_jb = std::max(0, std::min(26, atoi(ev)));   // (tests: force the overflow fallback)
     for (int attempt = 0; attempt < 2; ++attempt) {
         // glue log: <= 2 open ends + 1 confirm per junction, one junction per solid traveller at most; the tail of a
         // chunk that the next bucket does not fit into is abandoned, hence the generous second attempt
@@ -112,7 +112,7 @@ int compact_impl(cdbg_ctx* c) {
         c->st.n_launch_compact = NPL;
         hm.mark("compact: buffers + LDS tiers");
         CompactParams kh = kp; uint64_t n_src = NPL;         // what the HBM tier below reads: the buckets themselves, or their sub-buckets
-        if (nbig && getenv("CDBG_NO_SPLIT") == nullptr) {
+        if (nbig && c->knobs.get("CDBG_NO_SPLIT") == nullptr) {
             // Second-level split (k_split.h): what no LDS tier could take is re-bucketed by junction into sub-buckets of ~100 entries,
             // which go through the same tiers again (the hostile config-3 line spent 76 ms walking 17 K such buckets through HBM tables)
             CK(c->split_cur.alloc(4, true));

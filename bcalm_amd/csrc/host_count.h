@@ -8,7 +8,7 @@ namespace {
 // minimum (windows of 17 .. 111 keys); the LDS-doubling scan of k_scan.h otherwise
 inline bool scan_is_fast(const cdbg_ctx* c) {
     const int wn = c->k - c->m;
-    if (getenv("CDBG_GENERIC_SCAN")) return false;          // (test knob: the generic kernel for every shape)
+    if (c->knobs.get("CDBG_GENERIC_SCAN")) return false;          // (test knob: the generic kernel for every shape)
     return (c->k <= 63 && wn <= SCANF_WNMAX) || (c->k <= 127 && wn > SCANF_WNMAX && wn >= 17);
 }
 #ifndef CDBG_SCAN_GEN
@@ -45,10 +45,10 @@ void scan_params_base(cdbg_ctx* c, ScanParams& sp) {
     sp.tile_stride = 1; sp.tile_offset = 0; sp.error = c->derr.p;
 }
 // capacity of a partition region from a sampled histogram (single-pass capped layout)
-void capped_capacities(double mean, uint64_t NPL, uint32_t& part_cap, uint64_t& spill_cap) {
+void capped_capacities(const cdbg_ctx* c, double mean, uint64_t NPL, uint32_t& part_cap, uint64_t& spill_cap) {
     part_cap = (uint32_t)(mean * 2.5 + 8.0 * std::sqrt(mean + 1.0) + 16.0);
     part_cap = (part_cap + 7u) & ~7u;
-    if (const char* e = getenv("CDBG_PART_CAP")) part_cap = (uint32_t)std::max(1, atoi(e));   // test knob: force spills
+    if (const char* e = c->knobs.get("CDBG_PART_CAP")) part_cap = (uint32_t)std::max(1, atoi(e));   // test knob: force spills
     spill_cap = std::max<uint64_t>((uint64_t)(mean * (double)NPL / 32.0), 65536);
 }
 
@@ -64,7 +64,7 @@ int stream_scan_advance(cdbg_ctx* c) {
     const uint64_t landed = c->n_dev & ~15ull;
     if (!c->ss_on) {
         // (test knobs: CDBG_STREAM_MIN_BYTES / CDBG_STREAM_BATCH_TILES shrink the thresholds to simulator sizes)
-        const char* emin = getenv("CDBG_STREAM_MIN_BYTES");
+        const char* emin = c->knobs.get("CDBG_STREAM_MIN_BYTES");
         const uint64_t min_bytes = emin ? strtoull(emin, nullptr, 10) : (128ull << 20);
         if (landed < std::min<uint64_t>(c->expect_bytes / 2, min_bytes)) return CDBG_OK;
         configure(c, c->expect_bytes);
@@ -85,7 +85,7 @@ int stream_scan_advance(cdbg_ctx* c) {
         CK(exscan_u32(c, c->part_count.p, c->part_off.p, NPL));
         uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPL, &sample_records));
         const double mean = (double)sample_records * (double)tiles_exp / (double)ns / (double)NPL;
-        capped_capacities(mean, NPL, c->ss_part_cap, c->ss_spill_cap);
+        capped_capacities(c, mean, NPL, c->ss_part_cap, c->ss_spill_cap);
         if ((double)c->ss_part_cap * (double)NPL * RW * 8.0 > 200e9) { c->expect_bytes = 0; return CDBG_OK; }   // would not fit: no streaming
         CK(c->records.alloc((uint64_t)c->ss_part_cap * NPL * RW, false));
         CK(c->spill_recs.alloc(c->ss_spill_cap * RW, false)); CK(c->spill_part.alloc(c->ss_spill_cap, false));
@@ -95,7 +95,7 @@ int stream_scan_advance(cdbg_ctx* c) {
     }
     const uint64_t TB = scan_tile_bytes(c);
     const uint64_t tiles_now = landed > TB + 8192 ? (landed - 8192) / TB : 0;      // tiles whose halo has landed as well
-    const char* ebt = getenv("CDBG_STREAM_BATCH_TILES");
+    const char* ebt = c->knobs.get("CDBG_STREAM_BATCH_TILES");
     if (tiles_now < c->ss_done + (ebt ? strtoull(ebt, nullptr, 10) : 32768ull)) return CDBG_OK;   // batches of >= 128 MB
     // the kernel must see the bytes: order the compute stream behind the copies enqueued so far
     hipEvent_t ev; HIPCK(hipEventCreate(&ev));
@@ -180,12 +180,12 @@ int count_impl(cdbg_ctx* c) {
     // (sharded reads: the exact layout is what travels -- no slack on the wire; a single-pass scan into capped regions is
     //  squeezed into it by k_pack_regions, which costs one pass over the rank's records instead of a second pass over its reads)
     bool capped = tiles > 8192;
-    if (const char* e = getenv("CDBG_SCAN_MODE")) { if (!strcmp(e, "exact")) capped = false; else if (!strcmp(e, "capped")) capped = true; }
+    if (const char* e = c->knobs.get("CDBG_SCAN_MODE")) { if (!strcmp(e, "exact")) capped = false; else if (!strcmp(e, "capped")) capped = true; }
     if (tiles == 0) capped = false;                          // (a rank without reads: nothing to sample)
     // var: ONE pass into regions of their own size per partition, estimated from a denser sample -- what a skewed input gets instead
     // of the exact two-pass layout (CDBG_SCAN_MODE=var: test knob)
     bool var = false;
-    if (const char* e = getenv("CDBG_SCAN_MODE")) { if (!strcmp(e, "var") && tiles && !multi) { var = true; capped = false; } }
+    if (const char* e = c->knobs.get("CDBG_SCAN_MODE")) { if (!strcmp(e, "var") && tiles && !multi) { var = true; capped = false; } }
     uint64_t n_records = 0, hs[2] = {0, 0};
     uint32_t part_cap = 0; uint64_t n_spill = 0; bool packed_exact = false;
     uint64_t n_spilled_parts = 0;                            // partitions whose region overflowed (capped mode): counted from gathered copies
@@ -211,11 +211,11 @@ int count_impl(cdbg_ctx* c) {
             uint64_t sample_max = 0; CK(read_u64(c->dstats.p + 31, &sample_max));
             CK(t.stop(&c->st.ms_scan_hist));
             const double mean = (double)sample_records * (double)tiles / (double)ns / (double)NPS;
-            capped_capacities(mean, NPS, part_cap, spill_cap);
+            capped_capacities(c, mean, NPS, part_cap, spill_cap);
             if ((double)part_cap * (double)NPS * RW * 8.0 > 200e9) fits = false;       // would not fit: use the exact layout
             // (at least 32 sampled records in that partition: with a mean of a few records per partition -- long reads, k = 127 --
             //  the sampled maximum is Poisson noise, and scaling it up sent the config-5 share through two passes: 598 -> 662 ms)
-            else if (sample_max >= 32 && (double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && getenv("CDBG_SCAN_MODE") == nullptr) { fits = false; var = !multi; }
+            else if (sample_max >= 32 && (double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && c->knobs.get("CDBG_SCAN_MODE") == nullptr) { fits = false; var = !multi; }
             if (fits) {
                 if (c->xrecs.cap > c->records.cap) c->records.swap(c->xrecs);   // (sharded reads: the previous step left the region buffer there)
                 CK(c->records.alloc((uint64_t)part_cap * NPS * RW, false));
@@ -287,9 +287,9 @@ int count_impl(cdbg_ctx* c) {
         uint64_t sample_records = 0;
         CK(exscan(c->part_count.p)); CK(read_u64(c->part_off.p + NPS, &sample_records));
         const double scale = (double)tiles / (double)ns, mean = (double)sample_records * scale / (double)NPS;
-        uint32_t cap_min = 0; capped_capacities(mean, NPS, cap_min, spill_cap);
+        uint32_t cap_min = 0; capped_capacities(c, mean, NPS, cap_min, spill_cap);
         VarParams vp{ c->part_count.p, c->var_cap.p, NPS, (float)scale, cap_min, c->part_off.p, c->part_cursor.p, c->var_pairs.p, c->dstats.p + 30 };
-        if (const char* e = getenv("CDBG_VAR_SCALE")) vp.scale = (float)atof(e);   // test knob (with CDBG_PART_CAP): regions far too small, so that partitions spill
+        if (const char* e = c->knobs.get("CDBG_VAR_SCALE")) vp.scale = (float)atof(e);   // test knob (with CDBG_PART_CAP): regions far too small, so that partitions spill
         CDBG_LAUNCH(k_var_caps, (NPS + 255) / 256, 256, s, vp);
         CK(exscan_u32(c, c->var_cap.p, c->part_off.p, NPS));
         uint64_t total_cap = 0; CK(read_u64(c->part_off.p + NPS, &total_cap));
@@ -448,8 +448,8 @@ int count_impl(cdbg_ctx* c) {
     {
         // (admission by predicted fill: k_count_fast.h; one-word k-mers: off -- their second tier runs one workgroup per CU against three)
         CountFastParams fp{ cp, c->retry_list.p, c->big_count.p + 1, count_fast_record_limit<W>(c->k), W == 1 ? 0u : W == 2 ? 177u : 200u };
-        if (const char* e = getenv("CDBG_FAST_SKIP_Q8")) fp.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
-        if (const char* e = getenv("CDBG_FAST_MAX_RECORDS")) fp.fast_max_records = std::min<uint32_t>(count_fast_record_limit<W>(c->k), (uint32_t)std::max(1, atoi(e)));   // dev knob
+        if (const char* e = c->knobs.get("CDBG_FAST_SKIP_Q8")) fp.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
+        if (const char* e = c->knobs.get("CDBG_FAST_MAX_RECORDS")) fp.fast_max_records = std::min<uint32_t>(count_fast_record_limit<W>(c->k), (uint32_t)std::max(1, atoi(e)));   // dev knob
         if (capped) CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, true>), std::min<uint64_t>(NPL, COUNT_GRID), Cfg<W>::NTC, s, fp);
         else CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(NPL, COUNT_GRID), Cfg<W>::NTC, s, fp);
     }
@@ -463,13 +463,13 @@ int count_impl(cdbg_ctx* c) {
     // exact counts only for what was seen again; two workgroups per CU instead of one, and partitions of up to 6000 distinct k-mers
     // fit: config-5 share 67 (4096-slot tier) + 52 (multi-pass) -> 82 + 17 ms.  Two-word k-mers keep the 4096-slot tier (k = 55: more
     // than half of the occurrences are of k-mers seen again, and reading them twice costs more than the small table saves: 141 -> 149 ms)
-    const bool sift = W >= 3 && c->prm.abundance_min >= 2 && getenv("CDBG_NO_SIFT") == nullptr;
-    if constexpr (W >= 3) if (nretry && sift && getenv("CDBG_NO_COUNT_TIER2") == nullptr) {
+    const bool sift = W >= 3 && c->prm.abundance_min >= 2 && c->knobs.get("CDBG_NO_SIFT") == nullptr;
+    if constexpr (W >= 3) if (nretry && sift && c->knobs.get("CDBG_NO_COUNT_TIER2") == nullptr) {
         CK(c->retry_list2.alloc(nretry, false));
         HIPCK(hipMemsetAsync(c->big_count.p + 2, 0, sizeof(uint32_t), s));
         CountParams c2 = cp; c2.part_list = c->retry_list.p; c2.n_items = nretry;
         CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2, count_fast_record_limit<W>(c->k), 192u };   // (admission: predicted distinct k-mers beyond 3/4 of the fingerprint words -> multi-pass kernel untried)
-        if (const char* e = getenv("CDBG_FAST_SKIP2_Q8")) fp2.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
+        if (const char* e = c->knobs.get("CDBG_FAST_SKIP2_Q8")) fp2.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
         constexpr int TSS = 512, FSS = 8192, NTS = 512;       // (exact table: a quarter of tier 1's slots)
         const uint64_t grid = std::min<uint64_t>(nretry, SIFT_GRID);    // (two workgroups per CU are resident; the rest take turns: COUNT_GRID, host_ctx.h)
         if (capped) CDBG_LAUNCH((k_count_fast<W, TSS, NTS, 3, FSS>), grid, NTS, s, fp2);
@@ -478,7 +478,7 @@ int count_impl(cdbg_ctx* c) {
         CK(read_u32(c->big_count.p + 2, &nretry));
         retry_ptr = c->retry_list2.p;
     }
-    if constexpr (W <= 4) if (nretry && !sift && getenv("CDBG_NO_COUNT_TIER2") == nullptr) {   // (wider keys: a table twice the size does not fit the LDS)
+    if constexpr (W <= 4) if (nretry && !sift && c->knobs.get("CDBG_NO_COUNT_TIER2") == nullptr) {   // (wider keys: a table twice the size does not fit the LDS)
         // second tier: the same one-pass kernel with a table twice the size (one workgroup per CU) over the retry list; at the
         // config-5 share 6 % of the partitions -- a minimizer locus of long reads -- cost 250 of 590 ms in the multi-pass kernel
         CK(c->retry_list2.alloc(nretry, false));
@@ -487,7 +487,7 @@ int count_impl(cdbg_ctx* c) {
         // (three- and four-word k-mers: the admission rule here as well -- a partition predicted beyond 0.68 of the 4096 slots goes to
         //  the multi-pass kernel untried: count 216 -> 201 ms at the config-5 share; two-word k-mers: no difference, off)
         CountFastParams fp2{ c2, c->retry_list2.p, c->big_count.p + 2, count_fast_record_limit<W>(c->k), W >= 3 ? 175u : 0u };
-        if (const char* e = getenv("CDBG_FAST_SKIP2_Q8")) fp2.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
+        if (const char* e = c->knobs.get("CDBG_FAST_SKIP2_Q8")) fp2.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
         // (multi-word k-mers: 1024 threads -- the table fills the CU's LDS either way, so the workgroup size IS the occupancy: 16
         //  waves per CU instead of 8, second tier 81 -> 67 ms at the config-5 share, 24 -> 18 at the config-4 share)
 #ifndef CDBG_NT_TIER2
@@ -512,7 +512,7 @@ int count_impl(cdbg_ctx* c) {
         CountParams rp2 = cp;
         rp2.records = c->repair_recs.p; rp2.item_off = c->repair_off.p; rp2.part_list = c->repair_part.p; rp2.part_stride = 0;
         rp2.n_items = (uint32_t)n_spilled_parts; rp2.max_passes = 4096;
-        if (const char* ev = getenv("CDBG_REPAIR_MAX_PASSES")) rp2.max_passes = (uint32_t)std::max(1, atoi(ev));   // (tests: a spilled partition that is deferred as well)
+        if (const char* ev = c->knobs.get("CDBG_REPAIR_MAX_PASSES")) rp2.max_passes = (uint32_t)std::max(1, atoi(ev));   // (tests: a spilled partition that is deferred as well)
         constexpr int TSG = W == 1 ? TS : 2 * TS, NTG = W == 1 ? Cfg<W>::NTC : 1024;
         CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(rp2.n_items, W == 1 ? MP_GRID_1 : MP_GRID_W), NTG, s, rp2);
     }
@@ -566,7 +566,7 @@ int count_impl(cdbg_ctx* c) {
 #endif
     c->st.n_distinct = cs[0]; c->st.n_occurrences = cs[1]; c->st.n_solid = cs[2]; c->st.n_solid_travellers = cs[3];
     CK(read_u64(c->solid_cursor.p, &c->n_solid_entries));
-    if (getenv("CDBG_DEBUG_SEGHIST")) {                      // dev aid: solid entries per bucket, log2 bins (stderr)
+    if (c->knobs.get("CDBG_DEBUG_SEGHIST")) {                      // dev aid: solid entries per bucket, log2 bins (stderr)
         std::vector<uint32_t> sn(NPL); CK(read_u32(c->seg_n.p, sn.data(), NPL));
         uint64_t nb[32] = {0}, ne[32] = {0};
         for (uint64_t p = 0; p < NPL; ++p) { int b = 0; while ((1u << b) <= sn[p] && b < 31) ++b; ++nb[b]; ne[b] += sn[p]; }

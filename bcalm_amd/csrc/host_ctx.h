@@ -27,12 +27,24 @@ int fail(int code, const char* fmt, ...) {
 // (profiles/r03_scan_variance_by_allocation.log).  Buffers of 1 MB and more therefore go back to a per-device POOL of the process
 // instead of the driver, and an allocation takes the smallest pooled block that is large enough (and not more than twice as large):
 // a second context of the same shape runs on the very pages of the first.  cdbg_release_cached() empties the pool; a pooled
-// volume beyond DevPool::LIMIT is freed at once.
+// volume beyond DevPool::limit() -- a fraction of the card -- is freed at once.
 struct DevPool {
-    static constexpr size_t MIN_BYTES = 1u << 20, LIMIT = 160ull << 30;
+    static constexpr size_t MIN_BYTES = 1u << 20;
     struct Block { void* p; size_t bytes; };
-    std::mutex mu; std::vector<Block> blocks[64]; size_t held[64] = {};
+    std::mutex mu; std::vector<Block> blocks[64]; size_t held[64] = {}; size_t limit_[64] = {};
     static int device() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0; return d; }
+    // what the pool may keep on device d: 55 % of the card (160 GB of an MI355X's 288: one config-3 context), nothing with
+    // CDBG_NO_POOL set -- torch tensors, RCCL buffers and pinned staging of the same process cannot drain the pool, so it must
+    // leave them room whatever the card's size.  Read once per device (callers hold mu).
+    size_t limit(int d) {
+        if (!limit_[d]) {
+            size_t fr = 0, tot = 0;
+            if (getenv("CDBG_NO_POOL")) limit_[d] = 1;
+            else if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) limit_[d] = std::max<size_t>(tot / 100 * 55, 1);
+            else limit_[d] = 1;
+        }
+        return limit_[d];
+    }
     void* take(size_t want, size_t* got) {
         const int d = device();
         std::lock_guard<std::mutex> g(mu);
@@ -49,7 +61,7 @@ struct DevPool {
         (void)hipDeviceSynchronize();                    // (what hipFree did: the block may be handed to a context that works on another stream)
         {
             std::lock_guard<std::mutex> g(mu);
-            if (bytes >= MIN_BYTES && held[d] + bytes <= LIMIT) { blocks[d].push_back({ p, bytes }); held[d] += bytes; return; }
+            if (bytes >= MIN_BYTES && held[d] + bytes <= limit(d)) { blocks[d].push_back({ p, bytes }); held[d] += bytes; return; }
         }
         (void)hipFree(p);
     }
@@ -189,8 +201,20 @@ int glue_table_slots(uint64_t want, uint32_t* out) {
 
 }  // namespace
 
+// The environment knobs (test switches that force the rare paths, dev switches of the A/B scripts) are read ONCE, when the
+// context is created: no getenv on the per-step host path, and a job cannot change behaviour half way.
+struct Knobs {
+    std::vector<std::pair<std::string, std::string>> kv;
+    void snapshot() {
+        static const char* const NAMES[] = { "CDBG_DEBUG_SEGHIST", "CDBG_FAST_MAX_RECORDS", "CDBG_FAST_SKIP2_Q8", "CDBG_FAST_SKIP_Q8", "CDBG_FORCE_MULTI", "CDBG_GENERIC_SCAN", "CDBG_GLUE_LOG", "CDBG_GLUE_RANK", "CDBG_GLUE_REPLICATED", "CDBG_GLUE_TABLE", "CDBG_JOIN_LOG_JB", "CDBG_NO_COUNT_TIER2", "CDBG_NO_SIFT", "CDBG_NO_SPLIT", "CDBG_PART_CAP", "CDBG_REPAIR_MAX_PASSES", "CDBG_SCAN_MODE", "CDBG_STAGE_BYTES", "CDBG_STREAM_BATCH_TILES", "CDBG_STREAM_MIN_BYTES", "CDBG_VAR_SCALE", "CDBG_WALK_MAX" };
+        for (const char* n : NAMES) if (const char* e = getenv(n)) kv.emplace_back(n, e);
+    }
+    const char* get(const char* name) const { for (const auto& p : kv) if (p.first == name) return p.second.c_str(); return nullptr; }
+};
+
 struct cdbg_ctx {
     cdbg_params prm{};
+    Knobs knobs;
     int W = 1, k = 0, m = 0, log_np = 0, rank_bits = 0;
     uint64_t n_local_parts = 1;
     hipStream_t stream{};
@@ -203,6 +227,12 @@ struct cdbg_ctx {
     uint64_t stage_bytes = STAGE_BYTES;          // (CDBG_STAGE_BYTES: smaller staging chunks, tests of the streaming scan)
     uint8_t* pin[2] = { nullptr, nullptr }; hipEvent_t pin_ev[2] = {}; bool pin_busy[2] = { false, false };
     int pin_cur = 0; uint64_t pin_fill = 0; hipStream_t copy_stream{};
+    // Zero-copy ingest for multi-threaded parsers (cdbg_stage_acquire / cdbg_stage_commit): pinned buffers handed out to the caller's
+    // threads, filled in place, committed in any order -- every commit appends to the device text; one mutex orders the appends
+    // (and every other push).  state: 0 free, 1 held by a caller, 2 copy in flight
+    struct Stage { uint8_t* p = nullptr; hipEvent_t ev{}; int state = 0; };
+    static constexpr int MAX_STAGES = 64;
+    std::mutex ingest_mu; std::vector<Stage> stages;
     uint64_t n_dev = 0;                          // bytes of text already on (or on their way to) the device
     bool reads_final = false;                    // text complete, padded, nbytes set
     // streaming scan (cdbg_expect_input): tiles already scanned while the input was still arriving
@@ -267,7 +297,7 @@ int stream_scan_dispatch(cdbg_ctx* c);
 // ---- streaming ingest ----
 int ingest_init(cdbg_ctx* c) {
     if (c->pin[0]) return CDBG_OK;
-    if (const char* e = getenv("CDBG_STAGE_BYTES")) c->stage_bytes = std::min<uint64_t>(cdbg_ctx::STAGE_BYTES, std::max<uint64_t>(64, strtoull(e, nullptr, 10)));
+    if (const char* e = c->knobs.get("CDBG_STAGE_BYTES")) c->stage_bytes = std::min<uint64_t>(cdbg_ctx::STAGE_BYTES, std::max<uint64_t>(64, strtoull(e, nullptr, 10)));
     HIPCK(hipStreamCreate(&c->copy_stream));
     for (int i = 0; i < 2; ++i) {
         if (hipHostMalloc((void**)&c->pin[i], cdbg_ctx::STAGE_BYTES) != hipSuccess) return fail(CDBG_E_NOMEM, "pinned staging buffer (%llu bytes)", (unsigned long long)cdbg_ctx::STAGE_BYTES);
@@ -279,6 +309,8 @@ void ingest_release(cdbg_ctx* c) {
     for (int i = 0; i < 2; ++i) {
         if (c->pin[i]) { (void)hipHostFree(c->pin[i]); (void)hipEventDestroy(c->pin_ev[i]); c->pin[i] = nullptr; }
     }
+    for (auto& sg : c->stages) if (sg.p) { (void)hipHostFree(sg.p); (void)hipEventDestroy(sg.ev); }
+    c->stages.clear();
     if (c->copy_stream) { (void)hipStreamDestroy(c->copy_stream); c->copy_stream = hipStream_t{}; }
 }
 // device text with room for `need` bytes: grows by doubling (device-to-device copy of what is already there)
@@ -319,10 +351,52 @@ int ingest_append(cdbg_ctx* c, const char* src, uint64_t n) {
     }
     return CDBG_OK;
 }
+// ---- zero-copy staging (include/cdbg.h cdbg_stage_acquire / cdbg_stage_commit); callers hold c->ingest_mu ----
+int stage_acquire(cdbg_ctx* c, char** buf, uint64_t* cap) {
+    CK(ingest_init(c));
+    for (;;) {
+        int oldest = -1;
+        for (int i = 0; i < (int)c->stages.size(); ++i) {
+            cdbg_ctx::Stage& sg = c->stages[i];
+            if (sg.state == 2 && hipEventQuery(sg.ev) == hipSuccess) sg.state = 0;       // its copy has landed
+            if (sg.state == 0) { sg.state = 1; *buf = (char*)sg.p; *cap = c->stage_bytes; return CDBG_OK; }
+            if (sg.state == 2 && oldest < 0) oldest = i;
+        }
+        if ((int)c->stages.size() < cdbg_ctx::MAX_STAGES) {                                 // every buffer is with a caller or on its way: one more
+            cdbg_ctx::Stage sg;
+            if (hipHostMalloc((void**)&sg.p, cdbg_ctx::STAGE_BYTES) != hipSuccess) return fail(CDBG_E_NOMEM, "pinned staging buffer (%llu bytes)", (unsigned long long)cdbg_ctx::STAGE_BYTES);
+            HIPCK(hipEventCreate(&sg.ev));
+            sg.state = 1; c->stages.push_back(sg);
+            *buf = (char*)sg.p; *cap = c->stage_bytes; return CDBG_OK;
+        }
+        if (oldest < 0) return fail(CDBG_E_STATE, "cdbg_stage_acquire: all %d staging buffers are held by the caller", cdbg_ctx::MAX_STAGES);
+        HIPCK(hipEventSynchronize(c->stages[oldest].ev));
+    }
+}
+int ingest_flush(cdbg_ctx* c);
+int stage_commit(cdbg_ctx* c, char* buf, uint64_t n) {
+    cdbg_ctx::Stage* sg = nullptr;
+    for (auto& x : c->stages) if ((char*)x.p == buf) sg = &x;
+    if (!sg || sg->state != 1) return fail(CDBG_E_PARAM, "cdbg_stage_commit: not a buffer handed out by cdbg_stage_acquire");
+    if (n > c->stage_bytes) return fail(CDBG_E_PARAM, "cdbg_stage_commit: %llu bytes in a buffer of %llu", (unsigned long long)n, (unsigned long long)c->stage_bytes);
+    if (n && base_valid((uint8_t)buf[n - 1])) {                                             // every commit ends a sequence: what follows it in the text is another thread's
+        if (n == c->stage_bytes) return fail(CDBG_E_PARAM, "cdbg_stage_commit: a full buffer must end with a separator");
+        buf[n++] = '\n';
+    }
+    if (!n) { sg->state = 0; return CDBG_OK; }
+    CK(ingest_flush(c));                                                                    // (bytes of an earlier cdbg_push_text come first)
+    CK(ingest_reserve(c, c->n_dev + n));
+    HIPCK(hipMemcpyAsync(c->reads.p + c->n_dev, buf, n, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCK(hipEventRecord(sg->ev, c->copy_stream));
+    sg->state = 2;
+    c->n_dev += n;
+    if (c->expect_bytes && c->prm.world_size == 1 && !c->force_multi) CK(stream_scan_dispatch(c));
+    return CDBG_OK;
+}
 // text complete: last partial buffer out, all copies done, tail padded with separators
 int upload_pending(cdbg_ctx* c) {
     if (c->reads_final) return CDBG_OK;
-    if (!c->pin[0] || (c->n_dev == 0 && c->pin_fill == 0)) {                   // nothing was pushed
+    if (c->n_dev == 0 && c->pin_fill == 0) {                                   // nothing was pushed
         // a rank of a multi-GPU job may receive no reads at all (a small input dealt out in chunks): it still takes part
         // in every collective, with an empty text of separators
         if (c->prm.world_size > 1 || c->force_multi) {
@@ -360,7 +434,8 @@ int check_device_error(cdbg_ctx* c, const char* where) {
 // dev aid (CDBG_HOST_MARKS=1): wall-clock marks on stderr between the host-side phases of a stage, to find time that no
 // stage timer covers (allocations, host sorts, synchronous copies)
 struct HostMarks {
-    bool on = getenv("CDBG_HOST_MARKS") != nullptr; double t0 = now();
+    bool on = enabled(); double t0 = now();
+    static bool enabled() { static const bool e = getenv("CDBG_HOST_MARKS") != nullptr; return e; }   // (read once per process)
     static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
     void mark(const char* what) { if (!on) return; (void)hipDeviceSynchronize(); const double t = now(); fprintf(stderr, "[host] %-28s %8.2f ms\n", what, t - t0); t0 = t; }
 };

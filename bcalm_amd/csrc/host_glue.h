@@ -22,7 +22,7 @@ int glue_join_impl(cdbg_ctx* c, bool sharded) {
     HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
     const uint32_t world = sharded ? (uint32_t)c->prm.world_size : 1u;
     const uint64_t n_mine = c->n_glog / world + (world > 1 ? (c->n_glog >> 6) + 1024 : 0);      // records this rank joins (estimate when sharded)
-    bool bucketed = (getenv("CDBG_GLUE_TABLE") == nullptr || c->direct_join) && c->n_glog > 0;
+    bool bucketed = (c->knobs.get("CDBG_GLUE_TABLE") == nullptr || c->direct_join) && c->n_glog > 0;
     if (bucketed && c->direct_join) {                        // the buckets were filled by the compaction kernels
         const uint64_t JB = 1ull << c->join_log_jb;
         JoinBucketParams bp{ c->jfill.p, c->jrecs.p, (uint32_t)JB, c->link.p, c->dstats.p, nullptr, nullptr, 0, nullptr };
@@ -91,7 +91,7 @@ int glue_walk(cdbg_ctx* c, bool* done) {
     HIPCK(hipMemsetAsync(c->derr.p, 0, 4 * sizeof(uint32_t), s));
     HIPCK(hipMemsetAsync(c->rank_flag.p, 0, sizeof(uint32_t), s));
     uint32_t max_steps = 4096;
-    if (const char* e = getenv("CDBG_WALK_MAX")) max_steps = (uint32_t)strtoul(e, nullptr, 10);
+    if (const char* e = c->knobs.get("CDBG_WALK_MAX")) max_steps = (uint32_t)strtoul(e, nullptr, 10);
     // dstats: [4] live pieces, [5] pieces the kept walks visited, [6] head states (stays on the device: the launches cover the upper bound)
     uint64_t* const n_heads = c->dstats.p + 6;
     WalkInitParams ip{ (uint32_t)NP, c->piece_n.p, c->piece_kc.p, c->piece_boff.p, c->link.p, c->walk_rec.p, c->walk_heads.p, n_heads, c->dstats.p + 4 };
@@ -122,7 +122,7 @@ int glue_impl(cdbg_ctx* c) {
         // multi-GPU.  Every rank emits its own unitigs (emit_replicated = 0): the sharded glue of k_dglue.h -- every record and
         // every piece travels once.  emit_replicated = 1 (the CLI's rank 0 writes one file and needs the whole graph for the
         // links), or closed chains across ranks: the replicated exchange -- pieces + junction log of all ranks to every rank.
-        if (!c->prm.emit_replicated && getenv("CDBG_GLUE_REPLICATED") == nullptr) {
+        if (!c->prm.emit_replicated && c->knobs.get("CDBG_GLUE_REPLICATED") == nullptr) {
             const int rc = glue_sharded<W>(c);
             if (rc != DG_FALLBACK) return rc;
         }
@@ -137,7 +137,7 @@ int glue_impl(cdbg_ctx* c) {
     Timer t; CK(t.start(s));
     // one GPU: walk the chains from their heads; chains the walk does not take (too long, closed) -> list ranking below, for the rest of this context's life
     bool walked = false;
-    if (c->prm.world_size <= 1 && !c->force_multi && !c->xchg_done && !c->walk_off && getenv("CDBG_GLUE_RANK") == nullptr) CK(glue_walk(c, &walked));
+    if (c->prm.world_size <= 1 && !c->force_multi && !c->xchg_done && !c->walk_off && c->knobs.get("CDBG_GLUE_RANK") == nullptr) CK(glue_walk(c, &walked));
     if (walked) {
         { uint64_t cur[2]; CK(read_u64(c->cursors.p + 2, cur, 2)); c->n_unitigs = cur[0]; c->unitig_total = cur[1]; }
         CK(pack_unitigs(c));
@@ -246,11 +246,14 @@ int glue_impl(cdbg_ctx* c) {
     return CDBG_OK;
 }
 
+// a unitig set in device memory: the resident result, or one the caller supplied (cdbg_verify_unitigs)
+struct UnitigView { uint64_t U; const uint64_t* off; const uint32_t* len; const uint8_t* bases; uint64_t total_bases; };
+
+// the link table of a unitig set (k_links.h): link_off[2U + 1], link_to[n_links]
 template <int W>
-int link_impl(cdbg_ctx* c) {
-    if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_link before cdbg_glue");
+int links_build(cdbg_ctx* c, const UnitigView& v, DBuf<uint64_t>& link_off, DBuf<uint32_t>& link_to, uint64_t& n_links) {
     hipStream_t s = c->stream;
-    const uint64_t U = c->n_unitigs, NE = 2 * U;
+    const uint64_t U = v.U, NE = 2 * U;
     // (k_links.h packs a slot index with a flag in bit 30: the table may have at most 2^30 slots)
     if (pow2_at_least(4 * U + 64) > (1ull << 30)) return fail(CDBG_E_INTERNAL, "too many unitigs (%llu) for the 30-bit slots of the link table", (unsigned long long)U);
     const uint32_t cap = (uint32_t)pow2_at_least(4 * U + 64);
@@ -258,49 +261,115 @@ int link_impl(cdbg_ctx* c) {
     CK(lk_keys.alloc((uint64_t)cap * W, false)); CK(lk_cnt.alloc((uint64_t)cap * 2, true));
     CK(lk_ends.alloc((uint64_t)cap * 2 * LINK_PER_FLAG, false)); CK(end_slot.alloc(NE, false)); CK(deg.alloc(NE, false));
     HIPCK(hipMemsetAsync(lk_keys.p, 0xFF, (uint64_t)cap * W * sizeof(uint64_t), s));
-    CK(c->link_off.alloc(NE + 1, true));
+    CK(link_off.alloc(NE + 1, true));
     LinkParams lp{};
-    lp.n_unitigs = U; lp.k = c->k; lp.unitig_off = c->unitig_off.p; lp.unitig_len = c->unitig_len.p; lp.bases = c->unitig_bases.p;
+    lp.n_unitigs = U; lp.k = c->k; lp.unitig_off = v.off; lp.unitig_len = v.len; lp.bases = v.bases;
     lp.lk_keys = lk_keys.p; lp.lk_cnt = lk_cnt.p; lp.lk_ends = lk_ends.p; lp.lk_mask = cap - 1;
     lp.end_slot = end_slot.p; lp.deg = deg.p;
-    c->n_links = 0;
+    n_links = 0;
     if (NE) {
         const uint64_t grid = (NE + LINK_THREADS - 1) / LINK_THREADS;
         CDBG_LAUNCH((k_link_insert<W>), grid, LINK_THREADS, s, lp);
         CDBG_LAUNCH(k_link_count, grid, LINK_THREADS, s, lp);
         const uint64_t nb = (NE + EXSCAN_BLOCK - 1) / EXSCAN_BLOCK;
         CK(c->exscan_tmp.alloc(nb + 1, false));
-        const uint32_t* degp = deg.p;                        // (plain pointer: launch arguments are captured by value)
+        const uint32_t* degp = deg.p;                        // (plain pointers: launch arguments are captured by value)
+        uint64_t* const loff = link_off.p;
         CDBG_LAUNCH(k_exscan_sums, nb, EXSCAN_THREADS, s, degp, c->exscan_tmp.p, NE);
-        CDBG_LAUNCH(k_exscan_top, 1, EXSCAN_THREADS, s, c->exscan_tmp.p, nb, c->link_off.p + NE);
-        CDBG_LAUNCH(k_exscan_apply, nb, EXSCAN_THREADS, s, degp, (const uint64_t*)c->exscan_tmp.p, c->link_off.p, NE);
-        CK(read_u64(c->link_off.p + NE, &c->n_links));
-        CK(c->link_to.alloc(c->n_links, false));
-        lp.link_off = c->link_off.p; lp.link_to = c->link_to.p;
+        CDBG_LAUNCH(k_exscan_top, 1, EXSCAN_THREADS, s, c->exscan_tmp.p, nb, loff + NE);
+        CDBG_LAUNCH(k_exscan_apply, nb, EXSCAN_THREADS, s, degp, (const uint64_t*)c->exscan_tmp.p, loff, NE);
+        CK(read_u64(loff + NE, &n_links));
+        CK(link_to.alloc(n_links, false));
+        lp.link_off = link_off.p; lp.link_to = link_to.p;
         CDBG_LAUNCH(k_link_fill, grid, LINK_THREADS, s, lp);
         HIPCK(hipStreamSynchronize(s));
     }
+    return CDBG_OK;
+}
+UnitigView resident_unitigs(cdbg_ctx* c) { return UnitigView{ c->n_unitigs, c->unitig_off.p, c->unitig_len.p, c->unitig_bases.p, c->unitig_total }; }
+
+template <int W>
+int link_impl(cdbg_ctx* c) {
+    if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_link before cdbg_glue");
+    CK(links_build<W>(c, resident_unitigs(c), c->link_off, c->link_to, c->n_links));
     c->linked = true;
     return CDBG_OK;
 }
+
+// k-mer-set equality + maximality of a unitig set against the solid table (k_verify.h); out[8]
+template <int W>
+int verify_view(cdbg_ctx* c, const UnitigView& v, const uint64_t* link_off, const uint32_t* link_to, bool with_links, uint64_t* out) {
+    hipStream_t s = c->stream;
+    DBuf<uint64_t> d; CK(d.alloc(8, true));
+    VerifyParams vp{ v.U, c->k, v.off, v.len, v.bases,
+                     c->seg_off.p, c->seg_n.p, c->solid_keys.p, c->solid_cnt.p, c->n_local_parts, link_off, link_to, d.p };
+    if (v.U) CDBG_LAUNCH((k_verify_unitig_kmers<W>), std::min<uint64_t>((v.U + 255) / 256, 1u << 16), 256, s, vp);
+    CDBG_LAUNCH((k_verify_solid<W>), std::min<uint64_t>((c->n_local_parts + 255) / 256, 1u << 16), 256, s, vp);
+    if (with_links && v.U) CDBG_LAUNCH(k_verify_maximal, (2 * v.U + 255) / 256, 256, s, vp);
+    HIPCK(hipStreamSynchronize(s));
+    CK(read_u64(d.p, out, 8));
+    if (!with_links) out[6] = out[7] = ~0ull;
+    return CDBG_OK;
+}
+// edge conservation (k_verify.h): out[0] = D from the solid k-mers, out[1] = links of the unitig set, out[2] = 2 sum(LN - k), out[3] = distinct junctions
+template <int W>
+int verify_edges_view(cdbg_ctx* c, const UnitigView& v, uint64_t n_links, uint64_t* out) {
+    hipStream_t s = c->stream;
+    const uint64_t n_home = c->st.n_solid;
+    const uint64_t cap = pow2_at_least(3 * n_home + 1024);   // (at most 2 junctions per k-mer: never more than two thirds full)
+    if (cap > (1ull << 32)) return fail(CDBG_E_INTERNAL, "too many solid k-mers (%llu) for the 32-bit slots of the junction table", (unsigned long long)n_home);
+    DBuf<uint64_t> jt_keys, d; DBuf<uint32_t> jt_cnt;
+    CK(jt_keys.alloc(cap * W, false)); CK(jt_cnt.alloc(cap, false)); CK(d.alloc(4, true));
+    HIPCK(hipMemsetAsync(jt_keys.p, 0xFF, cap * W * sizeof(uint64_t), s));
+    HIPCK(hipMemsetAsync(jt_cnt.p, 0, cap * sizeof(uint32_t), s));
+    VerifyEdgeParams ep{ c->k, c->seg_off.p, c->seg_n.p, c->solid_keys.p, c->solid_cnt.p, c->n_local_parts, jt_keys.p, jt_cnt.p, (uint32_t)(cap - 1), d.p };
+    CDBG_LAUNCH((k_verify_edge_insert<W>), std::min<uint64_t>((c->n_local_parts + 255) / 256, 1u << 16), 256, s, ep);
+    CDBG_LAUNCH(k_verify_edge_sum, std::min<uint64_t>((cap + 255) / 256, 1u << 16), 256, s, ep);
+    HIPCK(hipStreamSynchronize(s));
+    uint64_t r[4]; CK(read_u64(d.p, r, 4));
+    if (r[2]) return fail(CDBG_E_INTERNAL, "junction table overflow in cdbg_verify_edges (%llu ends lost)", (unsigned long long)r[2]);
+    out[0] = r[0]; out[1] = n_links; out[2] = 2 * (v.total_bases - v.U * (uint64_t)c->k); out[3] = r[1];
+    return CDBG_OK;
+}
+inline bool holds_a_share(const cdbg_ctx* c) { return (c->prm.world_size > 1 || c->force_multi) && !c->prm.emit_replicated; }   // this rank holds a share of the unitigs: no links
 
 // the unitig definition checked on the resident result (k_verify.h)
 template <int W>
 int verify_impl(cdbg_ctx* c, uint64_t* out) {
     if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_verify before cdbg_glue");
-    hipStream_t s = c->stream;
-    const bool sharded_set = (c->prm.world_size > 1 || c->force_multi) && !c->prm.emit_replicated;   // this rank holds a share of the unitigs: no links
+    const bool sharded_set = holds_a_share(c);
     if (!sharded_set && !c->linked) CK(link_impl<W>(c));
-    DBuf<uint64_t> d; CK(d.alloc(8, true));
-    VerifyParams vp{ c->n_unitigs, c->k, c->unitig_off.p, c->unitig_len.p, c->unitig_bases.p,
-                     c->seg_off.p, c->seg_n.p, c->solid_keys.p, c->solid_cnt.p, c->n_local_parts, c->link_off.p, c->link_to.p, d.p };
-    if (c->n_unitigs) CDBG_LAUNCH((k_verify_unitig_kmers<W>), std::min<uint64_t>((c->n_unitigs + 255) / 256, 1u << 16), 256, s, vp);
-    CDBG_LAUNCH((k_verify_solid<W>), std::min<uint64_t>((c->n_local_parts + 255) / 256, 1u << 16), 256, s, vp);
-    if (!sharded_set && c->n_unitigs) CDBG_LAUNCH(k_verify_maximal, (2 * c->n_unitigs + 255) / 256, 256, s, vp);
-    HIPCK(hipStreamSynchronize(s));
-    CK(read_u64(d.p, out, 8));
-    if (sharded_set) out[6] = out[7] = ~0ull;
-    return CDBG_OK;
+    return verify_view<W>(c, resident_unitigs(c), c->link_off.p, c->link_to.p, !sharded_set, out);
+}
+template <int W>
+int verify_edges_impl(cdbg_ctx* c, uint64_t* out) {
+    if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_verify_edges before cdbg_glue");
+    if (c->prm.world_size > 1 || c->force_multi) { out[0] = out[1] = out[2] = out[3] = ~0ull; return CDBG_OK; }   // (a rank counts a share of the k-mers; their junctions belong to all ranks)
+    if (!c->linked) CK(link_impl<W>(c));
+    return verify_edges_view<W>(c, resident_unitigs(c), c->n_links, out);
+}
+// the same checks for a unitig set the CALLER supplies (host memory): out[0..7] as cdbg_verify, out[8..11] as cdbg_verify_edges
+template <int W>
+int verify_unitigs_impl(cdbg_ctx* c, const char* bases, const uint64_t* off, uint64_t n, uint64_t* out) {
+    if (c->stage < 1) return fail(CDBG_E_STATE, "cdbg_verify_unitigs before cdbg_count");
+    if (c->prm.world_size > 1 || c->force_multi) return fail(CDBG_E_STATE, "cdbg_verify_unitigs needs the whole solid set on this rank");
+    const uint64_t total = n ? off[n] : 0;
+    std::vector<uint32_t> len(std::max<uint64_t>(n, 1));
+    for (uint64_t i = 0; i < n; ++i) {
+        if (off[i + 1] < off[i] || off[i + 1] - off[i] < (uint64_t)c->k || off[i + 1] - off[i] > 0xFFFFFFFFull) return fail(CDBG_E_PARAM, "unitig %llu: bad length", (unsigned long long)i);
+        len[i] = (uint32_t)(off[i + 1] - off[i]);
+    }
+    for (uint64_t i = 0; i < total; ++i) if (!base_valid((uint8_t)bases[i])) return fail(CDBG_E_PARAM, "unitig base %llu is not one of ACGT", (unsigned long long)i);
+    DBuf<uint64_t> d_off, l_off; DBuf<uint32_t> d_len, l_to; DBuf<uint8_t> d_bases;
+    CK(d_off.alloc(n + 1, false)); CK(d_len.alloc(n, false)); CK(d_bases.alloc(total + 64, false));
+    HIPCK(hipMemcpy(d_off.p, off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIPCK(hipMemcpy(d_len.p, len.data(), std::max<uint64_t>(n, 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (total) HIPCK(hipMemcpy(d_bases.p, bases, total, hipMemcpyHostToDevice));
+    const UnitigView v{ n, d_off.p, d_len.p, d_bases.p, total };
+    uint64_t nl = 0;
+    CK(links_build<W>(c, v, l_off, l_to, nl));
+    CK(verify_view<W>(c, v, l_off.p, l_to.p, true, out));
+    return verify_edges_view<W>(c, v, nl, out + 8);
 }
 
 }  // namespace

@@ -74,12 +74,13 @@ def pmc_traffic(kernel_key, cfg):
 
 
 def W_OF(k):
-    return 1 if k <= 31 else 2 if k <= 63 else 3 if k <= 95 else 4
+    """64-bit words per k-mer: the reference's span rule k < 32 W (README.md:91-99), W = 1 .. 8 (k <= 255)"""
+    return k // 32 + 1
 
 
 def alg_bytes(k, st, n_reads, read_len):
     """SURVEY.md section 8(d) stage-interface bytes, with measured counts."""
-    W = 1 if k <= 31 else 2 if k <= 63 else 3 if k <= 95 else 4
+    W = W_OF(k)
     Kb = 8 * W
     sbar = (k - 10 + 2) / 2.0
     n_occ, S, P, U = st["n_occurrences"], st["n_solid"], st["n_pieces"], st["n_unitigs"]
@@ -412,8 +413,14 @@ def main():
     checks["k-mers spelled by the unitigs == solid set (count, 2 x 64-bit commutative sums)"] = vu == vs and vu[0] == tot["n_solid"]
     if vr["mergeable_ends"] is not None:
         checks["no two unitig ends are each other's only link (every unitig maximal)"] = vr["mergeable_ends"] == 0
+    # edge conservation (cdbg_verify_edges; bidirected-graphs-in-bcalm2.md:85): the edges of the solid k-mer graph, counted from the
+    # count stage's keys in one global (k-1)-mer table, are exactly the inner adjacencies of the unitigs plus the links between
+    # their ends -- a unitig that runs THROUGH a branching junction (over-compaction) leaves a strictly positive shortfall
+    ve = vr["edges"]
+    if ve is not None:
+        checks["edges of the solid graph == links + 2 x inner adjacencies (every inner junction 1-in / 1-out)"] = ve["graph"] == ve["links"] + ve["inner"]
     verify_info = {"unitig_kmers": [vu[0], "%016x" % vu[1], "%016x" % vu[2]], "solid_kmers": [vs[0], "%016x" % vs[1], "%016x" % vs[2]],
-                   "mergeable_ends": vr["mergeable_ends"], "closed_chains_cut": vr["closed_chains"]}
+                   "mergeable_ends": vr["mergeable_ends"], "closed_chains_cut": vr["closed_chains"], "edges": ve}
 
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)

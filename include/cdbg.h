@@ -75,6 +75,13 @@ typedef struct cdbg_stats_t {
                                         closed chain); 0: the list-ranking path of k_glue.h glued this run */
 } cdbg_stats_t;
 
+/* ABI version: bumped whenever a struct of this header changes.  From version 5 on cdbg_stats_t only ever GROWS AT ITS END;
+ * a binding checks cdbg_abi_version() against the header it was written for and sizeof(cdbg_stats_t) against
+ * cdbg_stats_sizeof() when it loads the library (bcalm_amd/api.py does), instead of reading fields at stale offsets. */
+#define CDBG_ABI_VERSION 5
+int cdbg_abi_version(void);
+uint64_t cdbg_stats_sizeof(void);
+
 /* error codes */
 #define CDBG_OK 0
 #define CDBG_E_PARAM (-1)     /* bad parameter (k out of range, ...) */
@@ -87,8 +94,9 @@ int  cdbg_create(const cdbg_params* params, cdbg_ctx** out);
 void cdbg_destroy(cdbg_ctx* ctx);
 /* cdbg_destroy hands the context's device buffers of 1 MB and more (the super-k-mer record region: 75 GB at config 3) to a per-device
  * pool of the process, and the next context of the same shape runs on the very same pages: the read scan is sensitive to the physical
- * placement of its region and counters, and every free + re-allocation made it slower.  At most 160 GB are
- * held per device; cdbg_release_cached returns everything to the driver. */
+ * placement of its region and counters, and every free + re-allocation made it slower.  At most 55 % of the
+ * card's memory is held per device (nothing with CDBG_NO_POOL set in the environment); cdbg_release_cached returns everything to the
+ * driver -- call it before another library of the same process (torch, RCCL) needs the HBM. */
 int cdbg_release_cached(void);
 const char* cdbg_last_error(void);
 
@@ -98,6 +106,16 @@ const char* cdbg_last_error(void);
  * /root/reference/scripts/unitigEvaluator.cpp:130-131). */
 int cdbg_push_reads(cdbg_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_reads);
 int cdbg_push_text(cdbg_ctx* ctx, const char* text, uint64_t nbytes);
+/* Zero-copy input for multi-threaded parsers (the `bcalm` CLI: N threads on record-aligned slices of a memory-mapped FASTA /
+ * FASTQ, one inflate thread per .gz of a file list; README.md:45-50).  cdbg_stage_acquire hands out one of the context's
+ * PINNED staging buffers; the caller writes sequence text into it (sequences separated by any byte outside ACGTacgt) and
+ * cdbg_stage_commit appends the first `nbytes` of it to the device text with an asynchronous copy (a '\n' is added when the
+ * text does not end with a separator: a commit always ends a sequence -- a sequence longer than a buffer is continued in
+ * the next one by repeating its last k-1 bases).  nbytes = 0 hands the buffer back unused.  Both calls are thread-safe
+ * and may be mixed with the push calls; commits append in the order in which they arrive (the result does not depend on
+ * it).  With cdbg_expect_input the scan of the complete tiles is launched from the commits as from the pushes. */
+int cdbg_stage_acquire(cdbg_ctx* ctx, char** buf, uint64_t* capacity);
+int cdbg_stage_commit(cdbg_ctx* ctx, char* buf, uint64_t nbytes);
 /* Optional, before the first push: the (approximate) number of text bytes that will be pushed, e.g. from the file size.
  * The device text is then allocated once, and the read scan starts on the part of the input that has already landed
  * while the caller is still parsing and pushing the rest (single GPU; README.md:45-50 inputs through the CLI). */
@@ -199,6 +217,21 @@ int cdbg_digest(cdbg_ctx* ctx, uint64_t out[4]);
  * Several ranks: the sums are additive over the ranks; a rank that holds a share of the unitigs (emit_replicated = 0) has
  * no link table and reports out[6] = out[7] = UINT64_MAX. */
 int cdbg_verify(cdbg_ctx* ctx, uint64_t out[8]);
+/* Edge conservation: the inner-junction half of the unitig definition (bidirected-graphs-in-bcalm2.md:85 -- "for every
+ * 0 < i < n the only edges incident on v_i are e_{i-1}, e_i and their mirrors") at any size.  cdbg_verify's maximality pass
+ * sees unitig ENDS only; a unitig that runs THROUGH a branching node passes it.  Here the edges of the solid k-mer graph are
+ * counted from the count stage's keys alone (one global table of canonical (k-1)-mers; bcalm_amd/csrc/k_verify.h):
+ *   out[0]  D = sum over the ends of all solid k-mers of the k-mer ends they see across their junction
+ *   out[1]  L = the same sum over the unitig ENDS (= number of links; builds them when they are not there yet)
+ *   out[2]  2 * sum over the unitigs of (LN - k): every inner adjacency of a unitig, seen from both sides
+ *   out[3]  distinct junctions of the solid graph
+ * out[0] == out[1] + out[2]  <=>  every inner junction of every unitig is 1-in / 1-out (the shortfall of a junction that
+ * a unitig runs through wrongly is strictly positive: nothing cancels).  Several ranks: every rank counts a share of the k-mers, their junctions belong to all: UINT64_MAX. */
+int cdbg_verify_edges(cdbg_ctx* ctx, uint64_t out[4]);
+/* The checks of cdbg_verify (out[0..7]) and cdbg_verify_edges (out[8..11]) for a unitig set SUPPLIED BY THE CALLER -- ASCII
+ * bases, offsets[n + 1] -- against the solid k-mers resident after cdbg_count: a FASTA written by any program can be judged
+ * against this library's counted k-mer set (and the tests plant an over-compacted unitig to see the edge check fail). */
+int cdbg_verify_unitigs(cdbg_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_unitigs, uint64_t out[12]);
 
 /* Edges between unitigs (the `L:<+/->:<id>:<+/->` tokens of /root/reference/README.md:62-72; GFA `L`
  * lines of scripts/convertToGFA.py:103-112).  After cdbg_glue: cdbg_link builds them on the GPU.

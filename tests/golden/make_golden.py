@@ -38,6 +38,8 @@ CASES = [
     # even k (README.md:99 "any k value"): a k-mer may equal its reverse complement (.md:30,57)
     ("tiny_read", 12, 1), ("minitip", 20, 1), ("minitip", 20, 2), ("circ_test1", 6, 1), ("circ_test2", 8, 1),
     ("circ_test3", 6, 1), ("pufferize_refs", 8, 1), ("pufferize_refs", 10, 1), ("palin4", 4, 1),
+    # the spec's own worked example (bidirected-graphs-in-bcalm2.md:64: k = 3, S = {GTATAC}; inputs/spec_gtatac.fa holds that string)
+    ("spec_gtatac", 3, 1),
 ]
 
 # SURVEY.md section 4 anchor table, transcribed by hand (seq, LN, KC); circular
@@ -56,6 +58,10 @@ ANCHORS = {
     # is its own reverse complement.  ATTG reaches AATT by the two distinct edges (ATTG,AATT,-,+) and (ATTG,AATT,-,-), so it has no
     # unique out-edge and neither node extends: two unitigs.  ACGTAC: ACGT (palindrome), CGTA, GTAC (palindrome): three unitigs
     "palin4/4/1": {"distinct": 5, "solid": 5, "unitigs": [["AATT", 4, 1], ["ATTG", 4, 2], ["ACGT", 4, 1], ["CGTA", 4, 1], ["GTAC", 4, 1]]},
+    # the spec's worked example, .md:64-68 + :78: k = 3, S = {GTATAC} -- two nodes, {GTA, TAC} and {ATA, TAT}, each seen twice, and the walk
+    # (e2, e3, e1) spells the input.  By hand: GTA overlaps TAT and TAC by its suffix TA (two outgoing edges, one of them the self-mirror
+    # GTA -> TAC) and nothing ends in GT; ATA -> TAT, ATA -> TAC, TAT -> ATA: neither node has a unique edge on either side: two unitigs
+    "spec_gtatac/3/1": {"distinct": 2, "solid": 2, "unitigs": [["GTA", 3, 2], ["ATA", 3, 2]]},
     "pufferize_refs/9/1": {"distinct": 70, "solid": 70, "unitigs_partial": [["AATTGGTCT", 9, 2], ["ATTGGTCTGGTTGGATTGTACTCATGATG", 29, 21]],
                            "n_unitigs": 3, "other": [[56, 49]]},
 }

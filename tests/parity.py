@@ -165,4 +165,56 @@ def assert_verified(g):
     v = g.verify()
     assert v["unitig_kmers"] == v["solid_kmers"], v
     assert v["mergeable_ends"] in (0, None), v
+    assert api.Graph.edges_conserved(v), v               # every inner junction of every unitig 1-in / 1-out (cdbg_verify_edges)
     return v
+
+
+_COMP = str.maketrans("ACGT", "TGCA")
+
+
+def _rc(s):
+    return s.translate(_COMP)[::-1]
+
+
+def check_edge_conservation_is_sensitive(g, k):
+    """cdbg_verify_edges / cdbg_verify_unitigs on a finished graph `g` that has at least one branching junction:
+    (1) the resident set and the same set handed back by the caller give the same numbers and conserve the edges;
+    (2) a unitig merged with a neighbour THROUGH a branching junction (over-compaction: same k-mer set, no mergeable ends
+        added) breaks the conservation and nothing else;
+    (3) a unitig cut in two (under-compaction) keeps the conservation and shows up as a mergeable pair instead.
+    -> number of planted merges that were tried"""
+    uni = [s for s, _ in g.unitigs()]
+    links = g.links()
+    v0 = g.verify()
+    assert v0["unitig_kmers"] == v0["solid_kmers"] and v0["mergeable_ends"] == 0 and api.Graph.edges_conserved(v0), v0
+    v1 = g.verify_unitigs(uni)
+    assert v1 == v0, (v1, v0)
+    planted = 0
+    for u, lk in enumerate(links):
+        for side in "+-":
+            out = [(v, ts) for fs, v, ts in lk if fs == side and v != u]
+            if len(out) < 2:
+                continue                                  # (not a branching junction on this side)
+            v, ts = out[0]
+            head = uni[u] if side == "+" else _rc(uni[u])
+            tail = uni[v] if ts == "+" else _rc(uni[v])
+            assert head[-(k - 1):] == tail[:k - 1], "a link is a (k-1)-overlap"
+            merged = head + tail[k - 1:]
+            bad = [s for i, s in enumerate(uni) if i not in (u, v)] + [merged]
+            vb = g.verify_unitigs(bad)
+            assert vb["unitig_kmers"] == vb["solid_kmers"], "the planted merge keeps the k-mer set"
+            assert not api.Graph.edges_conserved(vb), ("over-compaction not seen", vb)
+            assert vb["edges"]["graph"] > vb["edges"]["links"] + vb["edges"]["inner"], vb
+            planted += 1
+            if planted >= 3:
+                break
+        if planted >= 3:
+            break
+    long_ones = [i for i, s in enumerate(uni) if len(s) >= k + 1]
+    if long_ones:
+        i = long_ones[0]
+        cut = [s for j, s in enumerate(uni) if j != i] + [uni[i][:k], uni[i][1:]]
+        vc = g.verify_unitigs(cut)
+        assert vc["unitig_kmers"] == vc["solid_kmers"] and api.Graph.edges_conserved(vc), vc
+        assert vc["mergeable_ends"] == 2, vc
+    return planted

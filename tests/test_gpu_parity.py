@@ -417,3 +417,19 @@ def test_wide_kmers_gpu(oracle, hip, k, n_reads, read_len):
         assert st["kmer_words"] == k // 32 + 1
         assert st["n_distinct"] == exp["stats"]["distinct"] and st["n_solid"] == exp["stats"]["solid"]
         assert got == exp["unitigs"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,amin,n,L,cfg", [(31, 1, 200_000, 150, 3), (31, 2, 400_000, 150, 3 | 0x100), (32, 1, 100_000, 150, 3), (55, 1, 100_000, 150, 4), (127, 1, 20_000, 1000, 5)])
+def test_edge_conservation_sees_over_compaction_gpu(oracle, hip, k, amin, n, L, cfg):
+    """cdbg_verify_edges on the HIP result (bidirected-graphs-in-bcalm2.md:85, the inner-junction half of the unitig definition):
+    the edges of the solid graph are the links plus the inner adjacencies; a unitig merged THROUGH a branching junction -- planted
+    in the fetched result and handed back through cdbg_verify_unitigs -- breaks exactly that; a cut unitig shows as mergeable ends"""
+    from bcalm_amd import api
+    from parity import check_edge_conservation_is_sensitive
+    g = api.Graph(k, amin, lib=hip)
+    g.generate_reads(n, L, cfg)
+    g.run()
+    planted = check_edge_conservation_is_sensitive(g, k)
+    g.close()
+    assert planted >= 1

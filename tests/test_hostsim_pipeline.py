@@ -386,6 +386,20 @@ def test_verify_matches_the_kmer_set(oracle, sim, k, amin, n, L, cfg):
     assert kmer_set_sums(kmers[1:] + kmers[1:2], k)[0] == want[0] and kmer_set_sums(kmers[1:] + kmers[1:2], k) != want
 
 
+@pytest.mark.parametrize("k,amin,n,L,cfg", [(31, 1, 3000, 150, 3), (12, 1, 1500, 100, 3), (55, 1, 1500, 150, 4), (127, 1, 300, 500, 5)])
+def test_edge_conservation_sees_over_compaction(sim, oracle, k, amin, n, L, cfg):
+    """cdbg_verify_edges (.md:85, the inner-junction half of the definition): holds for the result, fails for a unitig that was
+    merged through a branching junction (which the k-mer-set and maximality checks do not see), holds for a cut unitig"""
+    from bcalm_amd import api
+    from parity import check_edge_conservation_is_sensitive
+    text = oracle.synth_reads(n, L, cfg)                 # (1 % errors at abundance-min 1: thousands of branching junctions)
+    g = api.Graph(k, amin, lib=sim, log2_partitions=5)
+    g.push_text(text); g.run()
+    planted = check_edge_conservation_is_sensitive(g, k)
+    g.close()
+    assert planted >= 1
+
+
 @pytest.mark.parametrize("key", sorted(GOLD))
 def test_verify_on_goldens(sim, key):
     """every golden input (cycles, hairpins, palindromes, even k): unitig k-mers == solid set, no mergeable pair of ends"""
