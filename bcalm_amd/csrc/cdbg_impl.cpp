@@ -22,6 +22,7 @@
 #include <ctime>
 #include <mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "k_links.h"

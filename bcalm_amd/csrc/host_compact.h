@@ -22,15 +22,20 @@ int compact_impl(cdbg_ctx* c) {
     // a mean fill of at most 96 of JB_CAP = 256 at 2.2, 131 at the bound.
     bool direct = !(c->prm.world_size > 1 || c->force_multi) && c->knobs.get("CDBG_GLUE_TABLE") == nullptr && c->knobs.get("CDBG_GLUE_LOG") == nullptr;
     int log_jb = 0;
-    { const uint64_t est = c->st.n_solid_travellers * 22 / 10 + 1024; while ((96ull << log_jb) < est && log_jb < 26) ++log_jb; }
-    if (const char* ev = c->knobs.get("CDBG_JOIN_LOG_JB")) log_jb = std::max(0, std::min(26, atoi(ev)));   // (tests: force the overflow fallback)
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    // (the second-level split of overfull buckets, k_split.h, makes travellers of its own -- a home k-mer whose two junctions land in
+    //  different sub-buckets leaves a copy, up to 3 more glue records each: what a first attempt learns about them sizes the next)
+    uint64_t split_extra = 0, split_buckets_now = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        const uint64_t trav_est = c->st.n_solid_travellers + split_extra, sized_extra = split_extra;
+        split_buckets_now = 0;
+        { log_jb = 0; const uint64_t est = trav_est * 22 / 10 + 1024; while ((96ull << log_jb) < est && log_jb < 26) ++log_jb; }
+        if (const char* ev = c->knobs.get("CDBG_JOIN_LOG_JB")) log_jb = std::max(0, std::min(26, atoi(ev)));   // (tests: force the overflow fallback)
         // glue log: <= 2 open ends + 1 confirm per junction, one junction per solid traveller at most; the tail of a
         // chunk that the next bucket does not fit into is abandoned, hence the generous second attempt
         // (every persistent wave of tier 0 may strand one partly used chunk of each output array as well)
         // (... in the wave tiers over the buckets and over the sub-buckets of the second-level split)
         const uint64_t wave_slack = 2 * std::min<uint64_t>(NPL, 256ull * 32) + 2 * std::min<uint64_t>(c->n_solid_entries / 32 + 4, 256ull * 32);
-        c->glog_cap = (attempt == 0 ? 3 : 8) * c->st.n_solid_travellers + (attempt + 1) * (CHUNK_SLACK_WGS * (uint64_t)GLOG_CHUNK + wave_slack * CW_GLOG_CHUNK) + 64;
+        c->glog_cap = (attempt == 0 ? 3 : 8) * trav_est + (attempt + 1) * (CHUNK_SLACK_WGS * (uint64_t)GLOG_CHUNK + wave_slack * CW_GLOG_CHUNK) + 64;
         if (direct) {
             c->glog_cap = ~0ull >> 2;                        // (the log cursor only counts)
             CK(c->jfill.alloc(1ull << log_jb, false)); CK(c->jrecs.alloc((JB_CAP << log_jb) * (uint64_t)(W + 1), false));
@@ -127,7 +132,7 @@ int compact_impl(cdbg_ctx* c) {
             CDBG_LAUNCH((k_split_buckets<W>), std::min<uint64_t>(nbig, PERSISTENT_GRID), SPLIT_THREADS, s, sp);
             kh = kp; kh.solid_keys = c->split_keys.p; kh.solid_cnt = c->split_cnt.p; kh.seg_off = c->vseg_off.p; kh.seg_n = c->vseg_n.p; kh.split = 1u;
             n_src = need[1];
-            c->st.n_split_buckets += nbig;
+            split_buckets_now = nbig; split_extra = std::max(split_extra, need[0]);
             CK(lds_tiers(kh, (uint32_t)need[1], c->vlist_a, c->vlist_b, nbig, left));
             hm.mark("compact: split + LDS tiers");
         }
@@ -156,11 +161,13 @@ int compact_impl(cdbg_ctx* c) {
             HIPCK(hipStreamSynchronize(s));
         }
         uint32_t e = 0; CK(read_u32(c->derr.p, &e));
+        if (e == 8 && direct && split_extra > sized_extra && attempt < 2) continue;   // join buckets sized without the split's records: once more, with them
         if (e == 8 && direct) { direct = false; --attempt; continue; }   // a join bucket overflowed (cannot happen with a sound hash): through the log instead
-        if ((e == 3 || e == 5) && attempt == 0) continue;    // piece arrays / glue log too small: retry with the safe bounds
+        if ((e == 3 || e == 5) && attempt < 2) continue;     // piece arrays / glue log too small: retry with the safe bounds (and what the split added)
         if (nbig) c->st.n_big_partitions += nbig;
         break;
     }
+    c->st.n_split_buckets += split_buckets_now;              // (of the attempt that is kept)
     CK(t.stop(&c->st.ms_compact));
     hm.mark("compact: workgroup tiers");
     CK(check_device_error(c, "compact"));

@@ -179,6 +179,13 @@ int count_impl(cdbg_ctx* c) {
     //                            partitions are repaired (gathered contiguously) before counting.
     // (sharded reads: the exact layout is what travels -- no slack on the wire; a single-pass scan into capped regions is
     //  squeezed into it by k_pack_regions, which costs one pass over the rank's records instead of a second pass over its reads)
+    // bytes a record region may take: what the card has free, plus what this context's region of the step before and the process's
+    // pool would hand back, less a reserve for the stages that follow (the card's size is asked, not assumed)
+    auto region_budget = [&]() -> double {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || !tot) return 200e9;
+        return (double)fr + (double)c->records.cap * 8.0 + (double)dev_pool().held[DevPool::device()] - 0.15 * (double)tot;
+    };
     bool capped = tiles > 8192;
     if (const char* e = c->knobs.get("CDBG_SCAN_MODE")) { if (!strcmp(e, "exact")) capped = false; else if (!strcmp(e, "capped")) capped = true; }
     if (tiles == 0) capped = false;                          // (a rank without reads: nothing to sample)
@@ -212,7 +219,7 @@ int count_impl(cdbg_ctx* c) {
             CK(t.stop(&c->st.ms_scan_hist));
             const double mean = (double)sample_records * (double)tiles / (double)ns / (double)NPS;
             capped_capacities(c, mean, NPS, part_cap, spill_cap);
-            if ((double)part_cap * (double)NPS * RW * 8.0 > 200e9) fits = false;       // would not fit: use the exact layout
+            if ((double)part_cap * (double)NPS * RW * 8.0 > region_budget()) fits = false;   // would not fit: use the exact layout
             // (at least 32 sampled records in that partition: with a mean of a few records per partition -- long reads, k = 127 --
             //  the sampled maximum is Poisson noise, and scaling it up sent the config-5 share through two passes: 598 -> 662 ms)
             else if (sample_max >= 32 && (double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && c->knobs.get("CDBG_SCAN_MODE") == nullptr) { fits = false; var = !multi; }
@@ -294,10 +301,14 @@ int count_impl(cdbg_ctx* c) {
         CK(exscan_u32(c, c->var_cap.p, c->part_off.p, NPS));
         uint64_t total_cap = 0; CK(read_u64(c->part_off.p + NPS, &total_cap));
         float ms2 = 0; CK(t.stop(&ms2)); c->st.ms_scan_hist = ms_sample1 + ms2;
-        if ((double)total_cap * RW * 8.0 > 200e9) var = false;                     // would not fit: the exact layout
-        else {
+        // does the region fit?  What the card has free, plus what this context (the region of the step before) and the process's
+        // pool would hand back, less a reserve for the stages that follow; an allocation that fails all the same falls back to
+        // the exact layout as well (no hard-coded card size)
+        if ((double)total_cap * RW * 8.0 > region_budget()) var = false;           // would not fit: the exact layout
+        else if (c->records.alloc(total_cap * RW, false) != CDBG_OK) var = false;
+        if (var) {
+            c->ss_on = false;                                // (as on the capped path: a re-count scans everything)
             spill_cap = std::max<uint64_t>(total_cap / 32, 65536);
-            CK(c->records.alloc(total_cap * RW, false));
             CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
             HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
             HIPCK(hipMemsetAsync(c->cursors.p + 6, 0, sizeof(uint64_t), s));
@@ -525,7 +536,7 @@ int count_impl(cdbg_ctx* c) {
         std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list.p, bl.data(), nbig));
         std::sort(bl.begin(), bl.end());
         std::vector<uint64_t> offs(nbig + 1, 0);
-        const uint64_t nmax = (uint64_t)RecFmt<W>::CAPB - c->k + 1;
+        const uint64_t nmax = std::min<uint64_t>((uint64_t)RecFmt<W>::CAPB - c->k + 1, 255);   // (members per record: the scan clamps at the 8-bit field)
         // (records of every listed partition: one bulk copy of the fill / offset array when the list is long -- a skewed input
         //  lists 10^4 partitions, and a synchronous 4-byte copy each cost 77 ms per step at the hostile config-3 line)
         std::vector<uint32_t> h_fill; std::vector<uint64_t> h_off;

@@ -97,21 +97,29 @@ int dg_cut_cycles(cdbg_ctx* c, const DRankParams& dp, uint64_t* n_cycles) {
     const int world = c->prm.world_size, me = c->prm.rank; hipStream_t s = c->stream;
     const uint32_t NSl = dp.n_local;
     DBuf<uint2> mine, all; DBuf<uint64_t> cur; DBuf<uint32_t> cut;
-    CK(cur.alloc(1, true));
-    CK(mine.alloc(std::min<uint64_t>(NSl, DG_CYCLE_MAX) + 1, false));
-    DrOpenParams op{ NSl, dp.base, dp.st, dp.link, mine.p, cur.p, std::min<uint64_t>(NSl, DG_CYCLE_MAX) };
-    if (NSl) CDBG_LAUNCH(k_dr_collect_open, (NSl + 255) / 256, 256, s, op);
-    uint64_t n_mine = 0; CK(read_u64(cur.p, &n_mine));
+    // (a rank-local failure -- an allocation, a state that is not where it should be -- must not leave the other ranks waiting in the
+    //  next collective: every local status goes through agree() before the ranks move on)
+    uint64_t n_mine = 0;
+    auto collect = [&]() -> int {
+        CK(cur.alloc(1, true));
+        CK(mine.alloc(std::min<uint64_t>(NSl, DG_CYCLE_MAX) + 1, false));
+        DrOpenParams op{ NSl, dp.base, dp.st, dp.link, mine.p, cur.p, std::min<uint64_t>(NSl, DG_CYCLE_MAX) };
+        if (NSl) CDBG_LAUNCH(k_dr_collect_open, (NSl + 255) / 256, 256, s, op);
+        return read_u64(cur.p, &n_mine);
+    };
+    CK(agree(c, collect(), "sharded glue: closed chains (collect)"));
     std::vector<uint64_t> cnt(world);
     if (c->tr.all_gather_u64(c->tr.user, &n_mine, cnt.data(), 1) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
     uint64_t total = 0; std::vector<uint64_t> roff(world), rcnt(world);
     for (int r = 0; r < world; ++r) { roff[r] = total * sizeof(uint2); rcnt[r] = cnt[r] * sizeof(uint2); total += cnt[r]; }
     if (total > DG_CYCLE_MAX) return DG_FALLBACK;        // (every rank sees the same total)
-    CK(all.alloc(total + 1, false));
+    CK(agree(c, all.alloc(total + 1, false), "sharded glue: closed chains (gather buffer)"));
     if (!c->tr_ordered) HIPCK(hipStreamSynchronize(s));
     if (c->tr.all_gather_v(c->tr.user, mine.p, n_mine * sizeof(uint2), all.p, roff.data(), rcnt.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_v failed");
     for (int r = 0; r < world; ++r) if (r != me) c->comm_bytes += n_mine * sizeof(uint2) + rcnt[r];
     std::vector<uint2> h(total);
+    std::vector<uint32_t> cuts; uint64_t ncyc = 0;
+    auto analyse = [&]() -> int {
     HIPCK(hipMemcpy(h.data(), all.p, total * sizeof(uint2), hipMemcpyDeviceToHost));
     // state -> successor; every state of a closed chain is in the list (both directions of every piece of it)
     std::sort(h.begin(), h.end(), [](const uint2& a, const uint2& b) { return a.x < b.x; });
@@ -122,7 +130,7 @@ int dg_cut_cycles(cdbg_ctx* c, const DRankParams& dp, uint64_t* n_cycles) {
         nx = h[lo].y; return true;
     };
     std::vector<uint8_t> seen(h.size(), 0);
-    std::vector<uint32_t> cuts; uint64_t ncyc = 0;
+    std::unordered_set<uint32_t> cut_pieces;             // (the two directions of a cycle elect the same piece: cut once)
     for (size_t i = 0; i < h.size(); ++i) {
         if (seen[i]) continue;
         uint32_t e = h[i].x, pmin = e >> 1; size_t steps = 0;
@@ -138,10 +146,11 @@ int dg_cut_cycles(cdbg_ctx* c, const DRankParams& dp, uint64_t* n_cycles) {
         // the two directions of a piece cycle elect the same piece; the one that passes its left end as an EXIT names the junction
         uint32_t partner = 0;
         if (!next_of(2u * pmin + 1u, partner)) return fail(CDBG_E_INTERNAL, "sharded glue: closed chain without its reverse direction");
-        bool dup = false;
-        for (size_t j = 0; j + 1 < cuts.size(); j += 2) if (cuts[j] == 2u * pmin) { dup = true; break; }
-        if (!dup) { cuts.push_back(2u * pmin); cuts.push_back(partner); ++ncyc; }
+        if (cut_pieces.insert(pmin).second) { cuts.push_back(2u * pmin); cuts.push_back(partner); ++ncyc; }
     }
+    return CDBG_OK;
+    };
+    CK(agree(c, analyse(), "sharded glue: closed chains (analysis)"));
     if (!cuts.empty()) {
         CK(cut.alloc(cuts.size(), false));
         HIPCK(hipMemcpy(cut.p, cuts.data(), cuts.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -241,7 +250,8 @@ int glue_sharded(cdbg_ctx* c) {
         uint64_t total_states = 2ull * own.b[world];
         int max_rounds = 4; while ((1ull << (max_rounds - 3)) < total_states) ++max_rounds;
         bool done = false;
-        uint64_t prev_open = ~0ull; int cuts_made = 0;
+        uint64_t prev_open = ~0ull; int cuts_made = 0; uint64_t cycles_cut = 0;
+        const int rounds_per_ranking = max_rounds;
         for (int round = 0; round < max_rounds; ++round) {
             if (NSl) CDBG_LAUNCH(k_dr_jump, gridS, 256, s, dp);
             CK(dg_route(c, NSl, R));
@@ -253,9 +263,10 @@ int glue_sharded(cdbg_ctx* c) {
                 const int rc = dg_cut_cycles(c, dp, &ncyc);
                 if (rc == DG_FALLBACK) break;
                 CK(rc);
-                c->st.n_cycles += ncyc; ++cuts_made;
+                cycles_cut += ncyc; ++cuts_made;
                 if (NSl) CDBG_LAUNCH(k_dr_init, gridS, 256, s, dp);
                 prev_open = ~0ull;
+                max_rounds = round + 1 + rounds_per_ranking;                // (the ranking starts over: a full budget of rounds again)
                 continue;
             }
             prev_open = R.n_all;
@@ -271,6 +282,7 @@ int glue_sharded(cdbg_ctx* c) {
             if (R.n_send) CDBG_LAUNCH(k_dr_apply, grid(R.n_send), 256, s, dp);
         }
         if (!done) { float ms = 0; CK(t.stop(&ms)); c->st.ms_exchange += ms; c->st.n_glue_rounds = 0; return DG_FALLBACK; }   // closed chains across ranks
+        c->st.n_cycles += cycles_cut;                                       // (only now: the fallback counts the chains it cuts itself)
     }
     // ---- 3. heads of this rank, then every piece to the owner of its head ----
     uint64_t hm[2] = {0, 0};

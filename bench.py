@@ -231,7 +231,7 @@ def cli_end_to_end(lib, k, amin, read_len, gen_cfg, n_reads, device_id):
             for off in range(0, n_reads * rec, step):
                 chunk = g.read_text(off, min(step, n_reads * rec - off))
                 f.write(b">r\n" + chunk[:-1].replace(b"\n", b"\n>r\n") + b"\n")
-        g.close()
+        g.close(); g.release_cached()
         nbytes = os.path.getsize(fa)
         t0 = time.perf_counter()
         p = subprocess.run([exe, "-in", fa, "-kmer-size", str(k), "-abundance-min", str(amin), "-out", os.path.join(tmp, "e2e")],
@@ -239,10 +239,17 @@ def cli_end_to_end(lib, k, amin, read_len, gen_cfg, n_reads, device_id):
         wall = time.perf_counter() - t0
         ufa = os.path.join(tmp, "e2e.unitigs.fa")
         m = re.search(r"graph: (\d+) pieces -> (\d+) unitigs", p.stdout)
-        rep = [line for line in p.stdout.split("\n") if line.startswith(("input:", "GPU:"))]
+        rep = [line for line in p.stdout.split("\n") if line.startswith(("input:", "host:", "GPU:"))]
+        split = {}
+        for name, pat in (("init_s", r"host: init ([\d.]+) s"), ("ingest_s", r"ingest ([\d.]+) s"), ("ingest_GB_per_s", r"ingest [\d.]+ s = ([\d.]+) GB/s"),
+                          ("stages_s", r"stages ([\d.]+) s"), ("links_d2h_s", r"links \+ D2H ([\d.]+) s"), ("write_s", r"write ([\d.]+) s ="),
+                          ("write_GB_per_s", r"write [\d.]+ s = ([\d.]+) GB/s"), ("threads", r"\((\d+) threads\)")):
+            mm = re.search(pat, p.stdout)
+            if mm:
+                split[name] = float(mm.group(1))
         return {"ok": p.returncode == 0 and os.path.exists(ufa) and os.path.getsize(ufa) > 0, "wall_s": wall, "fasta_bytes": nbytes, "reads": n_reads,
                 "unitigs": int(m.group(2)) if m else None, "unitig_file_bytes": os.path.getsize(ufa) if os.path.exists(ufa) else 0,
-                "input_GB_per_s": nbytes / wall / 1e9, "cli_report": rep,
+                "input_GB_per_s": nbytes / wall / 1e9, "split": split, "cli_report": rep,
                 "what": "wall clock of `bcalm -in reads.fa -kmer-size %d -abundance-min %d` on a %.2f GB FASTA of the same generator: process start, HIP init, "
                         "parse + pinned H2D overlapped with the scan, count, compact, glue, links, D2H, FASTA write" % (k, amin, nbytes / 1e9)}
     finally:
@@ -286,7 +293,9 @@ def main():
     a.k = a.k or CFG["k"]; a.read_len = a.read_len or CFG["read_len"]
     a.reads = a.reads or int(os.environ.get("CDBG_BENCH_READS", CFG["reads"]))
     a.cpu_sample_reads = a.cpu_sample_reads or (10_000_000 if a.k <= 31 else 400_000)
-    a.e2e_reads = a.e2e_reads or min(a.reads, (1_100_000_000 + a.read_len) // (a.read_len + 1))
+    # end-to-end leg: >= 4.5 GB of FASTA by default (the full read set of the config with --e2e-reads = --reads: 15.4 GB at config 3; the
+    # default keeps the whole bench within minutes -- writing the FASTA takes longer than the CLI needs for it)
+    a.e2e_reads = a.e2e_reads or min(a.reads, (int(os.environ.get("CDBG_E2E_BYTES", 4_500_000_000)) + a.read_len) // (a.read_len + 4))
     gen_cfg = a.cfg | (0x100 if a.skewed else 0)           # generator seed / mode (cdbg_generate_reads)
     if a.cpu_worker:
         d, dt = _cpu_worker((a.k, a.abundance_min, a.read_len, a.gen_cfg if a.gen_cfg is not None else a.cfg, a.cpu_sample_reads))
@@ -502,7 +511,8 @@ def main():
                                       "achieved": alg_total / (gpu_ms * 1e-3) / 1e9,
                                       "frac": alg_total / (gpu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
-    g.close()                                                # (frees the HBM of the bench graph before the baseline / end-to-end legs)
+    g.close(); g.release_cached()                            # (close() hands the buffers to the process's pool; release_cached() gives the HBM back to the driver: the
+                                                             #  end-to-end leg is a child process and cannot drain this process's pool)
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cb = cpu_baseline(a.k, a.abundance_min, a.read_len, gen_cfg, a.cpu_sample_reads)
@@ -513,7 +523,7 @@ def main():
                 g2 = bcalm_amd.Graph(a.k, a.abundance_min, lib=lib, device_id=local_rank)
                 g2.generate_reads(a.cpu_sample_reads, a.read_len, gen_cfg)
                 g2.run()
-                d2 = g2.digest(); s2 = g2.stats(); g2.close()
+                d2 = g2.digest(); s2 = g2.stats(); g2.close(); g2.release_cached()
                 cb["gpu_same_sample"] = {"set_digest": "%016x" % d2["set_digest"], "distinct": s2["n_distinct"], "unitigs": s2["n_unitigs"], "gpu_ms": s2["ms_total"]}
                 cb["cpu_gpu_sets_equal"] = cb["set_digest"] == cb["gpu_same_sample"]["set_digest"] and cb["distinct"] == s2["n_distinct"] and cb["unitigs"] == s2["n_unitigs"]
                 out["checks"]["cpu restatement and GPU agree on the baseline sample (set digest)"] = cb["cpu_gpu_sets_equal"]

@@ -156,3 +156,99 @@ def test_cli_errors(cli, tmp_path):
     assert r.returncode == 0, r.stdout                                       # even k runs (README.md:99)
     r = subprocess.run([cli, "-v"], capture_output=True, text=True)
     assert r.returncode == 0 and "version" in r.stdout
+
+
+def _rand_reads(seed, n, lo, hi, glen=3000):
+    import random
+    rng = random.Random(seed)
+    g = "".join(rng.choice("ACGT") for _ in range(glen))
+    comp = str.maketrans("ACGT", "TGCA")
+    out = []
+    for _ in range(n):
+        L = rng.randrange(lo, hi); s = rng.randrange(0, glen - L)
+        r = g[s:s + L]
+        if rng.random() < 0.5:
+            r = r.translate(comp)[::-1]
+        if rng.random() < 0.1:
+            p = rng.randrange(L); r = r[:p] + "N" + r[p + 1:]
+        out.append(r)
+    return out
+
+
+def _cli_set(cli, oracle, tmp_path, args, k, env=None):
+    e = dict(os.environ); e.update(env or {})
+    r = subprocess.run([cli] + args + ["-kmer-size", str(k), "-abundance-min", "1", "-out", "o"], cwd=tmp_path, capture_output=True, text=True, env=e)
+    assert r.returncode == 0, r.stdout + r.stderr
+    recs = _parse_fa(tmp_path / "o.unitigs.fa")
+    return oracle_lib.canonical_set(oracle, [(s, kc) for s, _, kc, _ in recs], k), r.stdout
+
+
+@pytest.mark.parametrize("stage_bytes", ["100000", "192"])
+def test_cli_parallel_fasta_slices(cli, oracle, tmp_path, stage_bytes):
+    """a plain FASTA (wrapped lines, comment lines, CRLF) cut into many record-aligned slices for 5 parser threads that write straight into
+    the library's staging buffers (cdbg_stage_acquire / _commit); with 192-byte buffers every 300 .. 900 bp sequence is continued over
+    several buffers with a k-1 overlap: same unitig set as the oracle on the plain reads"""
+    reads = _rand_reads(7, 120, 300, 900)
+    with open(tmp_path / "in.fa", "w", newline="") as f:
+        for i, r in enumerate(reads):
+            f.write(">r%d x>y\r\n" % i if i % 3 == 0 else ">r%d\n" % i)
+            if i % 7 == 0:
+                f.write(";comment\n")
+            for j in range(0, len(r), 61):
+                f.write(r[j:j + 61] + ("\r\n" if i % 3 == 0 else "\n"))
+    exp = oracle.run("\n".join(reads) + "\n", 21, 1)
+    got, out = _cli_set(cli, oracle, tmp_path, ["-in", "in.fa", "-nb-cores", "5"], 21, {"BCALM_SLICE_BYTES": "700", "CDBG_STAGE_BYTES": stage_bytes})
+    assert got == exp["unitigs"]
+    assert "input: 120 sequences, %d bases" % sum(len(r) for r in reads) in out
+
+
+def test_cli_parallel_fastq_slices_and_fallback(cli, oracle, tmp_path):
+    """strict four-line FASTQ in slices (quality lines that start with '@' and '+' must not be taken for headers); a file whose FIRST
+    record is four lines but a later one wraps falls back to the tolerant serial parser; a file list of plain and gzip files"""
+    import gzip
+    reads = _rand_reads(11, 150, 60, 200)
+    with open(tmp_path / "s.fastq", "w") as f:
+        for i, r in enumerate(reads):
+            q = ("@+I@" * len(r))[:len(r)] if i % 2 else ("+@" * len(r))[:len(r)]
+            f.write("@r%d\n%s\n+\n%s\n" % (i, r, q))
+    exp = oracle.run("\n".join(reads) + "\n", 21, 1)
+    got, out = _cli_set(cli, oracle, tmp_path, ["-in", "s.fastq", "-nb-cores", "4"], 21, {"BCALM_SLICE_BYTES": "500", "CDBG_STAGE_BYTES": "4096"})
+    assert got == exp["unitigs"] and "input: 150 sequences" in out
+    with open(tmp_path / "mixed.fastq", "w") as f:
+        for i, r in enumerate(reads):
+            if i == 70:                                  # one wrapped record in the middle
+                f.write("@r%d\n%s\n%s\n+\n%s\n%s\n" % (i, r[:30], r[30:], "I" * 30, "@" * (len(r) - 30)))
+            else:
+                f.write("@r%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)))
+    got, out = _cli_set(cli, oracle, tmp_path, ["-in", "mixed.fastq", "-nb-cores", "4"], 21, {"BCALM_SLICE_BYTES": "500"})
+    assert got == exp["unitigs"] and "input: 150 sequences" in out
+    # file list: two plain FASTA parts and one gzip FASTQ part
+    parts = [reads[:50], reads[50:100], reads[100:]]
+    with open(tmp_path / "p0.fa", "w") as f:
+        f.write("".join(">a\n%s\n" % r for r in parts[0]))
+    with open(tmp_path / "p1.fa", "w") as f:
+        f.write("".join(">b\n%s\n" % r for r in parts[1]))
+    with gzip.open(tmp_path / "p2.fq.gz", "wt") as f:
+        f.write("".join("@c\n%s\n+\n%s\n" % (r, "I" * len(r)) for r in parts[2]))
+    (tmp_path / "list.txt").write_text("p0.fa\np1.fa\np2.fq.gz\n")
+    got, out = _cli_set(cli, oracle, tmp_path, ["-in", "list.txt", "-nb-cores", "3"], 21, {"BCALM_SLICE_BYTES": "900"})
+    assert got == exp["unitigs"] and "input: 150 sequences" in out
+
+
+def test_stage_calls_through_the_abi(oracle):
+    """cdbg_stage_acquire / cdbg_stage_commit from Python (simulator build): same graph as cdbg_push_text; mixing both; a buffer handed back unused"""
+    import hostsim_lib
+    from bcalm_amd import api
+    sim = hostsim_lib.load()
+    text = oracle.synth_reads(800, 150, 3)
+    exp = oracle.run(text, 31, 2)
+    g = api.Graph(31, 2, lib=sim)
+    half = text.rfind(b"\n", 0, len(text) // 2) + 1
+    g.stage_text(text[:half]); g.push_text(text[half:])
+    buf, cap = api.C.c_void_p(), api.C.c_uint64()
+    assert sim.cdbg_stage_acquire(g._h, api.C.byref(buf), api.C.byref(cap)) == 0 and cap.value >= 64
+    assert sim.cdbg_stage_commit(g._h, buf, 0) == 0
+    assert sim.cdbg_stage_commit(g._h, buf, 0) != 0          # not held any more
+    g.run()
+    assert oracle_lib.canonical_set(oracle, g.unitigs(), 31) == exp["unitigs"]
+    g.close()
