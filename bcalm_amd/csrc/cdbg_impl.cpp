@@ -22,6 +22,9 @@
 #include <ctime>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <atomic>
+#include <chrono>
 #include <unordered_set>
 #include <vector>
 
@@ -81,6 +84,7 @@ int cdbg_create(const cdbg_params* p, cdbg_ctx** out) {
 void cdbg_destroy(cdbg_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
+    prewarm_join(c);
     ingest_release(c);
 #ifndef CDBG_HOSTSIM
     if (c->rccl) { c->rccl->destroy(); delete c->rccl; c->rccl = nullptr; }
@@ -140,6 +144,15 @@ int cdbg_expect_input(cdbg_ctx* c, uint64_t text_bytes) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
     if (c->stage != 0 || c->n_dev || c->pin_fill) return fail(CDBG_E_STATE, "cdbg_expect_input must precede the first push");
     c->expect_bytes = text_bytes;
+    // a large input on one GPU: obtain the text buffer, the record region and the solid arrays in the background (host_count.h prewarm_run)
+    uint64_t min_bytes = 1ull << 30;
+    if (const char* e = c->knobs.get("CDBG_PREWARM_MIN_BYTES")) min_bytes = strtoull(e, nullptr, 10);
+    if (c->prm.world_size == 1 && !c->force_multi && text_bytes >= min_bytes && !c->knobs.get("CDBG_NO_PREWARM") && !c->prewarm.joinable()) {
+        (void)hipSetDevice(c->prm.device_id);
+        configure(c, text_bytes);                          // (what the streaming scan will choose from the same number)
+        c->prewarm_reads = 1; c->prewarm_region = 1;
+        c->prewarm = std::thread(prewarm_run, c);
+    }
     return CDBG_OK;
 }
 int cdbg_generate_reads(cdbg_ctx* c, uint64_t first_read, uint64_t n_reads, uint64_t total_reads, uint64_t read_len, int cfg) {

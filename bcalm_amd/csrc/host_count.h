@@ -52,6 +52,60 @@ void capped_capacities(const cdbg_ctx* c, double mean, uint64_t NPL, uint32_t& p
     spill_cap = std::max<uint64_t>((uint64_t)(mean * (double)NPL / 32.0), 65536);
 }
 
+// ---- grids of the count stage's launches (every persistent workgroup of every launch may strand one partly used output chunk) ----
+#ifndef CDBG_SIFT_GRID
+#define CDBG_SIFT_GRID (256 * 16)
+#endif
+#ifndef CDBG_T2_GRID
+#define CDBG_T2_GRID 256
+#endif
+#ifndef CDBG_MP_GRID_W
+#define CDBG_MP_GRID_W 256
+#endif
+#ifndef CDBG_MP_GRID_1
+#define CDBG_MP_GRID_1 (256 * 48)                          // (one-word multi-pass kernel on the hostile line: count 92.4 -> 86.9 ms with 12288 instead of 3072 workgroups;
+#endif                                                   //  2048 instead of 256 for the wider kernels: neutral at k = 55, + 3 ms at k = 127 -- profiles/r04_ab_cfg3_count_grid.log)
+constexpr uint64_t SIFT_GRID = CDBG_SIFT_GRID, T2_GRID = CDBG_T2_GRID, MP_GRID_W = CDBG_MP_GRID_W, MP_GRID_1 = CDBG_MP_GRID_1;
+// (launches of the stage: one-pass tier 1 of COUNT_GRID workgroups, tier 2 of at most SIFT_GRID, multi-pass retry, spill repair, HBM tables)
+inline uint64_t count_solid_slack(uint64_t NPL) {
+    return 4096 + (std::min<uint64_t>(NPL, COUNT_GRID) + 3 * std::min<uint64_t>(NPL, PERSISTENT_GRID) + SIFT_GRID + T2_GRID + 2 * (MP_GRID_1 > MP_GRID_W ? MP_GRID_1 : MP_GRID_W) + 768 + 5) * (uint64_t)COUNT_CHUNK;
+}
+// first attempt at the solid arrays' size (see count_impl): a third of the bound of one entry per abundance-min member k-mers
+inline uint64_t count_solid_first_cap(uint64_t members, int amin, uint64_t NPL) {
+    return std::max<uint64_t>(members / (uint64_t)std::max(1, amin) / 3, 1u << 16) + count_solid_slack(NPL);
+}
+
+// ---------------------------------------------------------------------------------------
+// Pre-warm thread (cdbg_expect_input; host_ctx.h): the text buffer, the record region and the solid arrays, sized from the announced
+// volume a little above what the stages will ask for (a DBuf keeps an allocation that is large enough), obtained while the caller parses
+// ---------------------------------------------------------------------------------------
+void prewarm_run(cdbg_ctx* c) {
+    (void)hipSetDevice(c->prm.device_id);
+    const uint64_t bytes = c->expect_bytes;
+    { DBuf<uint8_t> b; const uint64_t cap = std::max<uint64_t>(256ull << 20, bytes + bytes / 64 + (8ull << 20));
+      if (c->reads.cap < cap && !c->n_dev && b.alloc(cap, false) == CDBG_OK) c->reads.swap(b); }   // (a context that is re-run keeps what it has)
+    c->prewarm_reads.store(0, std::memory_order_release);
+    const int RW = 2 * c->W;
+    const uint64_t NPL = c->n_local_parts;
+    {   // records: ~2 runs of junctions per window of k - m + 1 minimizer positions
+        const double rec = (double)bytes * 2.0 / (double)(c->k - c->m + 2) * 1.12;
+        uint32_t part_cap = 0; uint64_t spill_cap = 0; capped_capacities(c, rec / (double)NPL, NPL, part_cap, spill_cap);
+        DBuf<uint64_t> r;
+        size_t fr = 0, tot = 0;
+        const bool fits = hipMemGetInfo(&fr, &tot) == hipSuccess && (double)part_cap * (double)NPL * RW * 8.0 < 0.6 * (double)fr;
+        if (fits && c->records.cap < (uint64_t)part_cap * NPL * RW && r.alloc((uint64_t)part_cap * NPL * RW, false) == CDBG_OK) c->records.swap(r);
+    }
+    c->prewarm_region.store(0, std::memory_order_release);
+    {   // solid arrays (touched by cdbg_count only, which joins this thread first)
+        const uint64_t cap = count_solid_first_cap(bytes + bytes / 8, c->prm.abundance_min, NPL);
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (double)cap * (8.0 * c->W + 4.0) < 0.5 * (double)fr) {
+            (void)c->solid_keys.alloc(cap * (uint64_t)c->W, false); (void)c->solid_cnt.alloc(cap, false);
+        }
+    }
+}
+void prewarm_join(cdbg_ctx* c) { if (c->prewarm.joinable()) c->prewarm.join(); c->prewarm_reads = 0; c->prewarm_region = 0; }
+
 // ---------------------------------------------------------------------------------------
 // Streaming scan: with cdbg_expect_input() the library knows the input volume before the last byte has
 // arrived, so partitioning and region capacities are fixed from the first ~128 MB that landed and the single-pass scan
@@ -62,6 +116,7 @@ int stream_scan_advance(cdbg_ctx* c) {
     constexpr int RW = RecFmt<W>::RW;
     hipStream_t s = c->stream;
     const uint64_t landed = c->n_dev & ~15ull;
+    if (!c->ss_on && c->prewarm_region.load(std::memory_order_acquire)) return CDBG_OK;   // (the pre-warm thread is obtaining the record region: a later push starts the scan)
     if (!c->ss_on) {
         // (test knobs: CDBG_STREAM_MIN_BYTES / CDBG_STREAM_BATCH_TILES shrink the thresholds to simulator sizes)
         const char* emin = c->knobs.get("CDBG_STREAM_MIN_BYTES");
@@ -125,6 +180,7 @@ int count_impl(cdbg_ctx* c) {
     const bool multi_ctx = c->prm.world_size > 1 || c->force_multi;
     const int world = c->prm.world_size;
     if (multi_ctx && !c->have_tr) return fail(CDBG_E_STATE, "world_size %d but no transport: call cdbg_comm_init_rccl or cdbg_set_transport first", world);
+    prewarm_join(c);
     int rc_in = upload_pending(c);
     if (rc_in == CDBG_OK && (!c->reads.p || (c->nbytes == 0 && !multi_ctx))) rc_in = fail(CDBG_E_STATE, "no reads: call cdbg_push_reads/cdbg_push_text/cdbg_generate_reads first");
     if (!multi_ctx) CK(rc_in);
@@ -415,24 +471,17 @@ int count_impl(cdbg_ctx* c) {
     c->st.n_records = n_records; c->st.n_member_kmers = hs[0];
     hm.mark("count: spill repair/exchange");
 
-    // count
-    // (slack: every persistent workgroup of every launch of the stage may strand one partly used chunk)
-    // (launches of the stage: one-pass tier 1 of COUNT_GRID workgroups, tier 2 of at most SIFT_GRID, multi-pass retry, spill repair, HBM tables)
-#ifndef CDBG_SIFT_GRID
-#define CDBG_SIFT_GRID (256 * 16)
-#endif
-    constexpr uint64_t SIFT_GRID = CDBG_SIFT_GRID;
-#ifndef CDBG_T2_GRID
-#define CDBG_T2_GRID 256
-#endif
-#ifndef CDBG_MP_GRID_W
-#define CDBG_MP_GRID_W 256
-#endif
-#ifndef CDBG_MP_GRID_1
-#define CDBG_MP_GRID_1 (256 * 48)                          // (one-word multi-pass kernel on the hostile line: count 92.4 -> 86.9 ms with 12288 instead of 3072 workgroups;
-#endif                                                   //  2048 instead of 256 for the wider kernels: neutral at k = 55, + 3 ms at k = 127 -- profiles/r04_ab_cfg3_count_grid.log)
-    constexpr uint64_t T2_GRID = CDBG_T2_GRID, MP_GRID_W = CDBG_MP_GRID_W, MP_GRID_1 = CDBG_MP_GRID_1;
-    const uint64_t solid_cap = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + 4096 + (std::min<uint64_t>(NPL, COUNT_GRID) + 3 * std::min<uint64_t>(NPL, PERSISTENT_GRID) + SIFT_GRID + T2_GRID + 2 * (MP_GRID_1 > MP_GRID_W ? MP_GRID_1 : MP_GRID_W) + 768 + 5) * (uint64_t)COUNT_CHUNK;
+    // Solid entries: at most one per abundance-min member k-mers -- a bound that is 12 x the need at sequencing depth (config 3: 6.7 G
+    // entries, 81 GB, for 0.65 G), and fresh device memory costs 40 - 70 ms per GB to obtain (profiles/r05_micro_alloc.log: the CLI's
+    // first and only job paid seconds for it).  First attempt: a third of the bound; the kernels report an overflow (device error 1)
+    // without writing out of bounds, and the stage then runs once more with the bound itself (an input of mostly distinct k-mers).
+    const uint64_t solid_slack = count_solid_slack(NPL);
+    const uint64_t solid_bound = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + solid_slack;
+    uint64_t solid_cap = std::min(solid_bound, count_solid_first_cap(hs[0], c->prm.abundance_min, NPL));
+    if (c->knobs.get("CDBG_SOLID_FIRST_TINY")) solid_cap = 1u << 15;   // (tests: force the second attempt; not below one partition's entries -- the kernels park an overflowing partition at offset 0)
+    if (c->solid_keys.cap >= solid_bound * W && c->solid_cnt.cap >= solid_bound) solid_cap = solid_bound;   // (a context that was re-run keeps what it has)
+    float ms_count_first = 0;
+    for (int solid_attempt = 0;; ++solid_attempt) {
     CK(c->solid_keys.alloc(solid_cap * W, false));
     CK(c->solid_cnt.alloc(solid_cap, false));
     CK(c->solid_cursor.alloc(4, true));
@@ -566,8 +615,16 @@ int count_impl(cdbg_ctx* c) {
         CDBG_LAUNCH((k_count<W, TS, 256, true>), std::min<uint64_t>(nbig, PERSISTENT_GRID), 256, s, bp);
         c->st.n_big_partitions += nbig;
     }
-    CK(t.stop(&c->st.ms_count));
+    CK(t.stop(&c->st.ms_count)); c->st.ms_count += ms_count_first;
     hm.mark("count: HBM-table partitions");
+    { uint32_t de = 0; CK(read_u32(c->derr.p, &de));
+      if (de == 1 && solid_cap < solid_bound && solid_attempt == 0) {                       // the first attempt's estimate was too small: once more with the bound
+          ms_count_first = c->st.ms_count; solid_cap = solid_bound; c->st.n_big_partitions = 0; c->st.n_multipass_partitions = 0;
+          HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t)));
+          continue;
+      } }
+    break;
+    }
     CK(check_device_error(c, "count"));
     uint64_t cs[4]; CK(read_u64(c->dstats.p, cs, 4));
 #ifdef CDBG_PROFILE_PHASES

@@ -206,7 +206,7 @@ int glue_table_slots(uint64_t want, uint32_t* out) {
 struct Knobs {
     std::vector<std::pair<std::string, std::string>> kv;
     void snapshot() {
-        static const char* const NAMES[] = { "CDBG_DEBUG_SEGHIST", "CDBG_FAST_MAX_RECORDS", "CDBG_FAST_SKIP2_Q8", "CDBG_FAST_SKIP_Q8", "CDBG_FORCE_MULTI", "CDBG_GENERIC_SCAN", "CDBG_GLUE_LOG", "CDBG_GLUE_RANK", "CDBG_GLUE_REPLICATED", "CDBG_GLUE_TABLE", "CDBG_JOIN_LOG_JB", "CDBG_NO_COUNT_TIER2", "CDBG_NO_SIFT", "CDBG_NO_SPLIT", "CDBG_PART_CAP", "CDBG_REPAIR_MAX_PASSES", "CDBG_SCAN_MODE", "CDBG_STAGE_BYTES", "CDBG_STREAM_BATCH_TILES", "CDBG_STREAM_MIN_BYTES", "CDBG_VAR_SCALE", "CDBG_WALK_MAX" };
+        static const char* const NAMES[] = { "CDBG_SOLID_FIRST_TINY", "CDBG_PREWARM_MIN_BYTES", "CDBG_NO_PREWARM", "CDBG_DEBUG_SEGHIST", "CDBG_FAST_MAX_RECORDS", "CDBG_FAST_SKIP2_Q8", "CDBG_FAST_SKIP_Q8", "CDBG_FORCE_MULTI", "CDBG_GENERIC_SCAN", "CDBG_GLUE_LOG", "CDBG_GLUE_RANK", "CDBG_GLUE_REPLICATED", "CDBG_GLUE_TABLE", "CDBG_JOIN_LOG_JB", "CDBG_NO_COUNT_TIER2", "CDBG_NO_SIFT", "CDBG_NO_SPLIT", "CDBG_PART_CAP", "CDBG_REPAIR_MAX_PASSES", "CDBG_SCAN_MODE", "CDBG_STAGE_BYTES", "CDBG_STREAM_BATCH_TILES", "CDBG_STREAM_MIN_BYTES", "CDBG_VAR_SCALE", "CDBG_WALK_MAX" };
         for (const char* n : NAMES) if (const char* e = getenv(n)) kv.emplace_back(n, e);
     }
     const char* get(const char* name) const { for (const auto& p : kv) if (p.first == name) return p.second.c_str(); return nullptr; }
@@ -233,6 +233,11 @@ struct cdbg_ctx {
     struct Stage { uint8_t* p = nullptr; hipEvent_t ev{}; int state = 0; };
     static constexpr int MAX_STAGES = 64;
     std::mutex ingest_mu; std::vector<Stage> stages;
+    // Pre-warm (cdbg_expect_input on a large input): fresh device memory costs 40 - 70 ms per GB to obtain, seconds for the text, the
+    // record region and the solid arrays of a job -- a background thread obtains them, sized from the announced volume, while the
+    // caller parses.  prewarm_reads / prewarm_region: 1 while the thread is still about to publish c->reads / c->records (the ingest
+    // path waits for the text buffer instead of allocating a second one; the streaming scan starts once the region is there).
+    std::thread prewarm; std::atomic<int> prewarm_reads{0}, prewarm_region{0};
     uint64_t n_dev = 0;                          // bytes of text already on (or on their way to) the device
     bool reads_final = false;                    // text complete, padded, nbytes set
     // streaming scan (cdbg_expect_input): tiles already scanned while the input was still arriving
@@ -315,6 +320,7 @@ void ingest_release(cdbg_ctx* c) {
 }
 // device text with room for `need` bytes: grows by doubling (device-to-device copy of what is already there)
 int ingest_reserve(cdbg_ctx* c, uint64_t need) {
+    while (c->prewarm_reads.load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(200));   // (the pre-warm thread is obtaining the text buffer)
     if (c->reads.p && c->reads.cap >= need) return CDBG_OK;
     uint64_t cap = std::max<uint64_t>(c->reads.cap * 2, 256ull << 20);
     if (c->expect_bytes) cap = std::max<uint64_t>(cap, c->expect_bytes + c->expect_bytes / 64 + (8ull << 20));   // announced: one allocation

@@ -92,11 +92,19 @@ template <int W> struct CountGeom {
 //   smask        per wave: bit g set <=> a record of the batch starts at member position g
 //   emask        per wave: bit g set <=> the member at position g is the last of a record that has something to say about it
 //   fp           sifting tier only (FS > 0, below): FS fingerprint words
+// (sifting tier: members per wave and partition whose fingerprint word is remembered from pass 0; the rest look theirs up again)
+#ifdef CDBG_HOSTSIM
+constexpr uint32_t SIFT_MS_CAP = 96;                     // (simulator: the small test partitions run through both kinds of member)
+#else
+constexpr uint32_t SIFT_MS_CAP = 1280;
+#endif
 template <int W, int TS, int NT, int FS = 0>
 struct CountFastLds {
     uint64_t keys[TS * W];
     uint32_t cnt[TS];
     uint32_t fp[FS > 0 ? FS : 1]; uint32_t fpfill;       // fpfill: distinct fingerprints of the partition
+    uint16_t mslot[FS > 0 ? (NT / 64) * SIFT_MS_CAP : 2];   // sifting tier: per wave, the fingerprint word of its j-th member k-mer (pass 0 -> pass 1)
+    uint16_t ring[FS > 0 ? (NT / 64) * 128 : 2];            // sifting tier, pass 1: per wave, the members seen again that wait for a full 64-lane step
     uint64_t stage[(NT / 64) * CountCb<W>::V * RecFmt<W>::RW + 2];   // + 2: the dword window of the last record may over-read (up to 4 dwords)
     uint64_t smask[(NT / 64) * CountGeom<W>::MASKW];
     uint64_t emask[(NT / 64) * CountGeom<W>::MASKW];
@@ -216,6 +224,11 @@ CDBG_DEV void count_issue_ahead(const CountParams& P, CountAhead<W, CAPPED>& A, 
 // the second pass gives the exact table only the k-mers whose fingerprint was seen again.  Exact all the same: a fingerprint
 // seen once IS one occurrence of one k-mer (counted as a distinct k-mer of abundance 1 on the spot), and k-mers that share
 // a fingerprint are told apart by their keys in the exact table as before.  The exact table is a quarter of tier 1's.
+// Round 5: pass 1 no longer extracts every member a second time.  Pass 0 leaves, per member, the fingerprint WORD it ended at
+// (13 bits, L.mslot: the wave's j-th member); pass 1 runs a light step over the members -- slot -> "seen again" bit, nothing else:
+// 71 % of them at the config-5 share learn here that their k-mer occurred once -- and gathers the others in a small ring; a heavy
+// step (cut the k-mer out of the record, reverse complement, hash, exact insert) runs whenever 64 of them wait: every heavy
+// lane works.  Members beyond SIFT_MS_CAP per wave take the heavy step and look their fingerprint up by its tag as before.
 // returns false when the partition did not fit one pass (table left dirty)
 template <int W, int TS, int NT, int CAPPED, int FS = 0>
 CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT, FS>& L, const CountRange& rg, CountAhead<W, CAPPED>& A,
@@ -355,6 +368,7 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT,
 #pragma clang loop unroll(disable)
     for (int phase = SIFT ? 0 : 1; phase < 2; ++phase) {                       // (sifting tier: 0 = fingerprints, 1 = exact counts of what was seen again)
     RecView<W> R = A.cur->R;
+    uint32_t mbase = 0;                                                       // (sifting tier) members of this wave's earlier batches: the same numbering in both passes
     for (uint64_t c0 = w0; c0 < w1; c0 += 64) {                               // wave-uniform
         if (c0 != w0) count_load_chunk<W>(P, c0, w1, lane, R);                 // (the first 64 records came prefetched)
         const int nrec = (int)((w1 - c0) < 64 ? (w1 - c0) : 64);
@@ -398,6 +412,120 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT,
             }
             CDBG_WAVE_SYNC();
             if (!A.issued) { CDBG_FPH(1); count_issue_ahead<W, NW, CAPPED>(P, A, wave, lane); }        // behind the wait for this partition's own records
+            if constexpr (SIFT) if (phase == 1) {
+                // ---- sifting tier, pass 1: light steps over all members, heavy steps over the ones seen again ----
+                static_assert(!SIFT || (COUNT_CB <= 8 && COUNT_CB * (CountGeom<W>::NMAX < 255 ? CountGeom<W>::NMAX : 255) <= 2048), "ring entry: 11 bits of member position (a record holds at most 255 members: its 8-bit field), 3 bits of record");
+                uint16_t* const ring = L.ring + (size_t)wave * 128;
+                const uint16_t* const ms = L.mslot + (size_t)wave * SIFT_MS_CAP;
+                uint32_t rn = 0, rhead = 0;                                   // wave-uniform: entries waiting / first of them
+                auto heavy = [&](const uint32_t cnt) {                        // the first cnt (<= 64) waiting members, one per lane
+                    bool is_new = false;
+                    if ((uint32_t)lane < cnt) {
+                        const uint32_t e = ring[(rhead + (uint32_t)lane) & 127u];
+                        const uint32_t g = e & 0x7FFu, slot = (e >> 11) & 7u;
+                        const uint32_t ri = rinfo[slot];
+                        const uint32_t sh = (ri & 0x1FFFu) - 2u * g;
+                        const uint32_t isf = (uint32_t)(smask[g >> 6] >> (g & 63u)) & 1u, isl = (uint32_t)(emask[g >> 6] >> (g & 63u)) & 1u;
+                        const uint32_t facts = ((isf ? ri : 0u) & 0x68000000u) | ((isl ? ri : 0u) & ~0x68000000u);
+                        const bool trav = (facts & 0x0C000000u) != 0u;
+                        const uint32_t* dw = reinterpret_cast<const uint32_t*>(stage + slot * RW) + (sh >> 5);
+                        uint32_t in[2 * W + 1];
+#pragma unroll
+                        for (int j = 0; j < 2 * W + 1; ++j) in[j] = dw[j];
+                        Kmer<W> fw;
+#pragma unroll
+                        for (int i = 0; i < W; ++i)
+                            fw.w[i] = ((uint64_t)alignbit_u32(in[2 * i + 2], in[2 * i + 1], sh) << 32) | alignbit_u32(in[2 * i + 1], in[2 * i], sh);
+                        fw.mask(k);
+#ifdef CDBG_AB_NO_RC
+                        const Kmer<W> rc = fw; const bool rev = false;
+#else
+                        const Kmer<W> rc = fw.rc(k);
+                        const bool rev = rc < fw;
+#endif
+                        const Kmer<W>& can = rev ? rc : fw;
+                        const uint64_t ktop = can.w[W - 1] | ((uint64_t)((rev ? facts << 2 : facts) & 0xC0000000u) << 32);
+                        const uint32_t hh = can.hash_lds();
+                        uint32_t s = hh >> (32 - LOG_TS);
+                        bool go = true;
+                        if (e & 0x8000u) {                                     // beyond the remembered members: the fingerprint is found by its tag
+                            uint32_t fs = hh >> (32 - LOG_FS), probes = 0, old;
+                            const uint32_t tag = (((hh ^ (hh >> 15)) * 0x2C1B3C6Du) & ~3u) | 1u;
+#pragma clang loop unroll(disable)
+                            for (;;) {                                         // (the tag is there: pass 0 put it)
+                                old = L.fp[fs];
+                                if ((old & ~2u) == tag || old == 0u || ++probes == 64u) break;
+                                fs = (fs + 1) & (FS - 1);
+                            }
+                            if (!(old & 2u)) { go = false; if (!trav) ++n_once; }
+                        }
+                        if (go) {
+                            const uint64_t top = ktop, ptop = key_pending(ktop);
+                            uint32_t probes = 0;
+                            bool hit = false;
+#pragma clang loop unroll(disable)
+                            do {                                               // (single exit, publish inside the iteration: see ktable_insert)
+                                uint64_t* const slotp = &L.keys[(uint64_t)s * W];
+                                const uint64_t old = atomic_cas_u64(slotp + (W - 1), KEY_EMPTY, ptop);
+                                bool eq = true;
+                                if (old == top) {
+#pragma unroll
+                                    for (int i = 0; i < W - 1; ++i) eq &= (slotp[i] == can.w[i]);
+                                }
+                                const bool mine = old == KEY_EMPTY, same = (old == top) & eq, wait = old == ptop;
+                                if (wait) CDBG_SPIN_YIELD();
+                                if (mine) {
+#pragma unroll
+                                    for (int i = 0; i < W - 1; ++i) slotp[i] = can.w[i];
+                                    CDBG_LDS_FENCE();
+                                    atomic_exch_u64(slotp + (W - 1), top);
+                                }
+                                is_new = is_new | mine; hit = mine | same;
+                                const bool advance = !(hit | wait);
+                                s = advance ? ((s + 1) & (TS - 1)) : s; probes += advance ? 1u : 0u;
+                            } while (!hit && probes < 64u);
+                            if (!hit) L.over = 1;
+                            else {
+                                atomic_add_u32(&L.cnt[s], 1u);
+                                if (trav) atomic_or_u32(&L.cnt[s], TRAV_FLAG);
+                            }
+                        }
+                    }
+                    n_new += (uint32_t)__popcll(__ballot(is_new));
+                };
+                uint32_t started1 = 0;
+                for (uint32_t g0 = 0; g0 < total; g0 += 64) {                 // wave-uniform trip count
+                    const uint64_t M = uni_u64(smask[g0 >> 6]), E = uni_u64(emask[g0 >> 6]);
+                    const uint32_t g = g0 + (uint32_t)lane;
+                    const uint32_t slot = started1 + (uint32_t)__popcll(M & lane_le) - 1u;
+                    started1 += (uint32_t)__popcll(M);
+                    bool want = false; uint32_t entry = 0;
+                    if (g < total) {
+                        const uint32_t mi = mbase + g;
+                        entry = g | (slot << 11);
+                        if (mi < SIFT_MS_CAP) {
+                            const uint32_t old = L.fp[ms[mi]];
+                            want = (old & 2u) != 0u;
+                            if (!want) {                                       // seen once: one k-mer of abundance 1 (a traveller copy is not counted)
+                                const uint32_t ri = rinfo[slot];
+                                const uint32_t as_first = lane_pick_u32(M, ri, lane), as_last = lane_pick_u32(E, ri, lane);
+                                if (!(((as_first & 0x68000000u) | (as_last & ~0x68000000u)) & 0x0C000000u)) ++n_once;
+                            }
+                        } else { want = true; entry |= 0x8000u; }
+                    }
+                    const uint64_t wb = __ballot(want);
+                    if (want) ring[(rhead + rn + (uint32_t)__popcll(wb & (lane_le >> 1))) & 127u] = (uint16_t)entry;
+                    rn += (uint32_t)__popcll(wb);
+                    CDBG_WAVE_SYNC();
+                    if (rn >= 64u) { heavy(64u); rhead = (rhead + 64u) & 127u; rn -= 64u; CDBG_WAVE_SYNC(); }
+                }
+                if (rn) { heavy(rn); }
+                mbase += total;
+                CDBG_WAVE_SYNC();                                              // every lane has read the stage and the masks
+                if (lane < MASKW && lane <= (int)((total + 63) >> 6)) { smask[lane] = 0; emask[lane] = 0; }
+                CDBG_WAVE_SYNC();
+                continue;
+            }
             uint32_t started = 0;                                             // records of the batch that start before the step's window
             for (uint32_t g0 = 0; g0 < total; g0 += 64) {                     // wave-uniform trip count
                 const uint64_t M = uni_u64(smask[g0 >> 6]), E = uni_u64(emask[g0 >> 6]);   // (scalar: used as lane predicates below)
@@ -451,7 +579,7 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT,
                         uint32_t fs = hh >> (32 - LOG_FS);
                         const uint32_t tag = (((hh ^ (hh >> 15)) * 0x2C1B3C6Du) & ~3u) | 1u;
                         uint32_t probes = 0;
-                        if (phase == 0) {
+                        {                                                  // (pass 0 only: pass 1 is the branch above)
                             go = false;
 #pragma clang loop unroll(disable)
                             for (;;) {
@@ -461,18 +589,7 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT,
                                 fs = (fs + 1) & (FS - 1);
                                 if (++probes == 64u) { hit = false; break; }
                             }
-                        } else {
-                            uint32_t old;
-#pragma clang loop unroll(disable)
-                            for (;;) {                                         // (the tag is there: pass 0 put it -- unless the table overflowed, and then the partition is given up)
-                                old = L.fp[fs];
-                                if ((old & ~2u) == tag || old == 0u || ++probes == 64u) break;
-                                fs = (fs + 1) & (FS - 1);
-                            }
-                            if (!(old & 2u)) {                                 // seen once: one k-mer of abundance 1
-                                go = false;
-                                if (!trav) ++n_once;
-                            }
+                            if (mbase + g < SIFT_MS_CAP) L.mslot[(size_t)wave * SIFT_MS_CAP + mbase + g] = (uint16_t)fs;   // where pass 1 finds this member's "seen again" bit
                         }
                     }
                     if (!go) { if (!hit) L.over = 1; }
@@ -542,6 +659,7 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT,
             CDBG_WAVE_SYNC();                                                  // every lane has read the stage and the mask
             if (lane < MASKW && lane <= (int)((total + 63) >> 6)) { smask[lane] = 0; emask[lane] = 0; }   // hand the masks back clean
             CDBG_WAVE_SYNC();
+            mbase += total;
         }
     }
     if (SIFT && phase == 0) {

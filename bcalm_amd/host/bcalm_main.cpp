@@ -42,7 +42,7 @@ namespace {
 struct Options {
     std::string in, out;
     int k = 31, amin = 2, m = 0, device = 0, log_np = -1, n_gpus = 1, cores = 0;
-    bool gfa = false, verbose = false, all_ab = false;
+    bool gfa = false, verbose = false, all_ab = false, no_stream = false;
     std::string solid_out;
 };
 
@@ -65,6 +65,7 @@ Options parse(int argc, char** argv) {
         else if (a == "-log2-partitions") o.log_np = atoi(need("-log2-partitions"));
         else if (a == "-nb-gpus") o.n_gpus = atoi(need("-nb-gpus"));   // the GPU path's counterpart of -nb-cores: GPUs of this node (power of two)
         else if (a == "-gfa") o.gfa = true;
+        else if (a == "-no-stream-scan") o.no_stream = true;           // dev: do not announce the input volume (the read scan starts when the text is complete)
         else if (a == "-all-abundance-counts") o.all_ab = true;        // README.md:74-80
         else if (a == "-solid-kmers-out") o.solid_out = need("-solid-kmers-out");   // hidden in the reference (bcalm_1.cpp:37)
         else if (a == "-verbose") { o.verbose = true; if (i + 1 < argc && argv[i + 1][0] != '-') ++i; }
@@ -394,7 +395,7 @@ int main(int argc, char** argv) {
         } else files.push_back(o.in);
         uint64_t n_seq = 0, n_bases = 0;
         for (int attempt = 0;; ++attempt) {
-            if (world == 1) {                                // announce the volume: the scan starts while the input is still being parsed
+            if (world == 1 && !o.no_stream) {                // announce the volume: the scan starts while the input is still being parsed
                 uint64_t est = 0; for (const auto& f : files) est += estimate_text_bytes(f);
                 if (est) check(cdbg_expect_input(ctx, est));
             }

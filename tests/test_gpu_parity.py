@@ -233,20 +233,22 @@ def test_glue_record_paths_gpu(oracle, hip, mode, k, n_reads, read_len, cfg, mon
 
 
 @pytest.mark.parametrize("k", [64, 127, 160])
-@pytest.mark.parametrize("case", ["sifted", "solid_overflow", "fingerprint_overflow"])
+@pytest.mark.parametrize("case", ["sifted", "solid_overflow", "fingerprint_overflow", "many_members"])
 def test_count_sift_tier_gpu(oracle, hip, k, case):
     """k-mers of three words and more under an abundance filter, ONE partition of mostly once-seen k-mers that overflows the
     one-pass table: the sifting tier (fingerprints first, exact counts for what was seen again: k_count_fast.h) takes it; too
     many k-mers seen again for its small exact table, or too many fingerprints, and the multi-pass kernel does"""
     rng = random.Random(k * 7 + len(case))
     rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
-    solid_len = {"sifted": 250, "solid_overflow": 1500, "fingerprint_overflow": 250}[case] + k
-    noise = {"sifted": 26, "solid_overflow": 8, "fingerprint_overflow": 90}[case]
+    solid_len = {"sifted": 250, "solid_overflow": 1500, "fingerprint_overflow": 250, "many_members": 300}[case] + k
+    noise = {"sifted": 26, "solid_overflow": 8, "fingerprint_overflow": 90, "many_members": 55}[case]
     g = rnd(solid_len)
     reads = [g, g, g[5:], g[::-1].translate(str.maketrans("ACGT", "TGCA"))] + [rnd(k + 99) for _ in range(noise)]
+    if case == "many_members":                           # > 1280 member k-mers per wave (k_count_fast.h SIFT_MS_CAP): the members beyond find their fingerprint by its tag
+        reads += [g] * 16
     reads.append(g[:k + 10] + rnd(1) + g[k + 11:2 * k + 30])
     got = assert_parity(oracle, hip, "\n".join(reads) + "\n", k, 2, log2_partitions=0)
-    assert got["stats"]["n_multipass_partitions"] == (0 if case == "sifted" else 1), got["stats"]
+    assert got["stats"]["n_multipass_partitions"] == (0 if case in ("sifted", "many_members") else 1), got["stats"]
 
 
 @pytest.mark.parametrize("k", [55, 127])

@@ -222,7 +222,7 @@ def test_count_tiers(oracle, sim, k, glen, mode, monkeypatch):
 
 
 @pytest.mark.parametrize("k", [64, 96, 127, 160])
-@pytest.mark.parametrize("case", ["sifted", "solid_overflow", "fingerprint_overflow"])
+@pytest.mark.parametrize("case", ["sifted", "solid_overflow", "fingerprint_overflow", "many_members"])
 def test_count_sift_tier(oracle, sim, k, case):
     """k-mers of three words and more under an abundance filter: ONE partition of mostly once-seen k-mers overflows the one-pass table and
     goes to the sifting tier (fingerprints first, exact counts for what was seen again: k_count_fast.h); too many k-mers seen
@@ -230,14 +230,16 @@ def test_count_sift_tier(oracle, sim, k, case):
     import random
     rng = random.Random(k * 7 + len(case))
     rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
-    solid_len = {"sifted": 250, "solid_overflow": 1500, "fingerprint_overflow": 250}[case] + k
-    noise = {"sifted": 26, "solid_overflow": 8, "fingerprint_overflow": 90}[case]
+    solid_len = {"sifted": 250, "solid_overflow": 1500, "fingerprint_overflow": 250, "many_members": 300}[case] + k
+    noise = {"sifted": 26, "solid_overflow": 8, "fingerprint_overflow": 90, "many_members": 55}[case]
     g = rnd(solid_len)
     reads = [g, g, g[5:], g[::-1].translate(str.maketrans("ACGT", "TGCA"))] + [rnd(k + 99) for _ in range(noise)]
+    if case == "many_members":                           # > 1280 member k-mers per wave (k_count_fast.h SIFT_MS_CAP): the members beyond find their fingerprint by its tag
+        reads += [g] * 16
     # a k-mer seen once inside an otherwise repeated read, and a once-seen k-mer whose reverse complement comes from another read
     reads.append(g[:k + 10] + rnd(1) + g[k + 11:2 * k + 30])
     got = assert_parity(oracle, sim, "\n".join(reads) + "\n", k, 2, log2_partitions=0)
-    assert got["stats"]["n_multipass_partitions"] == (0 if case == "sifted" else 1), got["stats"]
+    assert got["stats"]["n_multipass_partitions"] == (0 if case in ("sifted", "many_members") else 1), got["stats"]
 
 
 @pytest.mark.parametrize("k,amin,log_np,m", [(128, 1, 0, 0), (128, 2, 3, 0), (160, 1, 2, 12), (191, 2, 3, 16), (192, 1, 1, 0), (224, 1, 0, 0), (255, 1, 4, 16), (255, 2, 2, 0)])
@@ -413,11 +415,14 @@ def test_verify_on_goldens(sim, key):
 
 
 @pytest.mark.parametrize("k,amin,n_reads,cfg", [(31, 2, 3000, 3), (21, 1, 2500, 2), (55, 2, 1500, 4)])
-def test_streaming_scan_while_ingesting(oracle, sim, monkeypatch, k, amin, n_reads, cfg):
+@pytest.mark.parametrize("prewarm", [False, True])
+def test_streaming_scan_while_ingesting(oracle, sim, monkeypatch, k, amin, n_reads, cfg, prewarm):
     """cdbg_expect_input: the scan runs on the tiles that have landed while the rest is still being pushed (thresholds
     shrunk to simulator sizes); same result as the oracle, and tiles really were scanned early"""
     from bcalm_amd import api
     monkeypatch.setenv("CDBG_STAGE_BYTES", "16384"); monkeypatch.setenv("CDBG_STREAM_MIN_BYTES", "40000"); monkeypatch.setenv("CDBG_STREAM_BATCH_TILES", "4")
+    if prewarm:                                          # the background thread that obtains text buffer, record region and solid arrays (cdbg_expect_input on a large input)
+        monkeypatch.setenv("CDBG_PREWARM_MIN_BYTES", "1")
     text = oracle.synth_reads(n_reads, 150, cfg)
     exp = oracle.run(text, k, amin)
     reads = text.split(b"\n")
@@ -433,3 +438,12 @@ def test_streaming_scan_while_ingesting(oracle, sim, monkeypatch, k, amin, n_rea
     g.close()
     assert st["n_tiles_overlapped"] > 0
     assert st["n_distinct"] == exp["stats"]["distinct"] and canon == exp["unitigs"]
+
+
+def test_solid_capacity_second_attempt(oracle, sim, monkeypatch):
+    """the count stage sizes the solid arrays from a third of the bound first; an input that needs more makes the kernels report the
+    overflow (nothing is written out of bounds) and the stage runs once more with the bound: same result (CDBG_SOLID_FIRST_TINY forces it)"""
+    monkeypatch.setenv("CDBG_SOLID_FIRST_TINY", "1")
+    for k, amin, n, L, cfg in ((31, 1, 3000, 150, 3), (55, 1, 1500, 150, 4), (127, 1, 300, 500, 5)):
+        got = assert_parity(oracle, sim, oracle.synth_reads(n, L, cfg), k, amin)
+        assert got["stats"]["n_solid"] > (1 << 15)
