@@ -46,7 +46,11 @@ void scan_params_base(cdbg_ctx* c, ScanParams& sp) {
 }
 // capacity of a partition region from a sampled histogram (single-pass capped layout)
 void capped_capacities(const cdbg_ctx* c, double mean, uint64_t NPL, uint32_t& part_cap, uint64_t& spill_cap) {
-    part_cap = (uint32_t)(mean * 2.5 + 8.0 * std::sqrt(mean + 1.0) + 16.0);
+    // A partition's records are the sum over its minimizer loci (~ coverage records each): the spread is ~ 5.5 sqrt(mean), so
+    // mean + 20 sqrt(mean) is + 3.6 sigma -- a few hundred of config 3's 4 M partitions spill and are repaired.  Round 5: was
+    // 2.5 mean + 8 sqrt(mean) (75 GB at config 3, now 53 GB): the scan does not care (same-box A/B, CDBG_PART_CAP 1128 / 768 / 640:
+    // scan 67.4 / 65.3 / 69.1 ms), and fresh device memory costs the CLI 40 ms per GB (profiles/r05_micro_alloc.log).
+    part_cap = (uint32_t)(mean + 20.0 * std::sqrt(mean + 1.0) + 16.0);
     part_cap = (part_cap + 7u) & ~7u;
     if (const char* e = c->knobs.get("CDBG_PART_CAP")) part_cap = (uint32_t)std::max(1, atoi(e));   // test knob: force spills
     spill_cap = std::max<uint64_t>((uint64_t)(mean * (double)NPL / 32.0), 65536);
