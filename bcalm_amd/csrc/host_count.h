@@ -258,6 +258,7 @@ int count_impl(cdbg_ctx* c) {
     uint64_t n_spilled_parts = 0;                            // partitions whose region overflowed (capped mode): counted from gathered copies
     Timer t;
     uint64_t spill_cap = 0;
+    uint64_t sample_ns = 0, sample_stride = 0, sample_recs = 0;   // the capped path's sampled histogram, when it ran (still in part_count)
     if (c->ss_on) capped = true;                             // tiles [0, ss_done) were scanned while the input was arriving
     if (capped) {
         bool fits = true;
@@ -270,6 +271,7 @@ int count_impl(cdbg_ctx* c) {
             LAUNCH_SCAN(SCAN_HIST, ns);
             CK(exscan(c->part_count.p));
             uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPS, &sample_records));
+            sample_ns = ns; sample_stride = stride; sample_recs = sample_records;
             // the fullest partition of the sample: a skewed input (repeats, low complexity, coverage peaks) puts far more
             // into some partitions than any capacity covers; the capped pass would then hammer a few fill counters and spill
             // (145 ms at the hostile config-3 line before falling back) -- such inputs go straight to the exact two-pass layout
@@ -309,13 +311,18 @@ int count_impl(cdbg_ctx* c) {
             CK(read_u64(c->cursors.p + 6, &n_spill));
             uint32_t derr = 0; CK(read_u32(c->derr.p, &derr));
             c->ss_on = false;                                // (the streamed part is accounted for; a re-count scans everything)
-            if (derr == 6 || n_spill > spill_cap || (multi && n_spill)) {   // estimate was off (very skewed input): exact layout instead
+            if (derr == 6 || n_spill > spill_cap) {          // estimate was off (very skewed input): exact layout instead
                 capped = false; HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t))); HIPCK(hipMemset(c->cursors.p + 6, 0, sizeof(uint64_t)));
             } else if (multi) {
                 // what travels is the exact owner-major layout: squeeze the regions (part_off = exclusive scan of the fills)
                 CK(c->xrecs.alloc(std::max<uint64_t>(n_records, 1) * RW, false));
                 PackRegionParams pk{ c->records.p, c->part_count.p, c->part_off.p, NPS, part_cap, RW, c->xrecs.p };
                 CDBG_LAUNCH(k_pack_regions, std::min<uint64_t>((NPS + 3) / 4, 256 * 16), 256, s, pk);
+                if (n_spill) {                               // the few records that overflowed their region go behind it (round 5: a spill used to send the whole step through the exact two-pass layout)
+                    HIPCK(hipMemsetAsync(c->part_cursor.p, 0, NPS * sizeof(uint64_t), s));
+                    PackSpillParams ps{ c->spill_recs.p, c->spill_part.p, n_spill, c->part_off.p, c->part_cursor.p, part_cap, RW, c->xrecs.p };
+                    CDBG_LAUNCH(k_pack_spills, std::min<uint64_t>((n_spill + 255) / 256, 1u << 16), 256, s, ps);
+                }
                 c->records.swap(c->xrecs);
                 capped = false; packed_exact = true;
             } else if (n_spill) {
@@ -341,18 +348,27 @@ int count_impl(cdbg_ctx* c) {
             }
         }
     }
+    if (var && (c->nbytes >> 35)) var = false;               // (the packed region cursors count in 36 bits, k_scan.h var_word: larger texts take the exact layout)
     if (var && !capped && !packed_exact) {
         const float ms_sample1 = c->st.ms_scan_hist;
         CK(t.start(s));
-        HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
-        HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
-        const uint64_t stride = tiles >= 64 ? 4 : 1;         // a quarter of the tiles: +- 10 % on a partition of 400 records
+        // Round 5: the regions are sized from the FIRST sample (1 tile in 64, already in part_count) -- a partition heavy enough to matter
+        // has dozens of sampled records (+- 4 sigma is in the capacity), the light ones get the uniform capacity, and what is
+        // misjudged spills and is repaired.  Round 4 scanned a quarter of the tiles again for it: 17 ms at the hostile config-3 line.
+        // (CDBG_VAR_RESAMPLE = stride: that second sample, for A/B; CDBG_SCAN_MODE=var without a first sample: taken here)
+        uint64_t stride = sample_ns ? sample_stride : std::min<uint64_t>(64, std::max<uint64_t>(1, tiles / 4096));
+        bool resample = sample_ns == 0;
+        if (const char* e = c->knobs.get("CDBG_VAR_RESAMPLE")) { stride = std::max(1, atoi(e)); resample = true; }
         const uint64_t ns = (tiles + stride - 1) / stride;
-        sp.tile_stride = (uint32_t)stride; sp.tile_offset = 0; sp.part_cap = 0; sp.var_limit = nullptr;
-        LAUNCH_SCAN(SCAN_HIST, ns);
+        uint64_t sample_records = sample_recs;
+        if (resample) {
+            HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
+            HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
+            sp.tile_stride = (uint32_t)stride; sp.tile_offset = 0; sp.part_cap = 0; sp.var_limit = nullptr;
+            LAUNCH_SCAN(SCAN_HIST, ns);
+            CK(exscan(c->part_count.p)); CK(read_u64(c->part_off.p + NPS, &sample_records));
+        }
         CK(c->var_cap.alloc(NPS, false)); CK(c->var_pairs.alloc(2 * NPS, false));
-        uint64_t sample_records = 0;
-        CK(exscan(c->part_count.p)); CK(read_u64(c->part_off.p + NPS, &sample_records));
         const double scale = (double)tiles / (double)ns, mean = (double)sample_records * scale / (double)NPS;
         uint32_t cap_min = 0; capped_capacities(c, mean, NPS, cap_min, spill_cap);
         VarParams vp{ c->part_count.p, c->var_cap.p, NPS, (float)scale, cap_min, c->part_off.p, c->part_cursor.p, c->var_pairs.p, c->dstats.p + 30 };
@@ -373,8 +389,8 @@ int count_impl(cdbg_ctx* c) {
             HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
             HIPCK(hipMemsetAsync(c->cursors.p + 6, 0, sizeof(uint64_t), s));
             CK(t.start(s));
-            CDBG_LAUNCH(k_copy_u64, (NPS + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_cursor.p, NPS);
-            sp.tile_stride = 1; sp.records = c->records.p; sp.var_limit = c->part_off.p + 1;
+            CDBG_LAUNCH(k_var_init, (NPS + 255) / 256, 256, s, vp);          // packed cursor words: end of the region | room left
+            sp.tile_stride = 1; sp.tile_offset = 0; sp.part_cap = 0; sp.records = c->records.p; sp.var_limit = c->part_off.p + 1;   // (non-null: the flag)
             sp.spill_recs = c->spill_recs.p; sp.spill_part = c->spill_part.p; sp.spill_cursor = c->cursors.p + 6; sp.spill_cap = spill_cap;
             LAUNCH_SCAN(SCAN_EMIT, tiles);
             sp.var_limit = nullptr;

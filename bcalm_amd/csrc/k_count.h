@@ -34,6 +34,10 @@ constexpr uint32_t TRAV_FLAG = 0x80000000u;          // in a count word: this en
 // its increment back: the stored value never gets within 4096 in-flight increments of bit 31 (the traveller flag) and
 // ends at exactly min(count, COUNT_SAT) whatever the interleaving.
 constexpr uint32_t COUNT_MAX = 0x7FFFFFFFu, COUNT_SAT = COUNT_MAX - 4095u;
+#ifndef CDBG_COUNT_MAX_SUB
+#define CDBG_COUNT_MAX_SUB 1
+#endif
+constexpr uint32_t COUNT_MAX_SUB = CDBG_COUNT_MAX_SUB;  // multi-pass kernel: passes that divide a partition by its records' sub-partition (1: by k-mer hash only, as in round 4)
 constexpr uint32_t COUNT_FAST_MAX_RECORDS = 1u << 23;   // 255 members x (2^23 - 1) records < COUNT_SAT
 CDBG_DEV void count_add_sat(uint32_t* p) {
     const uint32_t old = atomic_add_u32(p, 1u);
@@ -233,6 +237,7 @@ struct RecView {
         return x;
     }
     CDBG_DEV int n() const { return (int)(r[0] & 0xFFu); }
+    CDBG_DEV uint32_t sub() const { return (uint32_t)(r[0] >> 12) & 15u; }   // sub-partition of the record's minimizer (sub_of, kmer.h)
     CDBG_DEV bool first_trav() const { return (r[0] >> 8) & 1u; }
     CDBG_DEV bool last_trav() const { return (r[0] >> 9) & 1u; }
     CDBG_DEV bool first_foreign() const { return (r[0] >> 10) & 1u; }
@@ -363,6 +368,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
             reserved = true;
         }
         bool overflow = false;
+        const uint32_t nsub = npass < COUNT_MAX_SUB ? npass : COUNT_MAX_SUB, nhash = npass / nsub;   // passes = sub-partitions x hash classes
         const int nphase = (npass == 1 || onephase) ? 1 : 2;
         for (int phase = 0; phase < nphase && !overflow; ++phase) {
             for (uint32_t pass = 0; pass < npass; ++pass) {
@@ -388,6 +394,11 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
 #pragma unroll
                         for (int i = 0; i < RW; ++i) R.r[i] = P.records[(b0 + lane) * RW + i];
                         n = R.n();
+                        // multi-pass: a pass takes the RECORDS of its sub-partition(s) -- all occurrences of a k-mer in this bucket
+                        // come with the same minimizer, hence the same sub-partition (record meta bits 12-15) -- so a member k-mer is
+                        // extracted in one pass only; beyond four sub-partitions (a single hot minimizer locus cannot be split this
+                        // way) the passes divide the k-mers of a sub-partition by their hash as before
+                        if (npass > 1 && (R.sub() & (nsub - 1u)) != (pass & (nsub - 1u))) n = 0;
                     }
                     int incl = n;                                  // inclusive prefix sum over the wave
 #pragma unroll
@@ -415,7 +426,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                             const Kmer<W> rc = fw.rc(k);
                             const bool rev = rc < fw;
                             const Kmer<W>& can = rev ? rc : fw;
-                            if (npass == 1 || ((can.hash() >> 20) & (npass - 1)) == pass) {
+                            if (nhash == 1 || ((can.hash() >> 20) & (nhash - 1)) == pass / nsub) {
                                 bool is_new;
                                 Kmer<W> ck = can;                     // (the key carries the foreign-junction flags: KEY_FOREIGN_*)
                                 ck.w[W - 1] |= key_flags(t == 0 && Q.first_foreign(), t == qn - 1 && Q.last_foreign(), rev);
@@ -704,21 +715,28 @@ __global__ void k_repair_scatter(RepairParams P) {       // one thread per spill
 //  partition's records for the count kernels (part_pairs), spilled partitions empty there (the repair launch counts them).
 struct VarParams {
     const uint32_t* sample; uint32_t* cap; uint64_t n; float scale; uint32_t cap_min;
-    const uint64_t* off; const uint64_t* cursor; uint64_t* pairs; uint64_t* stats;   // stats[0] += records offered
+    const uint64_t* off; uint64_t* cursor; uint64_t* pairs; uint64_t* stats;   // stats[0] += records offered
 };
 __global__ void k_var_caps(VarParams P) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P.n) return;
     const float s = (float)P.sample[p];
     const uint32_t c = (uint32_t)(P.scale * (s + 4.0f * sqrtf(s) + 2.0f)) + 8u;
-    P.cap[p] = ((c > P.cap_min ? c : P.cap_min) + 7u) & ~7u;
+    constexpr uint32_t U = (1u << VAR_UNIT_LOG) - 1u;        // whole units of 64 records (var_word, k_scan.h)
+    P.cap[p] = ((c > P.cap_min ? c : P.cap_min) + U) & ~U;
 }
-__global__ void k_var_finish(VarParams P) {
+__global__ void k_var_init(VarParams P) {                    // (before the scan) the packed cursor word of every region
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P.n) P.cursor[p] = var_word(P.off[p], P.off[p + 1]);
+}
+__global__ void k_var_finish(VarParams P) {                  // (after the scan) cursor[p] back to the plain 'begin + records offered'; begin / end pairs
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t n = 0;
     if (p < P.n) {
-        const uint64_t b = P.off[p], lim = P.off[p + 1], e = P.cursor[p];
-        n = e - b;
+        const uint64_t b = P.off[p], lim = P.off[p + 1];
+        n = (P.cursor[p] & VAR_L_MASK) - (VAR_L_ZERO - (lim - b));
+        const uint64_t e = b + n;
+        P.cursor[p] = e;
         P.pairs[2 * p] = b; P.pairs[2 * p + 1] = e > lim ? b : e;
     }
     n = wave_sum_u64(n);
@@ -732,10 +750,22 @@ __global__ void k_pack_regions(PackRegionParams P) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t sl = wave; sl < P.n_slots; sl += n_waves) {
-        const uint64_t n = (uint64_t)P.fill[sl] * P.RW;
+        const uint64_t n = (uint64_t)(P.fill[sl] < P.part_cap ? P.fill[sl] : P.part_cap) * P.RW;   // (fill counts the records OFFERED: the rest is on the spill list)
         const uint64_t* src = P.regions + sl * P.part_cap * P.RW;
         uint64_t* dst = P.out + P.off[sl] * P.RW;
         for (uint64_t i = lane; i < n; i += 64) dst[i] = src[i];
+    }
+}
+
+// the spilled records of overfull regions behind their region's records (off[] was scanned from the OFFERED counts, so the room is there);
+// fill_extra: zeroed per-slot counters
+struct PackSpillParams { const uint64_t* spill_recs; const uint32_t* spill_part; uint64_t n_spill; const uint64_t* off; uint64_t* fill_extra; uint32_t part_cap; int RW; uint64_t* out; };
+__global__ void k_pack_spills(PackSpillParams P) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < P.n_spill; o += stride) {
+        const uint64_t sl = P.spill_part[o];
+        const uint64_t dst = (P.off[sl] + P.part_cap + atomic_add_u64(&P.fill_extra[sl], 1ULL)) * P.RW;
+        for (int w = 0; w < P.RW; ++w) P.out[dst + w] = P.spill_recs[o * P.RW + w];
     }
 }
 

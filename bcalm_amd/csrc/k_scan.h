@@ -69,8 +69,18 @@ struct ScanParams {
     uint32_t part_cap; uint32_t* part_fill;
     uint64_t* spill_recs; uint32_t* spill_part; uint64_t* spill_cursor; uint64_t spill_cap; uint32_t* error;
     uint32_t emit_all, npl;      // multi-GPU with sharded reads: emit every partition, slot = owner * npl + local partition
-    const uint64_t* var_limit;   // SCAN_EMIT with estimated regions: end of partition p's region (records beyond it go to the spill list); nullptr = exact offsets
+    const uint64_t* var_limit;   // SCAN_EMIT with estimated regions (non-null: a flag since round 5): part_cursor[p] is a PACKED word (var_word, below) that
+                                 // carries the region's end and the room left, so that placing a record stays ONE atomic and no gather; nullptr = exact offsets
 };
+// Packed cursor of an estimated region (single-pass layout of skewed inputs).  Regions are whole units of 64 records; the word is
+//   [ end of the region in units : 28 bits | L : 36 bits ],  L = 2^35 - capacity + records offered so far.
+// One atomic add of 1 returns the old word: the record fits iff L < 2^35 and then goes to end * 64 - 2^35 + L; the records offered
+// beyond the capacity keep counting in L (the host takes this layout only for texts below 2^35 bytes: L cannot carry into the end
+// field -- a partition is offered fewer records than the text has bytes).  Round 4 read the region's end from a second array:
+// one more scattered 8-byte gather per record (1.6 G of them at config-3 size: scan 83 -> ~70 ms on the hostile line).
+constexpr int VAR_UNIT_LOG = 6, VAR_L_BITS = 36;
+constexpr uint64_t VAR_L_MASK = (1ULL << VAR_L_BITS) - 1ULL, VAR_L_ZERO = 1ULL << (VAR_L_BITS - 1);
+CDBG_DEV uint64_t var_word(uint64_t begin, uint64_t end) { return ((end >> VAR_UNIT_LOG) << VAR_L_BITS) | (VAR_L_ZERO - (end - begin)); }
 constexpr int SCAN_HIST = 0, SCAN_EMIT = 1, SCAN_EMIT_CAPPED = 2;
 
 CDBG_DEV uint64_t scan_get64(const uint32_t* pk, int bitoff) {
@@ -104,11 +114,24 @@ CDBG_DEV void scan_emit_record(const ScanParams& P, const uint32_t* pk, int bito
     if (MODE == SCAN_EMIT) {
         // exact layout (var_limit == nullptr: the histogram pass sized every region), or ESTIMATED regions of their own size per
         // partition (var_limit[p] = end of p's region, sized from a sampled histogram: the single-pass layout of skewed inputs)
-        const uint64_t pos = atomic_add_u64(&P.part_cursor[lpart], 1ULL);
-        fits = P.var_limit == nullptr || pos < P.var_limit[lpart];
+#ifdef CDBG_AB_EXACT32
+        uint64_t pos = (uint64_t)atomic_add_u32(reinterpret_cast<uint32_t*>(&P.part_cursor[lpart]), 1u);   // (A/B only: 32-bit atomic on the low half; totals below 2^32)
+#else
+        uint64_t pos = atomic_add_u64(&P.part_cursor[lpart], 1ULL);
+#endif
+        fits = true;
+        if (P.var_limit != nullptr) {                        // packed word: end of the region | room left (var_word)
+            const uint64_t L = pos & VAR_L_MASK;
+            fits = L < VAR_L_ZERO;
+            pos = ((pos >> VAR_L_BITS) << VAR_UNIT_LOG) - VAR_L_ZERO + L;
+        }
         dst = P.records + pos * RW;
     } else {
+#ifdef CDBG_AB_FILL64
+        const uint32_t j = (uint32_t)atomic_add_u64(&P.part_cursor[lpart], 1ULL);   // (A/B only: the scan's time with a 64-bit fill counter; the count stage then sees empty partitions)
+#else
         const uint32_t j = atomic_add_u32(&P.part_fill[lpart], 1u);
+#endif
         fits = j < P.part_cap;
         dst = P.records + ((uint64_t)lpart * P.part_cap + j) * RW;
     }
@@ -340,7 +363,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
             const int me = (ce == e && !last_incl) ? e - 1 : ce;
             const int n = me - ms + 1;
             if (n > 0) {
-                uint32_t meta = (uint32_t)n;
+                uint32_t meta = (uint32_t)n | (sub_of(gq, P.log_np) << 12);   // (bits 12-15: the minimizer's sub-partition, for the multi-pass count)
                 const bool ft = firstchunk && first_incl && first_trav;
                 const bool lt = (ce == e) && last_incl && last_trav;
                 if (ft) meta |= 0x100u;

@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : WN
             const int me = (ce == e && !last_incl) ? e - 1 : ce;
             const int n = me - ms + 1;
             if (n > 0) {
-                uint32_t meta = (uint32_t)n;
+                uint32_t meta = (uint32_t)n | (sub_of(g0, P.log_np) << 12);   // (bits 12-15: the minimizer's sub-partition, for the multi-pass count)
                 const bool ft = firstchunk && first_incl && first_trav;
                 const bool lt = (ce == e) && last_incl && last_trav;
                 if (ft) meta |= 0x100u;

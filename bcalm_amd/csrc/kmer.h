@@ -280,5 +280,10 @@ CDBG_HD void kmer_junction_mins(const Kmer<W>& x, int k, int m, uint32_t& g_left
 CDBG_HD uint32_t part_of(uint32_t g, int log_np) {
     return log_np ? (uint32_t)((g * 0x9E3779B1u) >> (32 - log_np)) : 0u;
 }
+// sub-partition of a minimizer key inside its partition: the four hash bits below the partition's (log_np <= 26).  It rides in bits
+// 12-15 of every record's meta word; the multi-pass count kernel (k_count.h) takes the records of one sub-partition per pass.
+CDBG_HD uint32_t sub_of(uint32_t g, int log_np) {
+    return (uint32_t)((g * 0x9E3779B1u) >> (28 - log_np)) & 15u;
+}
 
 }  // namespace cdbg

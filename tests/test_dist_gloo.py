@@ -27,10 +27,15 @@ def _run_sharded(api, cdist, lib, orc, text, k, amin, world, rank, steps=1, **kw
     scan_mode = kw.pop("scan_mode", None)                # CDBG_SCAN_MODE: the single-pass capped scan + region packing at test sizes
     kw.pop("expect_fallback", None)
     empty_rank = kw.pop("empty_rank", None)              # this rank receives no reads at all (a small input dealt out in chunks)
+    part_cap = kw.pop("part_cap", None)                  # CDBG_PART_CAP: regions far too small -- spilled records are packed behind their regions
     if scan_mode:
         os.environ["CDBG_SCAN_MODE"] = scan_mode
     else:
         os.environ.pop("CDBG_SCAN_MODE", None)
+    if part_cap:
+        os.environ["CDBG_PART_CAP"] = part_cap
+    else:
+        os.environ.pop("CDBG_PART_CAP", None)
     g = api.Graph(k, amin, lib=lib, world_size=world, rank=rank, **kw)
     cdist.TorchTransport(dist).attach(g)
     if kw.get("reads_replicated"):
@@ -131,6 +136,7 @@ def test_two_rank_gloo():
                 (31, 2, 200, 150, 3, {"emit_replicated": True}),
                 (31, 2, 250, 150, 3, {"all_abundance_counts": True}), (55, 1, 100, 150, 4, {"all_abundance_counts": True, "emit_replicated": True}),
                 (31, 2, 300, 150, 3, {"reads_replicated": True}), (31, 2, 300, 150, 3, {"scan_mode": "capped", "log2_partitions": 6}),
+                (31, 2, 300, 150, 3, {"scan_mode": "capped", "log2_partitions": 6, "part_cap": "3"}), (55, 2, 150, 150, 4, {"scan_mode": "capped", "part_cap": "1"}),
                 (55, 2, 200, 150, 4, {"scan_mode": "capped", "reads_replicated": True}), (31, 2, 200, 150, 3, {"empty_rank": 1}),
                 (30, 2, 250, 150, 3, {}), (64, 1, 100, 300, 5, {"log2_partitions": 4}),
                 # closed chains across ranks (example/circular_unitigs_unittests): a ranking round that finishes nothing -> the unfinished

@@ -159,6 +159,7 @@ def test_multi_gpu_path_single_rank_rccl(oracle, hip, monkeypatch):
     (2, 31, 2, 60000, 150, 3, {"all_abundance_counts": True}),
     (2, 31, 2, 200000, 150, 3, {"reads_replicated": True}), (4, 32, 2, 60000, 150, 4, {"reads_replicated": True}),
     (2, 31, 2, 300000, 150, 3, {"scan_mode": "capped"}), (4, 77, 2, 6000, 1000, 5, {"scan_mode": "capped"}),
+    (2, 31, 2, 300000, 150, 3, {"scan_mode": "capped", "part_cap": "12"}), (4, 55, 2, 60000, 150, 4, {"scan_mode": "capped", "part_cap": "2"}),
     (2, 31, 1, 40, 5000, "circular", {}), (4, 55, 1, 25, 3000, "circular", {})])
 def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, read_len, cfg, kw, monkeypatch):
     """the complete N-rank data path on the real device: N contexts on GPU 0 driven by N host threads, reads sharded,
@@ -170,6 +171,8 @@ def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, rea
     kw = dict(kw)
     if kw.pop("scan_mode", None):                # sharded reads through the single-pass capped scan + region packing
         monkeypatch.setenv("CDBG_SCAN_MODE", "capped")
+    if kw.get("part_cap"):                       # regions far too small: the spilled records are packed behind their regions (k_pack_spills)
+        monkeypatch.setenv("CDBG_PART_CAP", kw.pop("part_cap"))
     if cfg == "circular":
         # isolated circular unitigs (plasmids) among the ranks: closed chains, cut in place by the sharded glue (k_dglue.h)
         rng = random.Random(n_reads + read_len)
