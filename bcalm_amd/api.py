@@ -39,12 +39,12 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-ABI_VERSION = 5                                        # include/cdbg.h CDBG_ABI_VERSION this binding was written for
+ABI_VERSION = 6                                        # include/cdbg.h CDBG_ABI_VERSION this binding was written for
 EXPORTS = ["cdbg_abi_version", "cdbg_stats_sizeof", "cdbg_create", "cdbg_destroy", "cdbg_release_cached", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
            "cdbg_generate_reads", "cdbg_expect_input", "cdbg_stage_acquire", "cdbg_stage_commit", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
            "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats", "cdbg_digest", "cdbg_verify",
            "cdbg_verify_edges", "cdbg_verify_unitigs",
-           "cdbg_fetch_unitigs_packed", "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", 
+           "cdbg_fetch_unitigs_packed", "cdbg_fetch_unitig_abundances", "cdbg_link", "cdbg_num_links", "cdbg_fetch_links", "cdbg_unitig_id_base",
            "cdbg_set_transport", "cdbg_comm_unique_id", "cdbg_comm_init_rccl", "cdbg_comm_bytes"]
 
 
@@ -106,6 +106,7 @@ def load(path: str | None = None) -> C.CDLL:
     lib.cdbg_link.argtypes = [vp]
     lib.cdbg_num_links.argtypes = [vp, C.POINTER(u64)]
     lib.cdbg_fetch_links.argtypes = [vp, C.POINTER(u64), C.POINTER(C.c_uint32)]
+    lib.cdbg_unitig_id_base.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     lib.cdbg_set_transport.argtypes = [vp, vp]
     lib.cdbg_comm_unique_id.argtypes = [vp]
     lib.cdbg_comm_init_rccl.argtypes = [vp, C.c_char_p]
@@ -233,8 +234,15 @@ class Graph:
         self._ck(self.lib.cdbg_fetch_unitig_abundances(self._h, 0, n, ab, off))
         return [list(ab[off[i]:off[i + 1]]) for i in range(n)]
 
+    def unitig_id_base(self):
+        """-> (first job-wide unitig id of this rank's share, unitigs of the whole job); after links() / cdbg_link"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.cdbg_unitig_id_base(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def links(self):
-        """-> per unitig (same order as unitigs()) a list of (from_sign, target_unitig, to_sign)"""
+        """-> per unitig (same order as unitigs()) a list of (from_sign, target_unitig, to_sign); a sharded set (several ranks,
+        emit_replicated = 0): collective, and target_unitig is a job-wide id (unitig_id_base() + the position in the owner's unitigs())"""
         self._ck(self.lib.cdbg_link(self._h))
         n, tb = C.c_uint64(), C.c_uint64()
         self._ck(self.lib.cdbg_num_unitigs(self._h, C.byref(n), C.byref(tb)))

@@ -236,6 +236,11 @@ int cdbg_num_links(cdbg_ctx* c, uint64_t* n) {
     if (!c->linked) return fail(CDBG_E_STATE, "cdbg_num_links before cdbg_link");
     *n = c->n_links; return CDBG_OK;
 }
+int cdbg_unitig_id_base(cdbg_ctx* c, uint64_t* first_id, uint64_t* total) {
+    if (!c || !first_id) return fail(CDBG_E_PARAM, "null argument");
+    if (!c->linked) return fail(CDBG_E_STATE, "cdbg_unitig_id_base before cdbg_link");
+    *first_id = c->unitig_id_base; if (total) *total = c->unitig_id_total; return CDBG_OK;
+}
 int cdbg_fetch_links(cdbg_ctx* c, uint64_t* end_off, uint32_t* link_to) {
     if (!c || !end_off) return fail(CDBG_E_PARAM, "null argument");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)

@@ -329,7 +329,7 @@ int count_impl(cdbg_ctx* c) {
                 // repair: gather region + spilled records of each spilled partition into one contiguous run (k_count.h)
                 RepairParams rp{};
                 rp.records = c->records.p; rp.spill_recs = c->spill_recs.p; rp.spill_part = c->spill_part.p; rp.n_spill = n_spill;
-                rp.part_fill = c->part_count.p; rp.npl = NPL; rp.part_cap = part_cap; rp.RW = RW;
+                rp.part_fill = c->part_count.p; rp.npl = NPL; rp.part_cap = part_cap; rp.RW = RW; rp.ovf = nullptr;
                 CK(c->rp_flag.alloc(NPL, false)); CK(c->rp_idx.alloc(NPL + 1, false));
                 rp.flag = c->rp_flag.p; rp.ridx = c->rp_idx.p;
                 CDBG_LAUNCH(k_repair_flag, (NPL + 255) / 256, 256, s, rp);
@@ -348,14 +348,15 @@ int count_impl(cdbg_ctx* c) {
             }
         }
     }
-    if (var && (c->nbytes >> 35)) var = false;               // (the packed region cursors count in 36 bits, k_scan.h var_word: larger texts take the exact layout)
     if (var && !capped && !packed_exact) {
+        // Skewed input, ONE pass: the capped layout (uniform regions, 32-bit fill counters: two memory requests per record) plus an overflow
+        // region for every partition the sample finds heavy (k_count.h, k_ovf_*).  Round 5: sized from the FIRST sample (1 tile in 64, still
+        // in part_count) -- a partition heavy enough to matter has dozens of sampled records (+ 4 sigma is in its capacity), the light ones keep
+        // the uniform capacity, and what is misjudged spills and is repaired.  Round 4 scanned a quarter of the tiles again for it (17 ms at
+        // the hostile config-3 line) and gave EVERY partition a region of its own, whose bounds every record looked up (scan 86 ms for 66).
+        // (CDBG_VAR_RESAMPLE = stride: a second sample of that density, for A/B; CDBG_SCAN_MODE=var without a first sample: taken here)
         const float ms_sample1 = c->st.ms_scan_hist;
         CK(t.start(s));
-        // Round 5: the regions are sized from the FIRST sample (1 tile in 64, already in part_count) -- a partition heavy enough to matter
-        // has dozens of sampled records (+- 4 sigma is in the capacity), the light ones get the uniform capacity, and what is
-        // misjudged spills and is repaired.  Round 4 scanned a quarter of the tiles again for it: 17 ms at the hostile config-3 line.
-        // (CDBG_VAR_RESAMPLE = stride: that second sample, for A/B; CDBG_SCAN_MODE=var without a first sample: taken here)
         uint64_t stride = sample_ns ? sample_stride : std::min<uint64_t>(64, std::max<uint64_t>(1, tiles / 4096));
         bool resample = sample_ns == 0;
         if (const char* e = c->knobs.get("CDBG_VAR_RESAMPLE")) { stride = std::max(1, atoi(e)); resample = true; }
@@ -364,40 +365,43 @@ int count_impl(cdbg_ctx* c) {
         if (resample) {
             HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
             HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
-            sp.tile_stride = (uint32_t)stride; sp.tile_offset = 0; sp.part_cap = 0; sp.var_limit = nullptr;
+            sp.tile_stride = (uint32_t)stride; sp.tile_offset = 0; sp.part_cap = 0; sp.var_limit = nullptr; sp.ovf = nullptr;
             LAUNCH_SCAN(SCAN_HIST, ns);
             CK(exscan(c->part_count.p)); CK(read_u64(c->part_off.p + NPS, &sample_records));
         }
-        CK(c->var_cap.alloc(NPS, false)); CK(c->var_pairs.alloc(2 * NPS, false));
+        CK(c->var_cap.alloc(NPS, false)); CK(c->var_pairs.alloc(2 * NPS, false)); CK(c->ovf_words.alloc(NPS, false));
         const double scale = (double)tiles / (double)ns, mean = (double)sample_records * scale / (double)NPS;
-        uint32_t cap_min = 0; capped_capacities(c, mean, NPS, cap_min, spill_cap);
-        VarParams vp{ c->part_count.p, c->var_cap.p, NPS, (float)scale, cap_min, c->part_off.p, c->part_cursor.p, c->var_pairs.p, c->dstats.p + 30 };
-        if (const char* e = c->knobs.get("CDBG_VAR_SCALE")) vp.scale = (float)atof(e);   // test knob (with CDBG_PART_CAP): regions far too small, so that partitions spill
-        CDBG_LAUNCH(k_var_caps, (NPS + 255) / 256, 256, s, vp);
+        capped_capacities(c, mean, NPS, part_cap, spill_cap);
+        OvfParams op{ c->part_count.p, c->var_cap.p, NPS, (float)scale, part_cap, c->part_off.p, NPS * (uint64_t)part_cap, c->ovf_words.p,
+                      c->part_count.p, nullptr, RW, c->var_pairs.p, c->dstats.p + 28 };
+        if (const char* e = c->knobs.get("CDBG_VAR_SCALE")) op.scale = (float)atof(e);   // test knob (with CDBG_PART_CAP): overflow regions far too small, so that partitions spill
+        CDBG_LAUNCH(k_ovf_caps, (NPS + 255) / 256, 256, s, op);
         CK(exscan_u32(c, c->var_cap.p, c->part_off.p, NPS));
-        uint64_t total_cap = 0; CK(read_u64(c->part_off.p + NPS, &total_cap));
+        uint64_t ovf_total = 0; CK(read_u64(c->part_off.p + NPS, &ovf_total));
+        const uint64_t total_cap = NPS * (uint64_t)part_cap + ovf_total;
         float ms2 = 0; CK(t.stop(&ms2)); c->st.ms_scan_hist = ms_sample1 + ms2;
-        // does the region fit?  What the card has free, plus what this context (the region of the step before) and the process's
-        // pool would hand back, less a reserve for the stages that follow; an allocation that fails all the same falls back to
-        // the exact layout as well (no hard-coded card size)
+        // does it fit?  What the card has free, plus what this context (the region of the step before) and the process's pool would hand
+        // back, less a reserve for the stages that follow; an allocation that fails all the same falls back to the exact layout as well
         if ((double)total_cap * RW * 8.0 > region_budget()) var = false;           // would not fit: the exact layout
         else if (c->records.alloc(total_cap * RW, false) != CDBG_OK) var = false;
         if (var) {
             c->ss_on = false;                                // (as on the capped path: a re-count scans everything)
             spill_cap = std::max<uint64_t>(total_cap / 32, 65536);
             CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
+            CK(t.start(s));
+            CDBG_LAUNCH(k_ovf_words, (NPS + 255) / 256, 256, s, op);
+            HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));      // the sample is spent: fill counters
             HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
             HIPCK(hipMemsetAsync(c->cursors.p + 6, 0, sizeof(uint64_t), s));
-            CK(t.start(s));
-            CDBG_LAUNCH(k_var_init, (NPS + 255) / 256, 256, s, vp);          // packed cursor words: end of the region | room left
-            sp.tile_stride = 1; sp.tile_offset = 0; sp.part_cap = 0; sp.records = c->records.p; sp.var_limit = c->part_off.p + 1;   // (non-null: the flag)
+            sp.tile_stride = 1; sp.tile_offset = 0; sp.records = c->records.p; sp.part_cap = part_cap; sp.part_fill = c->part_count.p; sp.ovf = c->ovf_words.p;
             sp.spill_recs = c->spill_recs.p; sp.spill_part = c->spill_part.p; sp.spill_cursor = c->cursors.p + 6; sp.spill_cap = spill_cap;
-            LAUNCH_SCAN(SCAN_EMIT, tiles);
-            sp.var_limit = nullptr;
-            CDBG_LAUNCH(k_var_finish, (NPS + 255) / 256, 256, s, vp);
+            LAUNCH_SCAN(SCAN_EMIT_CAPPED, tiles);
+            sp.ovf = nullptr;
+            op.records = c->records.p;
+            CDBG_LAUNCH(k_ovf_finish, std::min<uint64_t>((NPS + 3) / 4, 256 * 16), 256, s, op);
             CK(t.stop(&c->st.ms_scan_emit));
-            hm.mark("count: samples + single-pass scan into estimated regions");
-            CK(read_u64(c->dstats.p + 30, &n_records));
+            hm.mark("count: sample + single-pass scan into capped regions with overflow regions");
+            CK(read_u64(c->dstats.p + 28, &n_records));
             CK(read_u64(c->dstats.p, hs, 2));
             CK(read_u64(c->cursors.p + 6, &n_spill));
             uint32_t derr = 0; CK(read_u32(c->derr.p, &derr));
@@ -406,7 +410,7 @@ int count_impl(cdbg_ctx* c) {
             } else if (n_spill) {
                 RepairParams rp{};
                 rp.records = c->records.p; rp.spill_recs = c->spill_recs.p; rp.spill_part = c->spill_part.p; rp.n_spill = n_spill;
-                rp.part_fill = nullptr; rp.npl = NPL; rp.part_cap = 0; rp.RW = RW; rp.var_off = c->part_off.p; rp.var_cursor = c->part_cursor.p;
+                rp.part_fill = c->part_count.p; rp.npl = NPL; rp.part_cap = part_cap; rp.RW = RW; rp.ovf = c->ovf_words.p;
                 CK(c->rp_flag.alloc(NPL, false)); CK(c->rp_idx.alloc(NPL + 1, false));
                 rp.flag = c->rp_flag.p; rp.ridx = c->rp_idx.p;
                 CDBG_LAUNCH(k_repair_flag, (NPL + 255) / 256, 256, s, rp);
@@ -439,9 +443,14 @@ int count_impl(cdbg_ctx* c) {
         // pass 2: emit records at exact offsets
         CK(c->records.alloc(std::max<uint64_t>(n_records, 1) * RW, false));
         CK(t.start(s));
-        CDBG_LAUNCH(k_copy_u64, (NPS + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_cursor.p, NPS);
-        sp.records = c->records.p;
+        // the histogram is spent (part_off holds its scan): its words become the running indices, and end at the same counts.  Fewer than
+        // 2^32 records: pre-loaded with the offsets, so that a record costs one atomic and one store (k_scan.h)
+        const bool cur32 = n_records < (1ull << 32) && c->knobs.get("CDBG_EXACT_NO_CUR32") == nullptr;
+        if (cur32) CDBG_LAUNCH(k_cursor32_load, (NPS + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_count.p, NPS);
+        else HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
+        sp.records = c->records.p; sp.part_fill = c->part_count.p; sp.part_off = cur32 ? nullptr : c->part_off.p; sp.var_limit = nullptr;
         LAUNCH_SCAN(SCAN_EMIT, tiles);
+        if (cur32) CDBG_LAUNCH(k_cursor32_counts, (NPS + 255) / 256, 256, s, (const uint64_t*)c->part_off.p, c->part_count.p, NPS);
         CK(t.stop(&c->st.ms_scan_emit));
     }
     if (multi) {

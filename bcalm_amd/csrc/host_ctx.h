@@ -254,7 +254,7 @@ struct cdbg_ctx {
     DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
     DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;   // (fallback junction table)
     DBuf<uint32_t> retry_list2;                              // partitions that did not fit the second count tier either
-    DBuf<uint32_t> var_cap; DBuf<uint64_t> var_pairs;        // single-pass layout of skewed inputs: region capacities, begin / end of every partition's records
+    DBuf<uint32_t> var_cap; DBuf<uint64_t> var_pairs, ovf_words;        // single-pass layout of skewed inputs: region capacities, begin / end of every partition's records
     DBuf<uint64_t> split_keys, vseg_off, split_cur; DBuf<uint32_t> split_cnt, vseg_n, vlist_a, vlist_b;   // second-level bucket split (k_split.h)
     DBuf<uint64_t> repair_recs, repair_off, rp_idx; DBuf<uint32_t> repair_part, rp_flag, rp_size, rp_fill;   // capped-scan spill repair (kept: no allocation per step)
     DBuf<uint32_t> jfill; DBuf<uint64_t> jrecs;              // join buckets
@@ -278,6 +278,7 @@ struct cdbg_ctx {
     uint64_t n_unitigs = 0, unitig_total = 0;
     DBuf<uint32_t> piece_ab, unitig_ab;          // -all-abundance-counts
     DBuf<uint64_t> link_off; DBuf<uint32_t> link_to; uint64_t n_links = 0; bool linked = false;
+    uint64_t unitig_id_base = 0, unitig_id_total = 0;       // job-wide unitig ids of a sharded set (cdbg_link): this rank's first id, the job's unitigs
     DBuf<uint4> rank_a, rank_b; DBuf<uint32_t> rank_flag;
     DBuf<uint4> walk_rec; DBuf<uint32_t> walk_heads, walk_hlen; DBuf<uint64_t> walk_hoff; bool walk_off = false;   // chains walked from their heads (k_walk.h); walk_off: a run of this context had a chain the walk does not take
     // multi-GPU: transport (RCCL or caller-supplied) and the record exchange buffers

@@ -287,11 +287,78 @@ int links_build(cdbg_ctx* c, const UnitigView& v, DBuf<uint64_t>& link_off, DBuf
     return CDBG_OK;
 }
 UnitigView resident_unitigs(cdbg_ctx* c) { return UnitigView{ c->n_unitigs, c->unitig_off.p, c->unitig_len.p, c->unitig_bases.p, c->unitig_total }; }
+inline bool holds_a_share(const cdbg_ctx* c) { return (c->prm.world_size > 1 || c->force_multi) && !c->prm.emit_replicated; }   // this rank holds a share of the job's unitigs
+
+// The link table of a unitig set that is SHARDED over the ranks (k_links.h): collective.  Unitig ids are numbered rank after rank
+// (c->unitig_id_base = the unitigs of the ranks before this one); link_off covers this rank's ends, link_to holds job-wide end ids.
+template <int W>
+int links_build_sharded(cdbg_ctx* c) {
+    hipStream_t s = c->stream;
+    const int world = c->prm.world_size, me = c->prm.rank;
+    if (!c->have_tr) return fail(CDBG_E_STATE, "cdbg_link on a sharded unitig set needs the transport");
+    const uint64_t U = c->n_unitigs, NE = 2 * U;
+    std::vector<uint64_t> all(world); const uint64_t mine = U;
+    if (c->tr.all_gather_u64(c->tr.user, &mine, all.data(), 1) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_u64 failed");
+    uint64_t tot = 0, base = 0; for (int r = 0; r < world; ++r) { if (r == me) base = tot; tot += all[r]; }
+    c->unitig_id_base = base; c->unitig_id_total = tot;
+    const uint64_t NA = 2 * tot;
+    int rc = CDBG_OK;
+    DBuf<uint64_t> lk_keys, end_keys, all_keys; DBuf<uint32_t> lk_cnt, lk_ends, end_slot, deg, end_meta, all_meta;
+    uint32_t cap = 0;
+    auto local = [&]() -> int {                              // (a rank-local failure must not leave the others in the collective: agreed on below)
+        if (NA >= (1ull << 31) || pow2_at_least(2 * NA + 64) > (1ull << 30)) return fail(CDBG_E_INTERNAL, "too many unitigs (%llu) for the 30-bit slots of the link table", (unsigned long long)tot);
+        cap = (uint32_t)pow2_at_least(2 * NA + 64);
+        CK(end_keys.alloc(NE * W + 1, false)); CK(end_meta.alloc(NE + 1, false)); CK(all_keys.alloc(NA * W + 1, false)); CK(all_meta.alloc(NA + 1, false));
+        CK(lk_keys.alloc((uint64_t)cap * W, false)); CK(lk_cnt.alloc((uint64_t)cap * 2, true));
+        CK(lk_ends.alloc((uint64_t)cap * 2 * LINK_PER_FLAG, false)); CK(end_slot.alloc(NA + 1, false)); CK(deg.alloc(NE + 1, false));
+        HIPCK(hipMemsetAsync(lk_keys.p, 0xFF, (uint64_t)cap * W * sizeof(uint64_t), s));
+        CK(c->link_off.alloc(NE + 1, true));
+        return CDBG_OK;
+    };
+    rc = local();
+    CK(agree(c, rc, "links: buffers"));
+    LinkParams lp{};
+    lp.n_unitigs = U; lp.k = c->k; lp.unitig_off = c->unitig_off.p; lp.unitig_len = c->unitig_len.p; lp.bases = c->unitig_bases.p;
+    lp.lk_keys = lk_keys.p; lp.lk_cnt = lk_cnt.p; lp.lk_ends = lk_ends.p; lp.lk_mask = cap - 1;
+    lp.end_slot = end_slot.p; lp.deg = deg.p; lp.end_keys = end_keys.p; lp.end_meta = end_meta.p;
+    lp.all_keys = all_keys.p; lp.all_meta = all_meta.p; lp.n_all_ends = NA; lp.e0 = 2 * base;
+    const uint64_t grid = (NE + LINK_THREADS - 1) / LINK_THREADS;
+    if (NE) CDBG_LAUNCH((k_link_describe<W>), grid, LINK_THREADS, s, lp);
+    std::vector<uint64_t> roff(world), rcnt(world);
+    { uint64_t o = 0; for (int r = 0; r < world; ++r) { roff[r] = o * 2 * W * 8; rcnt[r] = all[r] * 2 * W * 8; o += all[r]; } }
+    if (!c->tr_ordered) HIPCK(hipStreamSynchronize(s));
+    if (c->tr.all_gather_v(c->tr.user, end_keys.p, NE * W * 8, all_keys.p, roff.data(), rcnt.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_v failed");
+    { uint64_t o = 0; for (int r = 0; r < world; ++r) { roff[r] = o * 2 * 4; rcnt[r] = all[r] * 2 * 4; o += all[r]; if (r != me) c->comm_bytes += (NE + 2 * all[r]) * (uint64_t)(W * 8 + 4); } }   // (sent to / received from every other rank)
+    if (c->tr.all_gather_v(c->tr.user, end_meta.p, NE * 4, all_meta.p, roff.data(), rcnt.data()) != 0) return fail(CDBG_E_INTERNAL, "transport all_gather_v failed");
+    c->n_links = 0;
+    auto join = [&]() -> int {
+        if (NA) CDBG_LAUNCH((k_link_insert_described<W>), (NA + LINK_THREADS - 1) / LINK_THREADS, LINK_THREADS, s, lp);
+        if (NE) {
+            CDBG_LAUNCH(k_link_count, grid, LINK_THREADS, s, lp);
+            const uint64_t nb = (NE + EXSCAN_BLOCK - 1) / EXSCAN_BLOCK;
+            CK(c->exscan_tmp.alloc(nb + 1, false));
+            const uint32_t* degp = deg.p; uint64_t* const loff = c->link_off.p;
+            CDBG_LAUNCH(k_exscan_sums, nb, EXSCAN_THREADS, s, degp, c->exscan_tmp.p, NE);
+            CDBG_LAUNCH(k_exscan_top, 1, EXSCAN_THREADS, s, c->exscan_tmp.p, nb, loff + NE);
+            CDBG_LAUNCH(k_exscan_apply, nb, EXSCAN_THREADS, s, degp, (const uint64_t*)c->exscan_tmp.p, loff, NE);
+            CK(read_u64(loff + NE, &c->n_links));
+            CK(c->link_to.alloc(c->n_links, false));
+            lp.link_off = c->link_off.p; lp.link_to = c->link_to.p;
+            CDBG_LAUNCH(k_link_fill, grid, LINK_THREADS, s, lp);
+        }
+        HIPCK(hipStreamSynchronize(s));
+        return CDBG_OK;
+    };
+    rc = join();
+    CK(agree(c, rc, "links: join"));
+    return CDBG_OK;
+}
 
 template <int W>
 int link_impl(cdbg_ctx* c) {
     if (c->stage < 3) return fail(CDBG_E_STATE, "cdbg_link before cdbg_glue");
-    CK(links_build<W>(c, resident_unitigs(c), c->link_off, c->link_to, c->n_links));
+    if (holds_a_share(c)) CK(links_build_sharded<W>(c));
+    else { CK(links_build<W>(c, resident_unitigs(c), c->link_off, c->link_to, c->n_links)); c->unitig_id_base = 0; c->unitig_id_total = c->n_unitigs; }
     c->linked = true;
     return CDBG_OK;
 }
@@ -331,7 +398,6 @@ int verify_edges_view(cdbg_ctx* c, const UnitigView& v, uint64_t n_links, uint64
     out[0] = r[0]; out[1] = n_links; out[2] = 2 * (v.total_bases - v.U * (uint64_t)c->k); out[3] = r[1];
     return CDBG_OK;
 }
-inline bool holds_a_share(const cdbg_ctx* c) { return (c->prm.world_size > 1 || c->force_multi) && !c->prm.emit_replicated; }   // this rank holds a share of the unitigs: no links
 
 // the unitig definition checked on the resident result (k_verify.h)
 template <int W>

@@ -671,76 +671,99 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(GLOBAL ? 1024 : (size_t
 struct RepairParams {
     const uint64_t* records; const uint64_t* spill_recs; const uint32_t* spill_part; uint64_t n_spill;
     const uint32_t* part_fill; uint64_t npl; uint32_t part_cap; int RW;
-    const uint64_t* var_off; const uint64_t* var_cursor;   // != null: regions of their own size -- partition p owns records [var_off[p], var_off[p + 1]), var_cursor[p] - var_off[p] were offered
+    const uint64_t* ovf;         // != null (skewed inputs): overflow-region words of the partitions (k_scan.h ScanParams::ovf); a partition with one holds
+                                 // part_cap records in its uniform region and the rest of its capacity in slots [part_cap, capacity) of the overflow region
     uint32_t* flag;              // [npl]  1 = spilled
     const uint64_t* ridx;        // [npl + 1] exclusive scan of flag: list index of a spilled partition
     uint32_t* item_part;         // [nsp]  spilled partitions, ascending
     uint32_t* item_size;         // [nsp]  records of the gathered run (= fill)
     const uint64_t* item_off;    // [nsp + 1] exclusive scan of item_size
     uint32_t* item_fill;         // [nsp]  spilled records placed so far (zeroed)
-    uint64_t* out;
+    uint64_t* out;               // gathered runs
 };
+CDBG_DEV uint64_t repair_capacity(const RepairParams& P, uint64_t p) {       // records of partition p that did NOT go to the spill list, at most
+    const uint64_t t = P.ovf ? (P.ovf[p] & OVF_CAP_MASK) : 0ULL;
+    return t ? t : (uint64_t)P.part_cap;
+}
 __global__ void k_repair_flag(RepairParams P) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < P.npl) P.flag[p] = P.var_off ? (P.var_cursor[p] > P.var_off[p + 1] ? 1u : 0u) : (P.part_fill[p] > P.part_cap ? 1u : 0u);
+    if (p < P.npl) P.flag[p] = (uint64_t)P.part_fill[p] > repair_capacity(P, p) ? 1u : 0u;
 }
 __global__ void k_repair_list(RepairParams P) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P.npl || !P.flag[p]) return;
     const uint64_t i = P.ridx[p];
-    P.item_part[i] = (uint32_t)p; P.item_size[i] = P.var_off ? (uint32_t)(P.var_cursor[p] - P.var_off[p]) : P.part_fill[p];
+    P.item_part[i] = (uint32_t)p; P.item_size[i] = P.part_fill[p];
 }
-__global__ void k_repair_gather(RepairParams P) {        // one workgroup per spilled partition: its region
+__global__ void k_repair_gather(RepairParams P) {        // one workgroup per spilled partition: its region(s)
     const uint32_t it = blockIdx.x;
     const uint64_t o0 = P.item_off[it] * P.RW, p = P.item_part[it];
-    const uint64_t nreg = (P.var_off ? P.var_off[p + 1] - P.var_off[p] : (uint64_t)P.part_cap) * P.RW;
-    const uint64_t src = P.var_off ? P.var_off[p] * P.RW : p * nreg;
+    const uint64_t nreg = (uint64_t)P.part_cap * P.RW;
+    const uint64_t src = p * nreg;
     for (uint64_t i = threadIdx.x; i < nreg; i += blockDim.x) P.out[o0 + i] = P.records[src + i];
+    const uint64_t cap = repair_capacity(P, p);
+    if (cap > P.part_cap) {                              // the slots [part_cap, capacity) of its overflow region
+        const uint64_t hb = (P.ovf[p] >> OVF_CAP_BITS) * P.RW, n2 = cap * P.RW;
+        for (uint64_t i = nreg + threadIdx.x; i < n2; i += blockDim.x) P.out[o0 + i] = P.records[hb + i];
+    }
 }
 __global__ void k_repair_scatter(RepairParams P) {       // one thread per spilled record
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; o < P.n_spill; o += stride) {
         const uint64_t sp = P.spill_part[o], it = P.ridx[sp];
-        const uint64_t cap = P.var_off ? P.var_off[sp + 1] - P.var_off[sp] : (uint64_t)P.part_cap;
-        const uint64_t dst = (P.item_off[it] + cap + atomic_add_u32(&P.item_fill[it], 1u)) * P.RW;
+        const uint64_t dst = (P.item_off[it] + repair_capacity(P, sp) + atomic_add_u32(&P.item_fill[it], 1u)) * P.RW;
         for (int w = 0; w < P.RW; ++w) P.out[dst + w] = P.spill_recs[o * P.RW + w];
     }
 }
 
 
-// ---- single-pass record layout for SKEWED inputs: a region of its own size per partition, estimated from a sampled histogram ----
-// (the uniform capacity of the capped layout cannot hold a coverage peak or a repeat; the exact layout costs a second pass over
-//  the reads: 64 ms of histogram at the hostile config-3 line).  k_var_caps: sampled count s -> capacity scale * (s + 4 sqrt(s) + 2),
-//  at least cap_min; the host scans the capacities into region offsets.  k_var_finish (after the scan): begin / end of every
-//  partition's records for the count kernels (part_pairs), spilled partitions empty there (the repair launch counts them).
-struct VarParams {
-    const uint32_t* sample; uint32_t* cap; uint64_t n; float scale; uint32_t cap_min;
-    const uint64_t* off; uint64_t* cursor; uint64_t* pairs; uint64_t* stats;   // stats[0] += records offered
+// ---- single-pass record layout for SKEWED inputs: the capped layout plus an OVERFLOW REGION for every partition the sample finds heavy ----
+// (the uniform capacity of the capped layout cannot hold a coverage peak or a repeat; the exact layout costs a second pass over the
+//  reads: 60 ms of histogram at config-3 size.  Round 4 gave every partition a region of its own estimated size -- begin and end looked
+//  up per record: the scan pays per memory request of a record, 86 instead of 66 ms.  Now only the records BEYOND the uniform capacity
+//  pay the look-up.)  k_ovf_caps: sampled count s -> total capacity scale * (s + 4 sqrt(s) + 2) of a heavy partition, 0 for the others;
+//  the host scans the capacities into offsets behind the uniform regions; k_ovf_words builds the words the scan reads; k_ovf_finish
+//  (after the scan) moves the uniform region's records of an overflowed partition to the front of its overflow region -- the partition
+//  is one run again -- and writes begin / end of every partition's records for the count kernels (part_pairs; spilled: empty, the
+//  repair launch counts them).
+struct OvfParams {
+    const uint32_t* sample; uint32_t* tcap; uint64_t n; float scale; uint32_t part_cap;
+    const uint64_t* toff; uint64_t area0; uint64_t* words;
+    const uint32_t* fill; uint64_t* records; int RW; uint64_t* pairs; uint64_t* stats;   // stats[0] += records offered, stats[1] += partitions that used their overflow region
 };
-__global__ void k_var_caps(VarParams P) {
+__global__ void k_ovf_caps(OvfParams P) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P.n) return;
     const float s = (float)P.sample[p];
-    const uint32_t c = (uint32_t)(P.scale * (s + 4.0f * sqrtf(s) + 2.0f)) + 8u;
-    constexpr uint32_t U = (1u << VAR_UNIT_LOG) - 1u;        // whole units of 64 records (var_word, k_scan.h)
-    P.cap[p] = ((c > P.cap_min ? c : P.cap_min) + U) & ~U;
+    float est = P.scale * (s + 4.0f * sqrtf(s) + 2.0f) + 8.0f;
+    if (est > (float)(OVF_CAP_MASK - 15ULL)) est = (float)(OVF_CAP_MASK - 15ULL);
+    const uint32_t c = ((uint32_t)est + 7u) & ~7u;
+    P.tcap[p] = c > P.part_cap ? c : 0u;
 }
-__global__ void k_var_init(VarParams P) {                    // (before the scan) the packed cursor word of every region
+__global__ void k_ovf_words(OvfParams P) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < P.n) P.cursor[p] = var_word(P.off[p], P.off[p + 1]);
+    if (p >= P.n) return;
+    const uint64_t t = P.tcap[p];
+    P.words[p] = t ? (((P.area0 + P.toff[p]) << OVF_CAP_BITS) | t) : 0ULL;
 }
-__global__ void k_var_finish(VarParams P) {                  // (after the scan) cursor[p] back to the plain 'begin + records offered'; begin / end pairs
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t n = 0;
-    if (p < P.n) {
-        const uint64_t b = P.off[p], lim = P.off[p + 1];
-        n = (P.cursor[p] & VAR_L_MASK) - (VAR_L_ZERO - (lim - b));
-        const uint64_t e = b + n;
-        P.cursor[p] = e;
-        P.pairs[2 * p] = b; P.pairs[2 * p + 1] = e > lim ? b : e;
+__global__ void k_ovf_finish(OvfParams P) {              // one wave per partition, grid-stride
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint64_t offered = 0, used = 0;
+    for (uint64_t p = wave; p < P.n; p += n_waves) {
+        const uint64_t f = P.fill[p], d = P.words[p], t = d & OVF_CAP_MASK, hb = d >> OVF_CAP_BITS, b = p * P.part_cap;
+        offered += f;
+        uint64_t r0 = b, r1 = b + f;
+        if (f > P.part_cap) {
+            if (f <= t) {
+                const uint64_t n = (uint64_t)P.part_cap * P.RW;
+                for (uint64_t i = lane; i < n; i += 64) P.records[hb * P.RW + i] = P.records[b * P.RW + i];
+                r0 = hb; r1 = hb + f; ++used;
+            } else r1 = b;                               // spilled: counted from its gathered copy
+        }
+        if (lane == 0) { P.pairs[2 * p] = r0; P.pairs[2 * p + 1] = r1; }
     }
-    n = wave_sum_u64(n);
-    if ((threadIdx.x & 63) == 0 && n) atomic_add_u64(&P.stats[0], n);
+    if (lane == 0) { if (offered) atomic_add_u64(&P.stats[0], offered); if (used) atomic_add_u64(&P.stats[1], used); }
 }
 
 // ---- multi-GPU, single-pass scan: squeeze the capped regions into the exact owner-major layout that travels ----

@@ -37,6 +37,12 @@ struct LinkParams {
     uint32_t* end_slot;   // [2U] table slot of each end (bit 31 = flag, bit 30 = palindromic key)
     uint32_t* deg;        // [2U] out-degree of each end
     const uint64_t* link_off; uint32_t* link_to;   // fill pass
+    // a unitig set SHARDED over the ranks of a multi-GPU job (round 5): every rank describes its ends -- the canonical junction key
+    // and a flag word -- all ranks gather all descriptions (rank order: the position of an end is its job-wide id, 2 x unitig id + side,
+    // with unitig ids numbered rank after rank), every rank joins ALL ends in its own table and keeps the links of its own ends
+    // [e0, e0 + 2 n_unitigs).  Ends are ~3 % of a graph's bytes: this replicates a 6 ms kernel, not the graph.
+    uint64_t* end_keys; uint32_t* end_meta;          // k_link_describe: [2U * W], [2U]  (bit 0 = flag, bit 1 = palindromic key)
+    const uint64_t* all_keys; const uint32_t* all_meta; uint64_t n_all_ends, e0;
 };
 
 // out-going oriented k-mer of end e of a unitig held as ASCII
@@ -65,10 +71,38 @@ __global__ void k_link_insert(LinkParams P) {
     if (idx < LINK_PER_FLAG) P.lk_ends[((uint64_t)s * 2 + flag) * LINK_PER_FLAG + idx] = (uint32_t)e;
     P.end_slot[e] = s | (flag << 31) | (pal ? (1u << 30) : 0u);
 }
+// (sharded set) the junction key and flags of every local end, as k_link_insert forms them
+template <int W>
+__global__ void k_link_describe(LinkParams P) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * P.n_unitigs) return;
+    const uint64_t u = e >> 1; const uint32_t side = (uint32_t)(e & 1);
+    const Kmer<W> x = link_end_kmer<W>(P.bases + P.unitig_off[u], P.unitig_len[u], P.k, side);
+    Kmer<W> j = suffix_km1<W>(x, P.k);
+    const Kmer<W> r = j.rc(P.k - 1);
+    const bool pal = (r == j);
+    const uint32_t flag = (!pal && r < j) ? 1u : 0u;
+    const Kmer<W> jc = flag ? r : j;
+    for (int i = 0; i < W; ++i) P.end_keys[e * W + i] = jc.w[i];
+    P.end_meta[e] = flag | (pal ? 2u : 0u);
+}
+// (sharded set) every end of the job into this rank's table; end_slot is indexed by the job-wide end id
+template <int W>
+__global__ void k_link_insert_described(LinkParams P) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= P.n_all_ends) return;
+    Kmer<W> jc; for (int i = 0; i < W; ++i) jc.w[i] = P.all_keys[g * W + i];
+    const uint32_t m = P.all_meta[g], flag = m & 1u, pal = (m >> 1) & 1u;
+    const KTable<W> T{ P.lk_keys, P.lk_mask };
+    bool nw; const uint32_t s = ktable_insert<W, true>(T, jc, nw);
+    const uint32_t idx = atomic_add_u32(&P.lk_cnt[s * 2 + flag], 1u);
+    if (idx < LINK_PER_FLAG) P.lk_ends[((uint64_t)s * 2 + flag) * LINK_PER_FLAG + idx] = (uint32_t)g;
+    P.end_slot[g] = s | (flag << 31) | (pal ? (1u << 30) : 0u);
+}
 __global__ void k_link_count(LinkParams P) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 2 * P.n_unitigs) return;
-    const uint32_t v = P.end_slot[e], s = v & 0x3FFFFFFFu, flag = v >> 31, pal = (v >> 30) & 1u;
+    const uint32_t v = P.end_slot[P.e0 + e], s = v & 0x3FFFFFFFu, flag = v >> 31, pal = (v >> 30) & 1u;
     const uint32_t other = pal ? flag : flag ^ 1u;
     const uint32_t c = P.lk_cnt[s * 2 + other];
     P.deg[e] = c < LINK_PER_FLAG ? c : LINK_PER_FLAG;
@@ -76,7 +110,7 @@ __global__ void k_link_count(LinkParams P) {
 __global__ void k_link_fill(LinkParams P) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 2 * P.n_unitigs) return;
-    const uint32_t v = P.end_slot[e], s = v & 0x3FFFFFFFu, flag = v >> 31, pal = (v >> 30) & 1u;
+    const uint32_t v = P.end_slot[P.e0 + e], s = v & 0x3FFFFFFFu, flag = v >> 31, pal = (v >> 30) & 1u;
     const uint32_t other = pal ? flag : flag ^ 1u;
     const uint32_t c = P.deg[e];
     const uint64_t o = P.link_off[e];

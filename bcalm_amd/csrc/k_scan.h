@@ -69,19 +69,19 @@ struct ScanParams {
     uint32_t part_cap; uint32_t* part_fill;
     uint64_t* spill_recs; uint32_t* spill_part; uint64_t* spill_cursor; uint64_t spill_cap; uint32_t* error;
     uint32_t emit_all, npl;      // multi-GPU with sharded reads: emit every partition, slot = owner * npl + local partition
-    const uint64_t* var_limit;   // SCAN_EMIT with estimated regions (non-null: a flag since round 5): part_cursor[p] is a PACKED word (var_word, below) that
-                                 // carries the region's end and the room left, so that placing a record stays ONE atomic and no gather; nullptr = exact offsets
+    const uint64_t* var_limit;   // SCAN_EMIT with estimated regions: end of partition p's region (records beyond it go to the spill list); nullptr = exact offsets
+    const uint64_t* ovf;         // SCAN_EMIT_CAPPED, skewed inputs: per partition 0 or (first record of its overflow region << OVF_CAP_BITS) | records the partition
+                                 // may hold in all (record j >= part_cap goes to slot j of that region; its first part_cap slots receive the uniform region's records afterwards)
+    const uint64_t* part_off;    // SCAN_EMIT: first record of partition p's region, added to the 32-BIT running index part_fill[p] (zeroed by the host);
+                                 // nullptr: part_fill[p] was pre-loaded with the offset itself (exact layout of fewer than 2^32 records: no second access)
 };
-// Packed cursor of an estimated region (single-pass layout of skewed inputs).  Regions are whole units of 64 records; the word is
-//   [ end of the region in units : 28 bits | L : 36 bits ],  L = 2^35 - capacity + records offered so far.
-// One atomic add of 1 returns the old word: the record fits iff L < 2^35 and then goes to end * 64 - 2^35 + L; the records offered
-// beyond the capacity keep counting in L (the host takes this layout only for texts below 2^35 bytes: L cannot carry into the end
-// field -- a partition is offered fewer records than the text has bytes).  Round 4 read the region's end from a second array:
-// one more scattered 8-byte gather per record (1.6 G of them at config-3 size: scan 83 -> ~70 ms on the hostile line).
-constexpr int VAR_UNIT_LOG = 6, VAR_L_BITS = 36;
-constexpr uint64_t VAR_L_MASK = (1ULL << VAR_L_BITS) - 1ULL, VAR_L_ZERO = 1ULL << (VAR_L_BITS - 1);
-CDBG_DEV uint64_t var_word(uint64_t begin, uint64_t end) { return ((end >> VAR_UNIT_LOG) << VAR_L_BITS) | (VAR_L_ZERO - (end - begin)); }
+// Round 5: placing a record is ONE returning 32-bit atomic and one store wherever the layout allows it.  The exact layout used to
+// advance a 64-bit cursor per partition: the same 1.6 G atomics on the same addresses took its emit pass from 66.8 to 89.1 ms at
+// config 3 (profiles/r05_ab_scan_atomic_width.log), and a 32-bit index plus a load of the region's offset costs the same 86 - 89 ms:
+// the pass pays per memory REQUEST of a record (capped layout: two), whatever its kind.
 constexpr int SCAN_HIST = 0, SCAN_EMIT = 1, SCAN_EMIT_CAPPED = 2;
+constexpr int OVF_CAP_BITS = 28;                         // (a partition of more than 2^28 records spills its excess, and the step then falls back to the exact layout)
+constexpr uint64_t OVF_CAP_MASK = (1ULL << OVF_CAP_BITS) - 1ULL;
 
 CDBG_DEV uint64_t scan_get64(const uint32_t* pk, int bitoff) {
     const int w = bitoff >> 5, sh = bitoff & 31;
@@ -114,26 +114,21 @@ CDBG_DEV void scan_emit_record(const ScanParams& P, const uint32_t* pk, int bito
     if (MODE == SCAN_EMIT) {
         // exact layout (var_limit == nullptr: the histogram pass sized every region), or ESTIMATED regions of their own size per
         // partition (var_limit[p] = end of p's region, sized from a sampled histogram: the single-pass layout of skewed inputs)
-#ifdef CDBG_AB_EXACT32
-        uint64_t pos = (uint64_t)atomic_add_u32(reinterpret_cast<uint32_t*>(&P.part_cursor[lpart]), 1u);   // (A/B only: 32-bit atomic on the low half; totals below 2^32)
-#else
-        uint64_t pos = atomic_add_u64(&P.part_cursor[lpart], 1ULL);
-#endif
+        uint64_t pos = (uint64_t)atomic_add_u32(&P.part_fill[lpart], 1u);
         fits = true;
-        if (P.var_limit != nullptr) {                        // packed word: end of the region | room left (var_word)
-            const uint64_t L = pos & VAR_L_MASK;
-            fits = L < VAR_L_ZERO;
-            pos = ((pos >> VAR_L_BITS) << VAR_UNIT_LOG) - VAR_L_ZERO + L;
+        if (P.part_off != nullptr) {                         // (nullptr: the counters were pre-loaded with the regions' offsets -- exact layout of fewer than 2^32 records)
+            pos += P.part_off[lpart];
+            fits = P.var_limit == nullptr || pos < P.var_limit[lpart];
         }
         dst = P.records + pos * RW;
     } else {
-#ifdef CDBG_AB_FILL64
-        const uint32_t j = (uint32_t)atomic_add_u64(&P.part_cursor[lpart], 1ULL);   // (A/B only: the scan's time with a 64-bit fill counter; the count stage then sees empty partitions)
-#else
         const uint32_t j = atomic_add_u32(&P.part_fill[lpart], 1u);
-#endif
         fits = j < P.part_cap;
         dst = P.records + ((uint64_t)lpart * P.part_cap + j) * RW;
+        if (!fits && P.ovf != nullptr) {                     // skewed input: a partition the sample found heavy has an overflow region of its own
+            const uint64_t d = P.ovf[lpart];                 // (one more load for the records beyond the uniform capacity only)
+            if ((uint64_t)j < (d & OVF_CAP_MASK)) { fits = true; dst = P.records + ((d >> OVF_CAP_BITS) + j) * RW; }
+        }
     }
     if (!fits) {
         const uint64_t o = atomic_add_u64(P.spill_cursor, 1ULL);
@@ -464,6 +459,16 @@ __global__ void k_max_u32(const uint32_t* a, uint64_t n, uint64_t* out) {       
 __global__ void k_copy_u64(const uint64_t* src, uint64_t* dst, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
+}
+
+// exact layout of fewer than 2^32 records: the 32-bit running indices start at the regions' offsets; afterwards back to record counts
+__global__ void k_cursor32_load(const uint64_t* off, uint32_t* cur, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cur[i] = (uint32_t)off[i];
+}
+__global__ void k_cursor32_counts(const uint64_t* off, uint32_t* cur, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cur[i] -= (uint32_t)off[i];
 }
 
 // ---- counter-based synthetic reads, resident in HBM ----

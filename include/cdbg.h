@@ -78,7 +78,7 @@ typedef struct cdbg_stats_t {
 /* ABI version: bumped whenever a struct of this header changes.  From version 5 on cdbg_stats_t only ever GROWS AT ITS END;
  * a binding checks cdbg_abi_version() against the header it was written for and sizeof(cdbg_stats_t) against
  * cdbg_stats_sizeof() when it loads the library (bcalm_amd/api.py does), instead of reading fields at stale offsets. */
-#define CDBG_ABI_VERSION 5
+#define CDBG_ABI_VERSION 6
 int cdbg_abi_version(void);
 uint64_t cdbg_stats_sizeof(void);
 
@@ -242,6 +242,12 @@ int cdbg_verify_unitigs(cdbg_ctx* ctx, const char* bases, const uint64_t* offset
 int cdbg_link(cdbg_ctx* ctx);
 int cdbg_num_links(cdbg_ctx* ctx, uint64_t* n);
 int cdbg_fetch_links(cdbg_ctx* ctx, uint64_t* end_off, uint32_t* link_to);
+/* Several ranks, every rank holding a share of the unitigs (emit_replicated = 0): cdbg_link is COLLECTIVE (all ranks call it).  Unitig
+ * ids are then job-wide, numbered rank after rank: this rank's unitig i (the order of cdbg_fetch_unitigs) is first_id + i, end_off
+ * covers this rank's ends and link_to holds job-wide end ids (2 x id + side) -- every rank can write its own share of the output
+ * file, `L:` tokens included (the bcalm CLI with -nb-gpus does).  One rank, or emit_replicated = 1: first_id = 0, total = this
+ * context's unitigs.  After cdbg_link. */
+int cdbg_unitig_id_base(cdbg_ctx* ctx, uint64_t* first_id, uint64_t* total);
 
 /* Environment variables read by the library -- test hooks that force paths an ordinary input does not reach (tests/), not
  * tuning knobs; results are identical with and without them:

@@ -26,6 +26,7 @@ def _run_sharded(api, cdist, lib, orc, text, k, amin, world, rank, steps=1, **kw
     kw = dict(kw)
     scan_mode = kw.pop("scan_mode", None)                # CDBG_SCAN_MODE: the single-pass capped scan + region packing at test sizes
     kw.pop("expect_fallback", None)
+    check_links = kw.pop("links", False)                 # cdbg_link on the sharded set, against the brute-force link oracle
     empty_rank = kw.pop("empty_rank", None)              # this rank receives no reads at all (a small input dealt out in chunks)
     part_cap = kw.pop("part_cap", None)                  # CDBG_PART_CAP: regions far too small -- spilled records are packed behind their regions
     if scan_mode:
@@ -53,19 +54,37 @@ def _run_sharded(api, cdist, lib, orc, text, k, amin, world, rank, steps=1, **kw
         g.run()
         mine = g.unitigs(); st = g.stats(); nbytes = g.comm_bytes()
         ab = g.unitig_abundances() if kw.get("all_abundance_counts") else None
+        lk = None
+        if check_links and not kw.get("emit_replicated"):
+            # the link table of a SHARDED unitig set (collective cdbg_link): job-wide ids, every rank the links of its own unitigs
+            my_links = g.links(); first, total = g.unitig_id_base()
+            lk = (first, total, my_links)
         gathered = [None] * world
-        dist.all_gather_object(gathered, (mine, st["n_distinct"], st["n_solid"], st["n_occurrences"]))
+        dist.all_gather_object(gathered, (mine, st["n_distinct"], st["n_solid"], st["n_occurrences"], lk))
         out = {"union": sorted((orc.canonical_unitig(s, k), int(kc)) for part in gathered for s, kc in part[0]),
                "mine": mine, "distinct": sum(p[1] for p in gathered), "solid": sum(p[2] for p in gathered),
                "occ": sum(p[3] for p in gathered), "comm_bytes": nbytes, "per_rank": [len(p[0]) for p in gathered], "ab": ab,
                "rounds": st["n_glue_rounds"]}
+        if lk is not None:
+            # ids are numbered rank after rank; the union of the ranks' link lists is the brute-force link set of the whole graph
+            import oracle_py as op
+            seqs = [s for part in gathered for s, _ in part[0]]
+            firsts = [part[4][0] for part in gathered]
+            ok_ids = firsts == [sum(len(q[0]) for q in gathered[:r]) for r in range(world)] and all(part[4][1] == len(seqs) for part in gathered)
+            got = set()
+            for part in gathered:
+                first, _, links = part[4]
+                for u, ls in enumerate(links):
+                    for fs, v, ts in ls:
+                        got.add((first + u, fs, v, ts))
+            out["links_ok"] = ok_ids and got == op.links(seqs, k)
     g.close()
     return out
 
 
 def _worker(rank, world, port, q, cases):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import hostsim_lib
     from bcalm_amd import api, dist as cdist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -94,6 +113,8 @@ def _worker(rank, world, port, q, cases):
         ok.append(got["distinct"] == exp["stats"]["distinct"] and got["solid"] == exp["stats"]["solid"] and got["occ"] == exp["stats"]["occurrences"])
         ok.append(got["comm_bytes"] > 0)
         # which glue ran: the sharded one (distributed ranking rounds > 0) unless every rank emits everything
+        if kw.get("links") and not kw.get("emit_replicated"):
+            ok.append(got.get("links_ok") is True)
         if "rounds" in got:
             ok.append((got["rounds"] > 0) == (not kw.get("emit_replicated") and not kw.get("expect_fallback")))
         if kw.get("all_abundance_counts"):
@@ -138,7 +159,9 @@ def test_two_rank_gloo():
                 (31, 2, 300, 150, 3, {"reads_replicated": True}), (31, 2, 300, 150, 3, {"scan_mode": "capped", "log2_partitions": 6}),
                 (31, 2, 300, 150, 3, {"scan_mode": "capped", "log2_partitions": 6, "part_cap": "3"}), (55, 2, 150, 150, 4, {"scan_mode": "capped", "part_cap": "1"}),
                 (55, 2, 200, 150, 4, {"scan_mode": "capped", "reads_replicated": True}), (31, 2, 200, 150, 3, {"empty_rank": 1}),
-                (30, 2, 250, 150, 3, {}), (64, 1, 100, 300, 5, {"log2_partitions": 4}),
+                (30, 2, 250, 150, 3, {"links": True}), (64, 1, 100, 300, 5, {"log2_partitions": 4, "links": True}),
+                (31, 2, 300, 150, 3, {"links": True}), (9, 1, 0, 0, "pufferize_refs", {"log2_partitions": 4, "minimizer_size": 4, "links": True}),
+                (8, 1, 0, 0, "even_k8", {"log2_partitions": 3, "minimizer_size": 4, "links": True}),
                 # closed chains across ranks (example/circular_unitigs_unittests): a ranking round that finishes nothing -> the unfinished
                 # states are gathered, every rank cuts the same junction, the sharded ranking starts again (no replicated fallback)
                 (7, 1, 0, 0, "circ_test1", {"log2_partitions": 3, "minimizer_size": 3}), (7, 1, 0, 0, "circ_test1", {"log2_partitions": 5, "minimizer_size": 4}),
@@ -146,7 +169,7 @@ def test_two_rank_gloo():
 
 
 def test_four_rank_gloo():
-    _launch(4, [(31, 2, 400, 150, 3, {}), (55, 1, 160, 150, 4, {"log2_partitions": 7}), (127, 2, 80, 500, 5, {"log2_partitions": 5}),
+    _launch(4, [(31, 2, 400, 150, 3, {"links": True}), (55, 1, 160, 150, 4, {"log2_partitions": 7, "links": True}), (127, 2, 80, 500, 5, {"log2_partitions": 5}),
                 # three plasmid-like circles of 1500 bp next to ordinary reads' worth of chains: cut in place, ranking restarted
                 (31, 1, 3, 1500, "@circular", {"log2_partitions": 6}), (55, 1, 2, 900, "@circular", {"log2_partitions": 5}),
                 (31, 2, 400, 150, 3, {"reads_replicated": True}), (31, 2, 300, 150, 3, {"scan_mode": "capped", "empty_rank": 3})], 31500, 300)

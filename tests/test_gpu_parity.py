@@ -275,6 +275,22 @@ def test_capped_single_pass_scan_gpu(oracle, hip, part_cap, monkeypatch):
     assert_parity(oracle, hip, text, 31, 2, log2_partitions=10)
 
 
+@pytest.mark.parametrize("k,cfg,n_reads,read_len,log_np,part_cap,var_scale", [
+    (31, 3 | 0x100, 60000, 150, 10, None, None), (31, 3 | 0x100, 60000, 150, 10, "24", None), (31, 3, 40000, 150, 10, "16", "0.5"),
+    (55, 4 | 0x100, 30000, 150, 9, "8", None), (127, 5 | 0x100, 2500, 1000, 8, "8", "0.3")])
+def test_capped_regions_with_overflow_regions_gpu(oracle, hip, k, cfg, n_reads, read_len, log_np, part_cap, var_scale, monkeypatch):
+    """the single-pass record layout of skewed inputs (CDBG_SCAN_MODE=var): uniform capped regions + an overflow region for every partition
+    the sampled histogram finds heavy, the uniform region's records moved to the front of it afterwards; a small CDBG_PART_CAP makes every
+    busy partition heavy, CDBG_VAR_SCALE makes the overflow regions too small (spill list + repair of partitions that have one)"""
+    monkeypatch.setenv("CDBG_SCAN_MODE", "var")
+    if part_cap:
+        monkeypatch.setenv("CDBG_PART_CAP", part_cap)
+    if var_scale:
+        monkeypatch.setenv("CDBG_VAR_SCALE", var_scale)
+    text = oracle.synth_reads(n_reads, read_len, cfg)
+    assert_parity(oracle, hip, text, k, 2, log2_partitions=log_np)
+
+
 def test_config2_genome_shape(oracle, hip):
     """BASELINE config 2 shape: one 4.64 Mbp sequence (E. coli MG1655 length; the FASTA itself is not
     available offline, so a seeded synthetic genome with planted direct and inverted repeats stands in),

@@ -267,15 +267,21 @@ def test_wide_kmers_beyond_the_default_span_list(oracle, sim, k, amin, log_np, m
     gg.push_text(text); gg.run(); assert_verified(gg); gg.close()
 
 
-@pytest.mark.parametrize("k,cfg,n_reads,read_len,log_np,part_min", [(31, 3 | 0x100, 1500, 150, 6, None), (31, 3, 1500, 150, 5, None), (55, 4 | 0x100, 700, 150, 4, None),
-                                                                     (127, 5 | 0x100, 60, 1000, 3, None), (21, 3 | 0x100, 1500, 150, 6, 1), (64, 4 | 0x100, 700, 150, 4, 1)])
-def test_single_pass_scan_into_estimated_regions(oracle, sim, k, cfg, n_reads, read_len, log_np, part_min, monkeypatch):
-    """CDBG_SCAN_MODE=var: the record layout of skewed inputs -- one scan pass into regions of their own size per partition,
-    estimated from a sampled histogram; with CDBG_PART_CAP=1 the estimate is made useless on purpose (every busy partition
-    spills and is repaired on the device).  Same solid set and unitigs as the oracle"""
+@pytest.mark.parametrize("k,cfg,n_reads,read_len,log_np,part_min,var_scale", [
+    (31, 3 | 0x100, 1500, 150, 6, None, None), (31, 3, 1500, 150, 5, None, None), (55, 4 | 0x100, 700, 150, 4, None, None), (127, 5 | 0x100, 60, 1000, 3, None, None),
+    (21, 3 | 0x100, 1500, 150, 6, 1, "0.02"), (64, 4 | 0x100, 700, 150, 4, 1, "0.02"),
+    (31, 3 | 0x100, 1500, 150, 6, 8, None), (55, 4, 700, 150, 4, 16, None), (96, 5 | 0x100, 60, 1000, 3, 8, None), (31, 3, 1500, 150, 5, 24, "0.7")])
+def test_single_pass_scan_into_estimated_regions(oracle, sim, k, cfg, n_reads, read_len, log_np, part_min, var_scale, monkeypatch):
+    """CDBG_SCAN_MODE=var: the record layout of skewed inputs -- ONE scan pass into the uniform capped regions plus an overflow region
+    for every partition the sampled histogram finds heavy (round 5; k_ovf_* in k_count.h).  CDBG_PART_CAP = 8 .. 24: a uniform capacity so
+    small that every busy partition is 'heavy' and runs over into its overflow region (which holds it: the sample of a small input is the
+    full histogram); with CDBG_VAR_SCALE the overflow regions are made too small on purpose, so that partitions spill out of them as
+    well and are repaired on the device.  Same solid set and unitigs as the oracle"""
     monkeypatch.setenv("CDBG_SCAN_MODE", "var")
     if part_min:
-        monkeypatch.setenv("CDBG_PART_CAP", str(part_min)); monkeypatch.setenv("CDBG_VAR_SCALE", "0.02")
+        monkeypatch.setenv("CDBG_PART_CAP", str(part_min))
+    if var_scale:
+        monkeypatch.setenv("CDBG_VAR_SCALE", var_scale)
     text = oracle.synth_reads(n_reads, read_len, cfg)
     assert_parity(oracle, sim, text, k, 2, log2_partitions=log_np)
     assert_parity(oracle, sim, text, k, 1, log2_partitions=log_np)
