@@ -532,6 +532,7 @@ int count_impl(cdbg_ctx* c) {
     hm.mark("count: solid buffers");
     CK(t.start(s));
     cp.n_items = (uint32_t)NPL; cp.max_passes = 64;
+    if (const char* e = c->knobs.get("CDBG_COUNT_MAX_SUB")) { uint32_t v = (uint32_t)std::max(1, atoi(e)); while (v & (v - 1)) v &= v - 1; cp.max_sub = std::min(v, 16u); }   // dev knob: 1, 2, 4, 8, 16
     // one-pass kernel over all partitions; the ones whose distinct k-mers do not fit the LDS table at once come back on
     // the retry list and go through the multi-pass kernel
     {

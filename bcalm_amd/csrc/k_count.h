@@ -275,6 +275,7 @@ struct CountParams {
     uint64_t* g_keys; uint32_t* g_cnt; const uint64_t* big_off;
     uint32_t n_items;              // partitions (or part_list entries) to process
     uint32_t max_passes;           // LDS multi-pass limit before a partition is deferred to the HBM pass
+    uint32_t max_sub;              // multi-pass kernel: passes that divide a partition by its records' sub-partition (a power of two <= 16; 0: COUNT_MAX_SUB)
 };
 
 // ---------------------------------------------------------------------------
@@ -368,7 +369,8 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
             reserved = true;
         }
         bool overflow = false;
-        const uint32_t nsub = npass < COUNT_MAX_SUB ? npass : COUNT_MAX_SUB, nhash = npass / nsub;   // passes = sub-partitions x hash classes
+        const uint32_t max_sub = P.max_sub ? P.max_sub : COUNT_MAX_SUB;
+        const uint32_t nsub = npass < max_sub ? npass : max_sub, nhash = npass / nsub;   // passes = sub-partitions x hash classes
         const int nphase = (npass == 1 || onephase) ? 1 : 2;
         for (int phase = 0; phase < nphase && !overflow; ++phase) {
             for (uint32_t pass = 0; pass < npass; ++pass) {

@@ -364,18 +364,20 @@ int main(int argc, char** argv) {
         if (o.n_gpus < 1 || (o.n_gpus & (o.n_gpus - 1))) usage_error("-nb-gpus must be a power of two");
         const int world = o.n_gpus;
         // one context per GPU; with several GPUs the reads are sharded over them and the contexts talk over RCCL inside
-        // libcdbg (include/cdbg.h "Multi-GPU"); rank 0 emits the complete unitig set (emit_replicated) and writes the file
+        // libcdbg (include/cdbg.h "Multi-GPU"); every rank ends with its SHARE of the unitigs, links the whole set collectively (job-wide ids)
+        // and its share is written from its own context -- round 4 gathered the whole graph on every rank (emit_replicated) for rank 0 to write
         std::vector<cdbg_ctx*> ctxs(world, nullptr);
         cdbg_ctx* ctx = nullptr;
         auto make_contexts = [&]() {
             for (int r = 0; r < world; ++r) {
                 cdbg_params p{}; p.k = o.k; p.abundance_min = o.amin; p.minimizer_size = o.m; p.log2_partitions = o.log_np;
                 p.device_id = world > 1 ? r : o.device; p.world_size = world; p.rank = r; p.all_abundance_counts = o.all_ab ? 1 : 0;
-                p.emit_replicated = 1;
+                p.emit_replicated = 0;
                 check(cdbg_create(&p, &ctxs[r]));
             }
             ctx = ctxs[0];
-            if (world > 1) {
+            // (CDBG_FORCE_MULTI, the library's test hook: one rank through the multi-rank code path -- it needs the transport then)
+            if (world > 1 || getenv("CDBG_FORCE_MULTI")) {
                 unsigned char uid[128]; check(cdbg_comm_unique_id(uid));
                 std::vector<std::thread> th; std::atomic<int> bad{0}; std::vector<std::string> errs(world);
                 for (int r = 0; r < world; ++r) th.emplace_back([&, r]() { if (cdbg_comm_init_rccl(ctxs[r], uid) != 0) { errs[r] = cdbg_last_error(); ++bad; } });
@@ -432,26 +434,39 @@ int main(int argc, char** argv) {
         all_ranks(cdbg_glue);
         auto t_stages = std::chrono::steady_clock::now();
         cdbg_stats_t st; check(cdbg_stats(ctx, &st));
-        uint64_t nu = 0, tb = 0; check(cdbg_num_unitigs(ctx, &nu, &tb));
-        std::unique_ptr<char[]> seq(new char[tb + 1]);       // (not value-initialised: a gigabyte at config 3)
-        std::vector<uint64_t> off(nu + 1), kc(nu ? nu : 1);
-        check(cdbg_fetch_unitigs(ctx, 0, nu, seq.get(), off.data(), kc.data()));
-        std::vector<uint32_t> ab; std::vector<uint64_t> aboff;
-        if (o.all_ab) { ab.resize(tb + 1); aboff.resize(nu + 1); check(cdbg_fetch_unitig_abundances(ctx, 0, nu, ab.data(), aboff.data())); }
-        // edges between unitigs (README.md:72 L: tokens; convertToGFA.py:103-112 GFA L lines)
-        check(cdbg_link(ctx));
-        uint64_t nl = 0; check(cdbg_num_links(ctx, &nl));
-        std::vector<uint64_t> loff(2 * nu + 1); std::vector<uint32_t> lto(nl ? nl : 1);
-        check(cdbg_fetch_links(ctx, loff.data(), lto.data()));
-        auto t2 = std::chrono::steady_clock::now();
+        // edges between unitigs (README.md:72 L: tokens; convertToGFA.py:103-112 GFA L lines).  Several GPUs: every rank holds a share of
+        // the unitigs; cdbg_link is collective there and numbers the unitigs job-wide, rank after rank (include/cdbg.h)
+        all_ranks(cdbg_link);
+        for (int r = 1; r < world; ++r) {                    // (the printed totals: k-mers and pieces of every rank's partitions, unitigs of every rank's share)
+            cdbg_stats_t sr; check(cdbg_stats(ctxs[r], &sr));
+            st.n_occurrences += sr.n_occurrences; st.n_distinct += sr.n_distinct; st.n_solid += sr.n_solid; st.n_pieces += sr.n_pieces;
+            st.n_unitigs += sr.n_unitigs; st.unitig_bases += sr.unitig_bases;
+            st.ms_count = std::max(st.ms_count, sr.ms_count); st.ms_compact = std::max(st.ms_compact, sr.ms_compact); st.ms_glue = std::max(st.ms_glue, sr.ms_glue);
+        }
 
-        // Output: the threads format blocks of unitigs into memory (own integer formatting; "%.1f" stays with printf so that km:f:
-        // rounds exactly as the reference's) and write them in block order, one write per block.
+        // Output: rank after rank (one rank: everything), each rank's share fetched, formatted by the threads in blocks of unitigs (own
+        // integer formatting; "%.1f" stays with printf so that km:f: rounds exactly as the reference's) and written in block order, one
+        // write per block.  Ids and link targets are job-wide.
         const std::string fa = prefix + ".unitigs.fa";
         FILE* out = fopen(fa.c_str(), "w");
         if (!out) usage_error("cannot write " + fa);
         FILE* gfa = nullptr;
         if (o.gfa) { gfa = fopen((prefix + ".unitigs.gfa").c_str(), "w"); if (gfa) fprintf(gfa, "H\tVN:Z:1.0\tks:i:%d\n", o.k); }
+        double s_fetch = 0, s_write = 0;
+        for (int r = 0; r < world; ++r) {
+        auto tf0 = std::chrono::steady_clock::now();
+        cdbg_ctx* const cx = ctxs[r];
+        uint64_t nu = 0, tb = 0; check(cdbg_num_unitigs(cx, &nu, &tb));
+        uint64_t id0 = 0, id_total = 0; check(cdbg_unitig_id_base(cx, &id0, &id_total));
+        std::unique_ptr<char[]> seq(new char[tb + 1]);       // (not value-initialised: a gigabyte at config 3)
+        std::vector<uint64_t> off(nu + 1), kc(nu ? nu : 1);
+        check(cdbg_fetch_unitigs(cx, 0, nu, seq.get(), off.data(), kc.data()));
+        std::vector<uint32_t> ab; std::vector<uint64_t> aboff;
+        if (o.all_ab) { ab.resize(tb + 1); aboff.resize(nu + 1); check(cdbg_fetch_unitig_abundances(cx, 0, nu, ab.data(), aboff.data())); }
+        uint64_t nl = 0; check(cdbg_num_links(cx, &nl));
+        std::vector<uint64_t> loff(2 * nu + 1); std::vector<uint32_t> lto(nl ? nl : 1);
+        check(cdbg_fetch_links(cx, loff.data(), lto.data()));
+        auto tf1 = std::chrono::steady_clock::now();
         {
             const uint64_t BLOCK = 1u << 15;
             const uint64_t nblocks = (nu + BLOCK - 1) / BLOCK;
@@ -468,20 +483,20 @@ int main(int argc, char** argv) {
                     const uint64_t i0 = b * BLOCK, i1 = std::min(nu, i0 + BLOCK);
                     fb.reserve((size_t)(off[i1] - off[i0]) + (size_t)(i1 - i0) * 96);
                     for (uint64_t i = i0; i < i1; ++i) {
-                        const uint64_t len = off[i + 1] - off[i];
+                        const uint64_t len = off[i + 1] - off[i], id = id0 + i;
                         const double km = (double)kc[i] / (double)(len - (uint64_t)o.k + 1);
-                        fb.push_back('>'); put_u(fb, i); fb.append(" LN:i:"); put_u(fb, len);
+                        fb.push_back('>'); put_u(fb, id); fb.append(" LN:i:"); put_u(fb, len);
                         if (o.all_ab) {                          // ><id> LN:i:<length> ab:Z:<abundance_0> ... (README.md:76)
                             fb.append(" ab:Z:");
                             for (uint64_t j = aboff[i]; j < aboff[i + 1]; ++j) { if (j != aboff[i]) fb.push_back(' '); put_u(fb, ab[j]); }
                         } else { fb.append(" KC:i:"); put_u(fb, kc[i]); fb.append(" km:f:"); put_km(fb, km); }
-                        if (gfa) { gb.append("S\t"); put_u(gb, i); gb.push_back('\t'); gb.append(seq.get() + off[i], (size_t)len);
+                        if (gfa) { gb.append("S\t"); put_u(gb, id); gb.push_back('\t'); gb.append(seq.get() + off[i], (size_t)len);
                                    gb.append("\tLN:i:"); put_u(gb, len); gb.append("\tKC:i:"); put_u(gb, kc[i]); gb.append("\tkm:f:"); put_km(gb, km); gb.push_back('\n'); }
                         for (int side = 1; side >= 0; --side)    // '+' links (through the last k-mer) first, then '-'
                             for (uint64_t j = loff[2 * i + side]; j < loff[2 * i + side + 1]; ++j) {
                                 const char fs = side ? '+' : '-', ts = (lto[j] & 1u) ? '-' : '+';
                                 fb.append(" L:"); fb.push_back(fs); fb.push_back(':'); put_u(fb, lto[j] >> 1); fb.push_back(':'); fb.push_back(ts);
-                                if (gfa) { gb.append("L\t"); put_u(gb, i); gb.push_back('\t'); gb.push_back(fs); gb.push_back('\t'); put_u(gb, lto[j] >> 1);
+                                if (gfa) { gb.append("L\t"); put_u(gb, id); gb.push_back('\t'); gb.push_back(fs); gb.push_back('\t'); put_u(gb, lto[j] >> 1);
                                            gb.push_back('\t'); gb.push_back(ts); gb.push_back('\t'); put_u(gb, (unsigned long long)(o.k - 1)); gb.append("M\n"); }
                             }
                         fb.append(" \n");
@@ -501,8 +516,12 @@ int main(int argc, char** argv) {
             for (auto& t : th) t.join();
             if (wfail) usage_error("write error on " + fa);
         }
+        auto tf2 = std::chrono::steady_clock::now();
+        s_fetch += std::chrono::duration<double>(tf1 - tf0).count(); s_write += std::chrono::duration<double>(tf2 - tf1).count();
+        }
         fclose(out); if (gfa) fclose(gfa);
         auto t3 = std::chrono::steady_clock::now();
+        const auto t2 = t3 - std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(s_write));   // (fetches and writes alternate with several ranks: the printed split is their sums)
         auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
         printf("input: %llu sequences, %llu bases (%.2f s parse)\n", (unsigned long long)n_seq, (unsigned long long)n_bases, sec(t_init, t1));
         uint64_t in_bytes = 0; for (const auto& f : files) { struct stat sb; if (stat(f.c_str(), &sb) == 0) in_bytes += (uint64_t)sb.st_size; }

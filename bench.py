@@ -166,7 +166,7 @@ def cpu_baseline(k, amin, read_len, cfg, sample_reads):
                     "only_ours": sorted(set(a) - set(b))[:3], "only_reference": sorted(set(b) - set(a))[:3]}
         except Exception:
             pass                                             # fall through to the port
-    if k <= 31:
+    if k <= 63:
         # the multithreaded shared-table restatement (oracle/cpu_mt.cpp: std::thread x all cores, ONE input, one lock-free
         # table; SURVEY.md section 8 d ii), pinned against the oracle in tests/test_oracle.py
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -268,7 +268,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--abundance-min", type=int, default=2)
-    ap.add_argument("--cpu-sample-reads", type=int, default=None, help="reads of the CPU baseline's sample (default: 10 M for k <= 31, 400 K per process otherwise)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=None, help="reads of the CPU baseline's sample (default: 10 M for k <= 31, 6 M for k <= 63 -- the multithreaded restatement; 400 K per process of the scalar port beyond)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (the bcalm CLI on a FASTA dump: t_e2e_s)")
     ap.add_argument("--e2e-reads", type=int, default=None, help="reads of the end-to-end FASTA (default: >= 1 GB of sequence)")
@@ -292,7 +292,7 @@ def main():
            5: dict(k=127, read_len=1000, reads=6_250_000, name="BASELINE config 5, the share of one of its 8 GPUs (50 M reads / 8)")}[a.cfg]
     a.k = a.k or CFG["k"]; a.read_len = a.read_len or CFG["read_len"]
     a.reads = a.reads or int(os.environ.get("CDBG_BENCH_READS", CFG["reads"]))
-    a.cpu_sample_reads = a.cpu_sample_reads or (10_000_000 if a.k <= 31 else 400_000)
+    a.cpu_sample_reads = a.cpu_sample_reads or (10_000_000 if a.k <= 31 else 6_000_000 if a.k <= 63 else 400_000)
     # end-to-end leg: >= 4.5 GB of FASTA by default (the full read set of the config with --e2e-reads = --reads: 15.4 GB at config 3; the
     # default keeps the whole bench within minutes -- writing the FASTA takes longer than the CLI needs for it)
     a.e2e_reads = a.e2e_reads or min(a.reads, (int(os.environ.get("CDBG_E2E_BYTES", 4_500_000_000)) + a.read_len) // (a.read_len + 4))

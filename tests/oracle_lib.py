@@ -89,7 +89,7 @@ def load():
 
 
 def cpu_mt_run(text, k, amin, threads):
-    """oracle/cpu_mt.cpp: the multithreaded CPU restatement (k <= 31) -> dict of counts, set digest and seconds"""
+    """oracle/cpu_mt.cpp: the multithreaded CPU restatement (k <= 63) -> dict of counts, set digest and seconds"""
     build()
     lib = C.CDLL(os.path.join(ODIR, "_build", "libcpu_mt.so"))
     lib.cpu_mt_run.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]

@@ -14,6 +14,7 @@ import gzip
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -320,3 +321,60 @@ def test_streaming_scan_while_ingesting_gpu(oracle, oracle_1m, hip, monkeypatch)
     assert st["n_tiles_overlapped"] > 0.5 * st["n_launch_scan"]
     assert st["n_distinct"] == exp["stats"]["distinct"] and st["n_solid"] == exp["stats"]["solid"]
     assert canon == exp["unitigs"]
+
+
+def _fa_links(path):
+    """-> {(u, from_sign, v, to_sign)} of a unitigs.fa"""
+    out = set()
+    for line in open(path):
+        if line.startswith(">"):
+            u = int(line[1:].split()[0])
+            for fs, v, ts in re.findall(r" L:([+-]):(\d+):([+-])", line):
+                out.add((u, fs, int(v), ts))
+    return out
+
+
+def test_cli_sharded_writer_through_one_rank_rccl(oracle, tmp_path):
+    """the CLI's multi-GPU output path on a 1-GPU box: CDBG_FORCE_MULTI sends the one rank through the multi-rank code (RCCL
+    communicator of one rank, sharded glue, the COLLECTIVE cdbg_link with job-wide unitig ids, the writer that walks the ranks).
+    Same unitig set as the oracle, and the L: tokens are exactly the brute-force links of the written sequences"""
+    sys.path.insert(0, os.path.join(oracle_lib.ROOT, "oracle"))
+    import oracle_py as op
+    assert os.path.exists(BCALM)
+    k = 31
+    text = oracle.synth_reads(20000, 150, 3).decode()
+    fa = tmp_path / "reads.fa"
+    with open(fa, "w") as f:
+        for i, r in enumerate(x for x in text.split("\n") if x):
+            f.write(f">r{i}\n{r}\n")
+    env = dict(os.environ, CDBG_FORCE_MULTI="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([BCALM, "-in", str(fa), "-kmer-size", str(k), "-abundance-min", "2"], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    recs = _parse_fa(tmp_path / "reads.unitigs.fa", k)
+    assert oracle_lib.canonical_set(oracle, recs, k) == oracle.run(text, k, 2)["unitigs"]
+    assert _fa_links(tmp_path / "reads.unitigs.fa") == op.links([s for s, _ in recs], k)
+
+
+def test_cli_on_every_visible_gpu(oracle, tmp_path):
+    """`bcalm -nb-gpus N` on a box with N >= 2 GPUs: every rank writes its share (job-wide ids, links across ranks).  Skips on one GPU"""
+    import torch
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    worlds = [w for w in (2, 4, 8) if w <= n]
+    if not worlds:
+        pytest.skip("needs >= 2 GPUs: %d visible" % n)
+    sys.path.insert(0, os.path.join(oracle_lib.ROOT, "oracle"))
+    import oracle_py as op
+    k = 31
+    text = oracle.synth_reads(40000, 150, 3).decode()
+    fa = tmp_path / "reads.fa"
+    with open(fa, "w") as f:
+        for i, r in enumerate(x for x in text.split("\n") if x):
+            f.write(f">r{i}\n{r}\n")
+    exp = oracle.run(text, k, 2)["unitigs"]
+    for w in worlds:
+        r = subprocess.run([BCALM, "-in", str(fa), "-kmer-size", str(k), "-abundance-min", "2", "-nb-gpus", str(w), "-out", f"w{w}"], cwd=tmp_path,
+                           capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert r.returncode == 0, r.stdout + r.stderr
+        recs = _parse_fa(tmp_path / f"w{w}.unitigs.fa", k)
+        assert oracle_lib.canonical_set(oracle, recs, k) == exp
+        assert _fa_links(tmp_path / f"w{w}.unitigs.fa") == op.links([s for s, _ in recs], k)

@@ -156,7 +156,9 @@ def test_reference_checker_accepts_oracle_unitigs(oracle, tmp_path, key):
     assert "REPEATED" not in final
 
 
-@pytest.mark.parametrize("k,amin,n_reads,cfg,threads", [(31, 2, 4000, 3, 4), (21, 1, 2000, 2, 3), (27, 3, 3000, 3, 8), (30, 2, 3000, 3, 4), (8, 1, 300, 3, 3)])
+@pytest.mark.parametrize("k,amin,n_reads,cfg,threads", [(31, 2, 4000, 3, 4), (21, 1, 2000, 2, 3), (27, 3, 3000, 3, 8), (30, 2, 3000, 3, 4), (8, 1, 300, 3, 3),
+                                                           # two-word k-mers (round 5: config 4's CPU baseline is the same program as config 3's)
+                                                           (32, 2, 3000, 4, 4), (55, 2, 4000, 4, 8), (63, 1, 1500, 4, 3), (40, 2, 2000, 3 | 0x100, 5)])
 def test_cpu_mt_baseline_matches_oracle(oracle, k, amin, n_reads, cfg, threads):
     """oracle/cpu_mt.cpp (bench.py's multithreaded CPU baseline) against the oracle: counts, KC sum and the set digest"""
     from parity import set_digest
