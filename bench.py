@@ -235,7 +235,8 @@ def cli_end_to_end(lib, k, amin, read_len, gen_cfg, n_reads, device_id):
         nbytes = os.path.getsize(fa)
         t0 = time.perf_counter()
         p = subprocess.run([exe, "-in", fa, "-kmer-size", str(k), "-abundance-min", str(amin), "-out", os.path.join(tmp, "e2e")],
-                           capture_output=True, text=True, timeout=900, cwd=tmp)
+                           capture_output=True, text=True, timeout=900, cwd=tmp,
+                           env={x: y for x, y in os.environ.items() if x != "CDBG_FORCE_MULTI"})   # (--force-dist sets it for THIS process: the CLI would take it as its own test hook)
         wall = time.perf_counter() - t0
         ufa = os.path.join(tmp, "e2e.unitigs.fa")
         m = re.search(r"graph: (\d+) pieces -> (\d+) unitigs", p.stdout)
