@@ -20,7 +20,7 @@ void launch_scan_mode(cdbg_ctx* c, ScanParams& sp, uint64_t grid) {
     hipStream_t s = c->stream;
     const bool fast_scan = scan_is_fast(c);
     sp.n_tiles = grid;
-    if (fast_scan && c->k - c->m > SCANF_WNMAX) {           // the two-level window minimum (k_scan_fast.h, WNT = -1): k <= 127 with a long minimizer window
+    if (fast_scan && (c->k - c->m > SCANF_WNMAX || (c->k - c->m >= 17 && c->knobs.get("CDBG_SCAN_TWO_LEVEL")))) {   // the two-level window minimum (k_scan_fast.h, WNT = -1): k <= 127 with a long minimizer window (dev knob: any window of 17 keys and more)
         if (grid == 0) return;
         CDBG_LAUNCH((k_scan_fast<W, MODE, -1>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, -1>, SCAN_THREADS, SCANF_GRID) * CDBG_SCAN_GEN), SCAN_THREADS, s, sp);
         return;
@@ -72,7 +72,10 @@ void capped_capacities(const cdbg_ctx* c, double mean, uint64_t NPL, uint32_t& p
 constexpr uint64_t SIFT_GRID = CDBG_SIFT_GRID, T2_GRID = CDBG_T2_GRID, MP_GRID_W = CDBG_MP_GRID_W, MP_GRID_1 = CDBG_MP_GRID_1;
 // (launches of the stage: one-pass tier 1 of COUNT_GRID workgroups, tier 2 of at most SIFT_GRID, multi-pass retry, spill repair, HBM tables)
 inline uint64_t count_solid_slack(uint64_t NPL) {
-    return 4096 + (std::min<uint64_t>(NPL, COUNT_GRID) + 3 * std::min<uint64_t>(NPL, PERSISTENT_GRID) + SIFT_GRID + T2_GRID + 2 * (MP_GRID_1 > MP_GRID_W ? MP_GRID_1 : MP_GRID_W) + 768 + 5) * (uint64_t)COUNT_CHUNK;
+    // (no launch has more workgroups than partitions: a small input -- a test, a shard of few partitions -- reserves megabytes, not the 3 - 15 GB
+    //  that the grids' constants alone came to; fresh device memory costs 40 - 70 ms per GB)
+    auto lim = [NPL](uint64_t grid) { return std::min<uint64_t>(NPL, grid); };
+    return 4096 + (lim(COUNT_GRID) + 3 * lim(PERSISTENT_GRID) + lim(SIFT_GRID) + lim(T2_GRID) + 2 * lim(MP_GRID_1 > MP_GRID_W ? MP_GRID_1 : MP_GRID_W) + lim(768) + 5) * (uint64_t)COUNT_CHUNK;
 }
 // first attempt at the solid arrays' size (see count_impl): a third of the bound of one entry per abundance-min member k-mers
 inline uint64_t count_solid_first_cap(uint64_t members, int amin, uint64_t NPL) {
