@@ -88,7 +88,11 @@ int compact_impl(cdbg_ctx* c) {
             auto next_tier = [&](CompactParams& kt) { kt = base; kt.part_list = cur->p; kt.n_items = nbig; kt.big_list = oth->p; kt.big_count = cnt_oth; };
             auto flip = [&]() -> int { HIPCK(hipStreamSynchronize(s)); CK(read_u32(cnt_oth, &nbig)); std::swap(cur, oth); std::swap(cnt_cur, cnt_oth);
                                        HIPCK(hipMemsetAsync(cnt_oth, 0, 4 * sizeof(uint32_t), s)); return CDBG_OK; };
-            if (nbig && Cfg<W>::TSW2 > Cfg<W>::TSW) {
+            // (one-word k-mers, round 5: a junction table of 1024 slots with 10-bit end ids -- buckets of 257 .. 512 entries.  Hostile config-3 line:
+            //  compact 54.6 -> 44.8 ms, the workgroup tier is left with 24 K of its 770 K buckets; uniform config 3: 24.3 -> 23.2 ms.  CDBG_CW_TIER2 = 0: off)
+            bool tier0b = Cfg<W>::TSW2 > Cfg<W>::TSW && nbig;
+            if (const char* e = c->knobs.get("CDBG_CW_TIER2")) tier0b = tier0b && atoi(e) != 0;
+            if (tier0b) {
                 // tier 0b: the deferred buckets again one wave each, with a table twice the size (fewer waves per CU, but no
                 // workgroup barriers: at the config-4 share the workgroup tier below spent 44 ms on the 129..256-entry buckets)
                 CompactParams k0; next_tier(k0);
@@ -96,6 +100,15 @@ int compact_impl(cdbg_ctx* c) {
                 CompactWaveParams wp{ k0, nbig, reinterpret_cast<uint32_t*>(c->cursors.p + 5) };
                 const uint64_t wgrid = resident_grid(k_compact_wave<W, Cfg<W>::TSW2>, CW_THREADS, 256 * 2);
                 CDBG_LAUNCH((k_compact_wave<W, Cfg<W>::TSW2>), std::min<uint64_t>(((uint64_t)nbig + CW_THREADS / 64 - 1) / (CW_THREADS / 64), wgrid), CW_THREADS, s, wp);
+                CK(flip());
+            }
+            if constexpr (W == 2) if (nbig && c->knobs.get("CDBG_CW_TIER3") == nullptr) {
+                // tier 0c (two-word k-mers, round 5): once more one wave per bucket, 1024 slots (buckets of 257 .. 512 entries), before the workgroup tiers
+                CompactParams k0; next_tier(k0);
+                HIPCK(hipMemsetAsync(c->cursors.p + 5, 0, sizeof(uint64_t), s));
+                CompactWaveParams wp{ k0, nbig, reinterpret_cast<uint32_t*>(c->cursors.p + 5) };
+                const uint64_t wgrid = resident_grid(k_compact_wave<W, 1024>, CW_THREADS, 256 * 2);
+                CDBG_LAUNCH((k_compact_wave<W, 1024>), std::min<uint64_t>(((uint64_t)nbig + CW_THREADS / 64 - 1) / (CW_THREADS / 64), wgrid), CW_THREADS, s, wp);
                 CK(flip());
             }
             if (nbig) {                                      // tier 1: a workgroup per bucket, LDS table of TS slots

@@ -69,6 +69,9 @@ void capped_capacities(const cdbg_ctx* c, double mean, uint64_t NPL, uint32_t& p
 #ifndef CDBG_MP_GRID_1
 #define CDBG_MP_GRID_1 (256 * 48)                          // (one-word multi-pass kernel on the hostile line: count 92.4 -> 86.9 ms with 12288 instead of 3072 workgroups;
 #endif                                                   //  2048 instead of 256 for the wider kernels: neutral at k = 55, + 3 ms at k = 127 -- profiles/r04_ab_cfg3_count_grid.log)
+#ifndef CDBG_MP1_WIDE
+#define CDBG_MP1_WIDE 1                                    // (round 5: the multi-pass kernel of one-word k-mers with the 8192-slot table and 1024 threads as well, as the wider k-mers have it -- half the passes at 16 waves per CU: hostile line count 89.9 -> 80.6 ms; 0: 4096 slots, 512 threads)
+#endif
 constexpr uint64_t SIFT_GRID = CDBG_SIFT_GRID, T2_GRID = CDBG_T2_GRID, MP_GRID_W = CDBG_MP_GRID_W, MP_GRID_1 = CDBG_MP_GRID_1;
 // (launches of the stage: one-pass tier 1 of COUNT_GRID workgroups, tier 2 of at most SIFT_GRID, multi-pass retry, spill repair, HBM tables)
 inline uint64_t count_solid_slack(uint64_t NPL) {
@@ -375,7 +378,11 @@ int count_impl(cdbg_ctx* c) {
         CK(c->var_cap.alloc(NPS, false)); CK(c->var_pairs.alloc(2 * NPS, false)); CK(c->ovf_words.alloc(NPS, false));
         const double scale = (double)tiles / (double)ns, mean = (double)sample_records * scale / (double)NPS;
         capped_capacities(c, mean, NPS, part_cap, spill_cap);
-        OvfParams op{ c->part_count.p, c->var_cap.p, NPS, (float)scale, part_cap, c->part_off.p, NPS * (uint64_t)part_cap, c->ovf_words.p,
+        // uniform capacity of a skewed input: at least 3 x the mean, so that a partition the sample does NOT flag (fewer than twice the mean sample + 2
+        // sampled records) fits with near certainty; the flagged ones get their overflow region from their own count + 4 sigma
+        if (c->knobs.get("CDBG_PART_CAP") == nullptr) part_cap = std::max<uint32_t>(part_cap, ((uint32_t)(3.0 * mean) + 7u) & ~7u);
+        const float heavy_min = c->knobs.get("CDBG_PART_CAP") ? 0.0f : (float)(2.0 * mean / scale + 2.0);
+        OvfParams op{ c->part_count.p, c->var_cap.p, NPS, (float)scale, heavy_min, part_cap, c->part_off.p, NPS * (uint64_t)part_cap, c->ovf_words.p,
                       c->part_count.p, nullptr, RW, c->var_pairs.p, c->dstats.p + 28 };
         if (const char* e = c->knobs.get("CDBG_VAR_SCALE")) op.scale = (float)atof(e);   // test knob (with CDBG_PART_CAP): overflow regions far too small, so that partitions spill
         CDBG_LAUNCH(k_ovf_caps, (NPS + 255) / 256, 256, s, op);
@@ -598,7 +605,7 @@ int count_impl(cdbg_ctx* c) {
         CountParams rp1 = cp;
         rp1.part_list = retry_ptr; rp1.n_items = nretry;
         // (multi-word k-mers: the table of the second tier and 1024 threads -- half the passes at 16 waves per CU: 45 -> 39 ms at the config-5 share)
-        constexpr int TSG = W == 1 ? TS : 2 * TS, NTG = W == 1 ? Cfg<W>::NTC : 1024;
+        constexpr int TSG = (W == 1 && !CDBG_MP1_WIDE) ? TS : 2 * TS, NTG = (W == 1 && !CDBG_MP1_WIDE) ? Cfg<W>::NTC : 1024;
         CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(nretry, W == 1 ? MP_GRID_1 : MP_GRID_W), NTG, s, rp1);
     }
     if (n_spilled_parts) {                                   // spilled partitions: count their gathered copies
@@ -606,7 +613,7 @@ int count_impl(cdbg_ctx* c) {
         rp2.records = c->repair_recs.p; rp2.item_off = c->repair_off.p; rp2.part_list = c->repair_part.p; rp2.part_stride = 0;
         rp2.n_items = (uint32_t)n_spilled_parts; rp2.max_passes = 4096;
         if (const char* ev = c->knobs.get("CDBG_REPAIR_MAX_PASSES")) rp2.max_passes = (uint32_t)std::max(1, atoi(ev));   // (tests: a spilled partition that is deferred as well)
-        constexpr int TSG = W == 1 ? TS : 2 * TS, NTG = W == 1 ? Cfg<W>::NTC : 1024;
+        constexpr int TSG = (W == 1 && !CDBG_MP1_WIDE) ? TS : 2 * TS, NTG = (W == 1 && !CDBG_MP1_WIDE) ? Cfg<W>::NTC : 1024;
         CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(rp2.n_items, W == 1 ? MP_GRID_1 : MP_GRID_W), NTG, s, rp2);
     }
     uint32_t nbig = 0;
@@ -618,29 +625,18 @@ int count_impl(cdbg_ctx* c) {
         std::vector<uint32_t> bl(nbig); CK(read_u32(c->big_list.p, bl.data(), nbig));
         std::sort(bl.begin(), bl.end());
         std::vector<uint64_t> offs(nbig + 1, 0);
-        const uint64_t nmax = std::min<uint64_t>((uint64_t)RecFmt<W>::CAPB - c->k + 1, 255);   // (members per record: the scan clamps at the 8-bit field)
-        // (records of every listed partition: one bulk copy of the fill / offset array when the list is long -- a skewed input
-        //  lists 10^4 partitions, and a synchronous 4-byte copy each cost 77 ms per step at the hostile config-3 line)
-        std::vector<uint32_t> h_fill; std::vector<uint64_t> h_off;
-        if (nbig > 64) {
-            if (capped) { h_fill.resize(NPL); CK(read_u32(c->part_count.p, h_fill.data(), NPL)); }
-            else if (var) { h_off.resize(2 * NPL); CK(read_u64(c->var_pairs.p, h_off.data(), 2 * NPL)); }
-            else { h_off.resize(NPL + 1); CK(read_u64(c->part_off.p, h_off.data(), NPL + 1)); }
-        }
-        for (uint32_t i = 0; i < nbig; ++i) {
-            uint64_t nrec_p;
-            if (!h_fill.empty()) nrec_p = h_fill[bl[i]];
-            else if (!h_off.empty()) nrec_p = var ? h_off[2 * (size_t)bl[i] + 1] - h_off[2 * (size_t)bl[i]] : h_off[bl[i] + 1] - h_off[bl[i]];
-            else if (capped) { uint32_t f = 0; CK(read_u32(c->part_count.p + bl[i], &f)); nrec_p = f; }
-            else if (var) { uint64_t po[2]; CK(read_u64(c->var_pairs.p + 2 * (size_t)bl[i], po, 2)); nrec_p = po[1] - po[0]; }
-            else { uint64_t po[2]; CK(read_u64(c->part_off.p + bl[i], po, 2)); nrec_p = po[1] - po[0]; }
-            const uint64_t occ = nrec_p * nmax;
-            offs[i + 1] = offs[i] + pow2_at_least(2 * occ + 4 * 256);
-        }
+        // table of a listed partition: twice its member k-mers (an upper bound of its distinct ones), counted on the device (k_big_members).
+        // Round 4 took records x the largest record of the format: 3 - 5 x too many slots, which one workgroup clears and sweeps
+        HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
+        DBuf<uint64_t> d_members; CK(d_members.alloc(nbig, true));
+        { CountParams mp = cp; mp.part_list = c->big_list.p; mp.n_items = nbig; mp.max_sub = (uint32_t)RW;   // (max_sub: words per record for this launch)
+          BigMembersParams bm{ mp, d_members.p };
+          CDBG_LAUNCH(k_big_members, nbig, 256, s, bm); }
+        std::vector<uint64_t> h_members(nbig); CK(read_u64(d_members.p, h_members.data(), nbig));
+        for (uint32_t i = 0; i < nbig; ++i) offs[i + 1] = offs[i] + pow2_at_least(2 * h_members[i] + 4 * 256);
         CK(g_keys.alloc(offs[nbig] * W, false)); CK(g_cnt.alloc(offs[nbig], false));
         CK(big_off.alloc(nbig + 1, false));
         HIPCK(hipMemcpy(big_off.p, offs.data(), (nbig + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-        HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
         CountParams bp = cp;
         bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_cnt = g_cnt.p; bp.big_off = big_off.p;
         bp.n_items = nbig; bp.max_passes = 1;

@@ -93,6 +93,8 @@ struct DBuf {                                   // owned device array
             if (want * sizeof(T) >= DevPool::MIN_BYTES) p = (T*)dev_pool().take(want * sizeof(T), &got);
             if (p) cap = got / sizeof(T);
             else {
+                static const bool dbg = getenv("CDBG_DEBUG_ALLOC") != nullptr;   // dev aid (read once per process): every fresh allocation of 256 MB and more, with what the card has free
+                if (dbg && want * sizeof(T) >= (256u << 20)) { size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot); fprintf(stderr, "[alloc] %8.2f GB (free %7.2f of %7.2f GB, pool %7.2f GB)\n", (double)(want * sizeof(T)) / 1e9, (double)fr / 1e9, (double)tot / 1e9, (double)dev_pool().held[DevPool::device()] / 1e9); }
                 hipError_t e = hipMalloc(&p, want * sizeof(T));
                 // (pooled blocks of other shapes may be in the way.  The failed call leaves its error as the thread's LAST error: read it away, or the
                 //  next launch check -- hipGetLastError() -- reports an out-of-memory that was dealt with here; found by the round-5 fuzz session)
@@ -142,7 +144,7 @@ constexpr int TS_COMPACT_1 = CDBG_TSK1, TS_COMPACT_2 = 512, TS_COMPACT_4 = 512;
 #endif
 template <int W> struct Cfg { static constexpr int TSC = 1024, TSK = 256, TSK2 = 512, NTC = 512, TSW = 128, TSW2 = 256; };
 // TSW: slots of the wave-per-bucket compaction tier (buckets of at most TSW / 2 entries; k_compact_wave.h)
-template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1, TSK2 = 2 * TS_COMPACT_1, NTC = CDBG_NTC1, TSW = 512, TSW2 = 512; };   // (TSW2 == TSW: no second wave tier)
+template <> struct Cfg<1> { static constexpr int TSC = TS_COUNT_1, TSK = TS_COMPACT_1, TSK2 = 2 * TS_COMPACT_1, NTC = CDBG_NTC1, TSW = 512, TSW2 = 1024; };   // (TSW2: the second wave tier, buckets of 257 .. 512 entries: round 5)
 #ifndef CDBG_TSW2
 #define CDBG_TSW2 256
 #endif
@@ -208,7 +210,7 @@ int glue_table_slots(uint64_t want, uint32_t* out) {
 struct Knobs {
     std::vector<std::pair<std::string, std::string>> kv;
     void snapshot() {
-        static const char* const NAMES[] = { "CDBG_SCAN_TWO_LEVEL", "CDBG_COUNT_MAX_SUB", "CDBG_VAR_RESAMPLE", "CDBG_EXACT_NO_CUR32", "CDBG_SOLID_FIRST_TINY", "CDBG_PREWARM_MIN_BYTES", "CDBG_NO_PREWARM", "CDBG_DEBUG_SEGHIST", "CDBG_FAST_MAX_RECORDS", "CDBG_FAST_SKIP2_Q8", "CDBG_FAST_SKIP_Q8", "CDBG_FORCE_MULTI", "CDBG_GENERIC_SCAN", "CDBG_GLUE_LOG", "CDBG_GLUE_RANK", "CDBG_GLUE_REPLICATED", "CDBG_GLUE_TABLE", "CDBG_JOIN_LOG_JB", "CDBG_NO_COUNT_TIER2", "CDBG_NO_SIFT", "CDBG_NO_SPLIT", "CDBG_PART_CAP", "CDBG_REPAIR_MAX_PASSES", "CDBG_SCAN_MODE", "CDBG_STAGE_BYTES", "CDBG_STREAM_BATCH_TILES", "CDBG_STREAM_MIN_BYTES", "CDBG_VAR_SCALE", "CDBG_WALK_MAX" };
+        static const char* const NAMES[] = { "CDBG_CW_TIER3", "CDBG_CW_TIER2", "CDBG_SCAN_TWO_LEVEL", "CDBG_COUNT_MAX_SUB", "CDBG_VAR_RESAMPLE", "CDBG_EXACT_NO_CUR32", "CDBG_SOLID_FIRST_TINY", "CDBG_PREWARM_MIN_BYTES", "CDBG_NO_PREWARM", "CDBG_DEBUG_SEGHIST", "CDBG_FAST_MAX_RECORDS", "CDBG_FAST_SKIP2_Q8", "CDBG_FAST_SKIP_Q8", "CDBG_FORCE_MULTI", "CDBG_GENERIC_SCAN", "CDBG_GLUE_LOG", "CDBG_GLUE_RANK", "CDBG_GLUE_REPLICATED", "CDBG_GLUE_TABLE", "CDBG_JOIN_LOG_JB", "CDBG_NO_COUNT_TIER2", "CDBG_NO_SIFT", "CDBG_NO_SPLIT", "CDBG_PART_CAP", "CDBG_REPAIR_MAX_PASSES", "CDBG_SCAN_MODE", "CDBG_STAGE_BYTES", "CDBG_STREAM_BATCH_TILES", "CDBG_STREAM_MIN_BYTES", "CDBG_VAR_SCALE", "CDBG_WALK_MAX" };
         for (const char* n : NAMES) if (const char* e = getenv(n)) kv.emplace_back(n, e);
     }
     const char* get(const char* name) const { for (const auto& p : kv) if (p.first == name) return p.second.c_str(); return nullptr; }

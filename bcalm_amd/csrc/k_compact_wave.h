@@ -25,9 +25,13 @@ constexpr uint32_t CW_BATCH = 8;                         // buckets handed out p
 constexpr uint16_t CWL_CONF = 1u << 14, CWL_POSTED = 1u << 15;
 constexpr uint16_t CWN_NONE = 0xFFFFu, CWN_FOREIGN = 0xFFFEu;
 
+template <int TSW> struct CwSlot {                      // field layout of a junction-table slot (see cw_jt_register)
+    static constexpr uint32_t EB = TSW > 512 ? 10u : 9u, SIDE_BIT = 6u + 2u * EB, TAG_MASK = ~((2u << SIDE_BIT) - 1u);
+};
 template <int W, int TSW>
 struct CompactWaveLds {                                 // one per wave
     static constexpr int EMAX = TSW / 2;
+    static_assert(TSW <= 512 || W <= 2, "the 1024-slot wave tier: one- and two-word k-mers (16-bit base offsets: EMAX * k < 65536)");
     uint64_t ekeys[EMAX * W];                           // the bucket's k-mers in entry order: word i of entry e at [i * EMAX + e]
     uint32_t jt[TSW];                                   // junction table: one slot per junction that an end of the bucket registers at (cw_jt_*);
                                                         // once the links are known, its memory holds the terminal ends of home entries (walk 1 work list)
@@ -55,6 +59,8 @@ CDBG_DEV Kmer<W> cw_key(const CompactWaveLds<W, TSW>& L, uint32_t e) {
 //   bits [0,3) / [3,6)   ends registered on side 0 / 1 (side 0: the end's outgoing (k-1)-suffix IS the canonical junction)
 //   bits [6,15) / [15,24) the first end registered on side 0 / 1      bit 24  the side of the end that claimed the slot
 //   bits [25,32)          tag            (a claimed slot is never 0: the claimer's side counts 1)
+// (a table of 1024 slots -- buckets of up to 512 entries, round 5: the second one-wave tier of one-word k-mers -- has 10-bit end ids:
+//  [6,16) / [16,26), side in bit 26, a 5-bit tag: CwSlot)
 // Even k: a k-mer that is its own reverse complement reaches the junction with both of its ends from the same side, so
 // that side counts 2 and the junction is never 1-in/1-out (the two edges (s,+) / (s,-) of the overlap table, .md:41-46).
 // Odd k: a junction that is its own reverse complement has one side only -- never 1-in/1-out either (every end there
@@ -71,28 +77,29 @@ CDBG_DEV Kmer<W> cw_junction_of(const Kmer<W>& x, uint32_t end, int k, uint32_t&
 // registers end `it` (side known) at junction jc; returns the slot, or NONE32 when the table is too full (the caller defers the bucket)
 template <int W, int TSW>
 CDBG_DEV uint32_t cw_jt_register(CompactWaveLds<W, TSW>& L, const Kmer<W>& jc, const Kmer<W>& j, const Kmer<W>& r, uint32_t side, uint32_t it, int k) {
-    constexpr int LOG = TSW == 512 ? 9 : TSW == 256 ? 8 : TSW == 128 ? 7 : -1;
-    static_assert(LOG > 0, "wave table size (end ids are 9-bit fields of a slot)");
+    constexpr int LOG = TSW == 1024 ? 10 : TSW == 512 ? 9 : TSW == 256 ? 8 : TSW == 128 ? 7 : -1;
+    static_assert(LOG > 0, "wave table size (end ids are 9- or 10-bit fields of a slot)");
+    constexpr uint32_t EB = CwSlot<TSW>::EB, SIDE_BIT = CwSlot<TSW>::SIDE_BIT, TAG_MASK = CwSlot<TSW>::TAG_MASK;
     const uint32_t h = jc.hash_lds();
     uint32_t s = h >> (32 - LOG);
-    const uint32_t tag = (h << LOG) & 0xFE000000u;               // the 7 hash bits below the slot index
-    const uint32_t mine = tag | (side << 24) | (it << (6u + 9u * side)) | (1u << (3u * side));
+    const uint32_t tag = (h << LOG) & TAG_MASK;                  // the 7 (5: 1024 slots) hash bits below the slot index
+    const uint32_t mine = tag | (side << SIDE_BIT) | (it << (6u + EB * side)) | (1u << (3u * side));
     uint32_t probes = 0, res = NONE32; bool done = false;
 #pragma clang loop unroll(disable)
     do {
         const uint32_t old = atomic_cas_u32(&L.jt[s], 0u, mine);
         bool same = false;
-        if (old != 0u && (old & 0xFE000000u) == tag) {            // same tag: is it the same junction?  ask the end that claimed the slot
+        if (old != 0u && (old & TAG_MASK) == tag) {               // same tag: is it the same junction?  ask the end that claimed the slot
             // (no reverse complement needed: the stored k-mer x' of that end touches its junction with its (k-1)-suffix -- right
             //  end -- or its (k-1)-prefix -- left end -- as written, and the junctions are equal exactly when that is j or rc(j))
-            const uint32_t cs = (old >> 24) & 1u, rid = (old >> (6u + 9u * cs)) & 0x1FFu;
+            const uint32_t cs = (old >> SIDE_BIT) & 1u, rid = (old >> (6u + EB * cs)) & ((1u << EB) - 1u);
             const Kmer<W> xr = cw_key<W, TSW>(L, rid >> 1);
             const Kmer<W> c = (rid & 1u) == END_RIGHT ? suffix_km1<W>(xr, k) : prefix_km1<W>(xr, k);
             same = (c == j) | (c == r);
         }
         if (same) {
             const uint32_t before = atomic_add_u32(&L.jt[s], 1u << (3u * side));
-            if (((before >> (3u * side)) & 7u) == 0u) atomic_or_u32(&L.jt[s], it << (6u + 9u * side));   // the first end on this side
+            if (((before >> (3u * side)) & 7u) == 0u) atomic_or_u32(&L.jt[s], it << (6u + EB * side));   // the first end on this side
         }
         done = (old == 0u) | same;
         res = done ? s : res;
@@ -229,7 +236,7 @@ CDBG_DEV void compact_bucket_wave(const CompactParams& P, CompactWaveLds<W, TSW>
             const uint32_t side = w >> 15;
             const uint32_t v = L.jt[w & 0x7FFFu];
             const uint32_t own = (v >> (3u * side)) & 7u, opp = (v >> (3u * (1u - side))) & 7u;
-            const uint32_t yy = (v >> (6u + 9u * (1u - side))) & 0x1FFu, y = yy >> 1, ye = yy & 1u;
+            const uint32_t yy = (v >> (6u + CwSlot<TSW>::EB * (1u - side))) & ((1u << CwSlot<TSW>::EB) - 1u), y = yy >> 1, ye = yy & 1u;
             if (own == 1u && opp == 1u && y != e) {      // (never through the node's own other end)
                 const bool yhome = !(L.cnt[y] & TRAV_FLAG);
                 if (home && yhome) link = LNK_INTERNAL | (ye << 2) | (y << 3);
@@ -435,7 +442,7 @@ template <int W, int TSW>
 #ifndef CDBG_CW_WAVES4
 #define CDBG_CW_WAVES4 3
 #endif
-__global__ void __launch_bounds__(CW_THREADS, W == 1 ? CDBG_CW_WAVES1 : W == 2 ? (TSW > 256 ? 2 : CDBG_CW_WAVES2) : (TSW > 256 ? 2 : CDBG_CW_WAVES4)) k_compact_wave(CompactWaveParams WP) {
+__global__ void __launch_bounds__(CW_THREADS, W == 1 ? (TSW > 512 ? 3 : CDBG_CW_WAVES1) : W == 2 ? (TSW > 256 ? 2 : CDBG_CW_WAVES2) : (TSW > 256 ? 2 : CDBG_CW_WAVES4)) k_compact_wave(CompactWaveParams WP) {
     CDBG_SHARED CompactWaveLds<W, TSW> Ls[CW_THREADS / 64];
     const CompactParams& P = WP.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)uni_u32((uint32_t)tid >> 6);

@@ -664,6 +664,24 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(GLOBAL ? 1024 : (size_t
     if (threadIdx.x == 0) for (int i = 0; i < 4; ++i) if (acc[i]) atomic_add_u64(&P.stats[i], acc[i]);
 }
 
+// member k-mers of every LISTED partition (the HBM-table pass sizes its tables from them: round 5 -- records x the largest record a format
+// allows over-sized them 3 - 5 x, and one workgroup clears and sweeps a table: at k = 127 a partition of a repeat's locus had 600 MB of it)
+struct BigMembersParams { CountParams c; uint64_t* members; };
+__global__ void k_big_members(BigMembersParams B) {
+    const CountParams& P = B.c;
+    const uint32_t item = blockIdx.x;
+    const uint32_t p = P.part_list[item];
+    uint64_t rec0, rec1;
+    if (P.part_stride) { const uint32_t f = P.part_fill[p]; rec0 = (uint64_t)p * P.part_stride; rec1 = rec0 + (f > P.part_stride ? 0u : f); }
+    else if (P.part_pairs) { rec0 = P.part_off[2ull * p]; rec1 = P.part_off[2ull * p + 1]; }
+    else { rec0 = P.part_off[p]; rec1 = P.part_off[p + 1]; }
+    uint64_t mine = 0;
+    const int RW = (int)P.max_sub;                       // (reused field: words per record, set by the host for this launch)
+    for (uint64_t i = rec0 + threadIdx.x; i < rec1; i += blockDim.x) mine += P.records[i * RW] & 0xFFu;
+    mine = wave_sum_u64(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomic_add_u64(&B.members[item], mine);
+}
+
 // ---- capped-layout repair: gather a spilled partition's region + spill records contiguously ----
 // Entirely on the device (the host only reads two totals): partitions whose fill exceeds the region capacity are
 // flagged and compacted into a list (two prefix sums), their regions are copied into one array of back-to-back runs, and
@@ -729,7 +747,7 @@ __global__ void k_repair_scatter(RepairParams P) {       // one thread per spill
 //  is one run again -- and writes begin / end of every partition's records for the count kernels (part_pairs; spilled: empty, the
 //  repair launch counts them).
 struct OvfParams {
-    const uint32_t* sample; uint32_t* tcap; uint64_t n; float scale; uint32_t part_cap;
+    const uint32_t* sample; uint32_t* tcap; uint64_t n; float scale; float heavy_min; uint32_t part_cap;
     const uint64_t* toff; uint64_t area0; uint64_t* words;
     const uint32_t* fill; uint64_t* records; int RW; uint64_t* pairs; uint64_t* stats;   // stats[0] += records offered, stats[1] += partitions that used their overflow region
 };
@@ -740,7 +758,10 @@ __global__ void k_ovf_caps(OvfParams P) {
     float est = P.scale * (s + 4.0f * sqrtf(s) + 2.0f) + 8.0f;
     if (est > (float)(OVF_CAP_MASK - 15ULL)) est = (float)(OVF_CAP_MASK - 15ULL);
     const uint32_t c = ((uint32_t)est + 7u) & ~7u;
-    P.tcap[p] = c > P.part_cap ? c : 0u;
+    // heavy: sampled well above what a partition of the uniform part of the input shows (heavy_min: twice the mean sample + 2).  The margins of a
+    // 1-in-64 sample are wide -- without this bar the typical partition (6 sampled records at config 3: up to 1139 with + 4 sigma) counted as heavy
+    // and the region came to 2.4 x the uniform layout's (k = 55, 125 M reads: 189 GB, and the step ran out of memory).
+    P.tcap[p] = (s >= P.heavy_min && c > P.part_cap) ? c : 0u;
 }
 __global__ void k_ovf_words(OvfParams P) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

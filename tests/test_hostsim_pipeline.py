@@ -453,3 +453,27 @@ def test_solid_capacity_second_attempt(oracle, sim, monkeypatch):
     for k, amin, n, L, cfg in ((31, 1, 3000, 150, 3), (55, 1, 1500, 150, 4), (127, 1, 300, 500, 5)):
         got = assert_parity(oracle, sim, oracle.synth_reads(n, L, cfg), k, amin)
         assert got["stats"]["n_solid"] > (1 << 15)
+
+
+def _mid_bucket_text(k, glen, seed):
+    """a genome whose buckets hold a few hundred solid k-mers each (abundance-min 1), with an inverted repeat, a direct repeat, a two-letter stretch and a
+    homopolymer run among them: buckets of 257 .. 512 entries for the second one-wave compaction tier of one-word k-mers"""
+    rng = random.Random(seed)
+    comp = str.maketrans("ACGT", "TGCA")
+    g = "".join(rng.choice("ACGT") for _ in range(glen))
+    low = "".join(rng.choice("AC") for _ in range(glen // 10))
+    return "\n".join([g, low, g[300:300 + 3 * k][::-1].translate(comp) + "A" * (2 * k) + g[700:700 + 2 * k], g[100:100 + 2 * k], g[glen // 2:glen // 2 + 400]]) + "\n"
+
+
+@pytest.mark.parametrize("k,glen,log_np", [(31, 12000, 5), (21, 6000, 4), (15, 5000, 4), (8, 3000, 3), (30, 9000, 5), (31, 40000, 7)])
+@pytest.mark.parametrize("tier2", ["1", "0"])
+def test_second_wave_tier_one_word(oracle, sim, k, glen, log_np, tier2, monkeypatch):
+    """round 5: buckets of 257 .. 512 entries of one-word k-mers through a second one-wave tier (junction table of 1024 slots, 10-bit end ids in a
+    slot) instead of the workgroup tier; CDBG_CW_TIER2 = 1 / 0 forces / forbids it (by default it runs when the first tier defers many buckets)"""
+    from bcalm_amd import api
+    from parity import assert_verified
+    monkeypatch.setenv("CDBG_CW_TIER2", tier2)
+    text = _mid_bucket_text(k, glen, glen + k)
+    assert_parity(oracle, sim, text, k, 1, log2_partitions=log_np)
+    gg = api.Graph(k, 1, lib=sim, log2_partitions=log_np)
+    gg.push_text(text); gg.run(); assert_verified(gg); gg.close()
