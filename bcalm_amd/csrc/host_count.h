@@ -541,7 +541,8 @@ int count_impl(cdbg_ctx* c) {
     cp.big_list = c->big_list.p; cp.big_count = c->big_count.p; cp.error = c->derr.p;
     hm.mark("count: solid buffers");
     CK(t.start(s));
-    cp.n_items = (uint32_t)NPL; cp.max_passes = 64;
+    cp.n_items = (uint32_t)NPL; cp.max_passes = 16;                // (round 5: was 64 -- beyond 16 LDS passes the HBM-table pass is cheaper: hostile k = 127 share 4.2 -> 2.0 s, k = 55 1.03 -> 0.85 s)
+    if (const char* e = c->knobs.get("CDBG_MAX_PASSES")) cp.max_passes = (uint32_t)std::max(1, atoi(e));   // dev knob: LDS passes before a partition goes to the HBM-table pass
     if (const char* e = c->knobs.get("CDBG_COUNT_MAX_SUB")) { uint32_t v = (uint32_t)std::max(1, atoi(e)); while (v & (v - 1)) v &= v - 1; cp.max_sub = std::min(v, 16u); }   // dev knob: 1, 2, 4, 8, 16
     // one-pass kernel over all partitions; the ones whose distinct k-mers do not fit the LDS table at once come back on
     // the retry list and go through the multi-pass kernel
