@@ -102,8 +102,8 @@ int compact_impl(cdbg_ctx* c) {
                 CDBG_LAUNCH((k_compact_wave<W, Cfg<W>::TSW2>), std::min<uint64_t>(((uint64_t)nbig + CW_THREADS / 64 - 1) / (CW_THREADS / 64), wgrid), CW_THREADS, s, wp);
                 CK(flip());
             }
-            if constexpr (W == 2) if (nbig && c->knobs.get("CDBG_CW_TIER3") == nullptr) {
-                // tier 0c (two-word k-mers, round 5): once more one wave per bucket, 1024 slots (buckets of 257 .. 512 entries), before the workgroup tiers
+            if constexpr (W >= 2 && W <= 4) if (nbig && c->knobs.get("CDBG_CW_TIER3") == nullptr) {
+                // tier 0c (k-mers of two to four words, round 5): once more one wave per bucket, 1024 slots (buckets of 257 .. 512 entries), before the workgroup tiers
                 CompactParams k0; next_tier(k0);
                 HIPCK(hipMemsetAsync(c->cursors.p + 5, 0, sizeof(uint64_t), s));
                 CompactWaveParams wp{ k0, nbig, reinterpret_cast<uint32_t*>(c->cursors.p + 5) };

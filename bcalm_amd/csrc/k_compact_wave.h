@@ -31,7 +31,7 @@ template <int TSW> struct CwSlot {                      // field layout of a jun
 template <int W, int TSW>
 struct CompactWaveLds {                                 // one per wave
     static constexpr int EMAX = TSW / 2;
-    static_assert(TSW <= 512 || W <= 2, "the 1024-slot wave tier: one- and two-word k-mers (16-bit base offsets: EMAX * k < 65536)");
+    static_assert(TSW <= 512 || W <= 4, "the 1024-slot wave tier: k <= 127 (16-bit base offsets: EMAX * k = 512 * 127 < 65536)");
     uint64_t ekeys[EMAX * W];                           // the bucket's k-mers in entry order: word i of entry e at [i * EMAX + e]
     uint32_t jt[TSW];                                   // junction table: one slot per junction that an end of the bucket registers at (cw_jt_*);
                                                         // once the links are known, its memory holds the terminal ends of home entries (walk 1 work list)

@@ -469,14 +469,17 @@ def test_edge_conservation_sees_over_compaction_gpu(oracle, hip, k, amin, n, L, 
     assert planted >= 1
 
 
-@pytest.mark.parametrize("k,glen,log_np", [(31, 400000, 10), (21, 200000, 9), (15, 60000, 8), (30, 300000, 10)])
+@pytest.mark.parametrize("k,glen,log_np", [(31, 400000, 10), (21, 200000, 9), (15, 60000, 8), (30, 300000, 10), (55, 400000, 10), (96, 200000, 9), (127, 200000, 9)])
 @pytest.mark.parametrize("tier2", ["1", "0"])
 def test_second_wave_tier_one_word_gpu(oracle, hip, k, glen, log_np, tier2, monkeypatch):
     """buckets of 257 .. 512 entries of one-word k-mers through the second one-wave compaction tier (1024-slot junction table) on the device"""
     import bcalm_amd
     from parity import assert_verified
     from test_hostsim_pipeline import _mid_bucket_text
-    monkeypatch.setenv("CDBG_CW_TIER2", tier2)
+    if k <= 31:
+        monkeypatch.setenv("CDBG_CW_TIER2", tier2)
+    elif tier2 == "0":
+        monkeypatch.setenv("CDBG_CW_TIER3", "off")
     text = _mid_bucket_text(k, glen, glen + k)
     assert_parity(oracle, hip, text, k, 1, log2_partitions=log_np)
     gg = bcalm_amd.Graph(k, 1, lib=hip, log2_partitions=log_np)
