@@ -602,24 +602,12 @@ int count_impl(cdbg_ctx* c) {
         retry_ptr = c->retry_list2.p;
     }
     c->st.n_multipass_partitions = nretry;
-    // slabs of the multi-pass kernel's EXPANDED passes (k_count.h): one per workgroup of its launches, for partitions of up to xp_cap member k-mers
-    // (a repeat's minimizer locus: 0.2 M at k = 31, 0.6 M at k = 55, 1.7 M at k = 127); obtained only when there is something to count that way
-#ifdef CDBG_HOSTSIM
-    constexpr uint64_t XP_CAP = 1ull << 17;                  // (simulator: test sizes -- partitions beyond the slab keep walking their records)
-    const uint64_t mp_grid = 16;
-#else
-    constexpr uint64_t XP_CAP = W == 1 ? (1ull << 19) : (1ull << 21);
-    const uint64_t mp_grid = W == 1 ? std::min<uint64_t>(MP_GRID_1, 1024) : MP_GRID_W;      // (W = 1: the launch's workgroup count does not matter to its time -- 2048 .. 12288 measured)
-#endif
-    if ((nretry || n_spilled_parts) && c->knobs.get("CDBG_NO_EXPAND") == nullptr) {
-        if (c->xp_slab.alloc(mp_grid * (uint64_t)(W + 1) * XP_CAP, false) == CDBG_OK) { cp.xp_buf = c->xp_slab.p; cp.xp_cap = XP_CAP; }
-    }
     if (nretry) {
         CountParams rp1 = cp;
         rp1.part_list = retry_ptr; rp1.n_items = nretry;
         // (multi-word k-mers: the table of the second tier and 1024 threads -- half the passes at 16 waves per CU: 45 -> 39 ms at the config-5 share)
         constexpr int TSG = (W == 1 && !CDBG_MP1_WIDE) ? TS : 2 * TS, NTG = (W == 1 && !CDBG_MP1_WIDE) ? Cfg<W>::NTC : 1024;
-        CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(nretry, cp.xp_buf ? mp_grid : (W == 1 ? MP_GRID_1 : MP_GRID_W)), NTG, s, rp1);
+        CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(nretry, W == 1 ? MP_GRID_1 : MP_GRID_W), NTG, s, rp1);
     }
     if (n_spilled_parts) {                                   // spilled partitions: count their gathered copies
         CountParams rp2 = cp;
@@ -627,7 +615,7 @@ int count_impl(cdbg_ctx* c) {
         rp2.n_items = (uint32_t)n_spilled_parts; rp2.max_passes = 4096;
         if (const char* ev = c->knobs.get("CDBG_REPAIR_MAX_PASSES")) rp2.max_passes = (uint32_t)std::max(1, atoi(ev));   // (tests: a spilled partition that is deferred as well)
         constexpr int TSG = (W == 1 && !CDBG_MP1_WIDE) ? TS : 2 * TS, NTG = (W == 1 && !CDBG_MP1_WIDE) ? Cfg<W>::NTC : 1024;
-        CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(rp2.n_items, cp.xp_buf ? mp_grid : (W == 1 ? MP_GRID_1 : MP_GRID_W)), NTG, s, rp2);
+        CDBG_LAUNCH((k_count<W, TSG, NTG, false>), std::min<uint64_t>(rp2.n_items, W == 1 ? MP_GRID_1 : MP_GRID_W), NTG, s, rp2);
     }
     uint32_t nbig = 0;
     HIPCK(hipStreamSynchronize(s));
@@ -668,8 +656,7 @@ int count_impl(cdbg_ctx* c) {
     break;
     }
     CK(check_device_error(c, "count"));
-    uint64_t cs[5]; CK(read_u64(c->dstats.p, cs, 5));
-    if (HostMarks::enabled()) fprintf(stderr, "[host] count: %llu partitions through the multi-pass kernel, %llu of them with expanded passes\n", (unsigned long long)c->st.n_multipass_partitions, (unsigned long long)cs[4]);
+    uint64_t cs[4]; CK(read_u64(c->dstats.p, cs, 4));
 #ifdef CDBG_PROFILE_PHASES
     { uint64_t ph[16]; CK(read_u64(c->dstats.p + 8, ph, 16));
       for (int w = 0; w < 2; ++w) fprintf(stderr, "k_count_fast phase cycles, %s wave, summed over WGs: loop-end->top %llu | wait own records + stage %llu | insert %llu | barrier A %llu | sweep %llu | barrier B %llu\n", w ? "last" : "first",

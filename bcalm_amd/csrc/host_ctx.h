@@ -210,7 +210,7 @@ int glue_table_slots(uint64_t want, uint32_t* out) {
 struct Knobs {
     std::vector<std::pair<std::string, std::string>> kv;
     void snapshot() {
-        static const char* const NAMES[] = { "CDBG_NO_EXPAND", "CDBG_MAX_PASSES", "CDBG_CW_TIER3", "CDBG_CW_TIER2", "CDBG_SCAN_TWO_LEVEL", "CDBG_COUNT_MAX_SUB", "CDBG_VAR_RESAMPLE", "CDBG_EXACT_NO_CUR32", "CDBG_SOLID_FIRST_TINY", "CDBG_PREWARM_MIN_BYTES", "CDBG_NO_PREWARM", "CDBG_DEBUG_SEGHIST", "CDBG_FAST_MAX_RECORDS", "CDBG_FAST_SKIP2_Q8", "CDBG_FAST_SKIP_Q8", "CDBG_FORCE_MULTI", "CDBG_GENERIC_SCAN", "CDBG_GLUE_LOG", "CDBG_GLUE_RANK", "CDBG_GLUE_REPLICATED", "CDBG_GLUE_TABLE", "CDBG_JOIN_LOG_JB", "CDBG_NO_COUNT_TIER2", "CDBG_NO_SIFT", "CDBG_NO_SPLIT", "CDBG_PART_CAP", "CDBG_REPAIR_MAX_PASSES", "CDBG_SCAN_MODE", "CDBG_STAGE_BYTES", "CDBG_STREAM_BATCH_TILES", "CDBG_STREAM_MIN_BYTES", "CDBG_VAR_SCALE", "CDBG_WALK_MAX" };
+        static const char* const NAMES[] = { "CDBG_MAX_PASSES", "CDBG_CW_TIER3", "CDBG_CW_TIER2", "CDBG_SCAN_TWO_LEVEL", "CDBG_COUNT_MAX_SUB", "CDBG_VAR_RESAMPLE", "CDBG_EXACT_NO_CUR32", "CDBG_SOLID_FIRST_TINY", "CDBG_PREWARM_MIN_BYTES", "CDBG_NO_PREWARM", "CDBG_DEBUG_SEGHIST", "CDBG_FAST_MAX_RECORDS", "CDBG_FAST_SKIP2_Q8", "CDBG_FAST_SKIP_Q8", "CDBG_FORCE_MULTI", "CDBG_GENERIC_SCAN", "CDBG_GLUE_LOG", "CDBG_GLUE_RANK", "CDBG_GLUE_REPLICATED", "CDBG_GLUE_TABLE", "CDBG_JOIN_LOG_JB", "CDBG_NO_COUNT_TIER2", "CDBG_NO_SIFT", "CDBG_NO_SPLIT", "CDBG_PART_CAP", "CDBG_REPAIR_MAX_PASSES", "CDBG_SCAN_MODE", "CDBG_STAGE_BYTES", "CDBG_STREAM_BATCH_TILES", "CDBG_STREAM_MIN_BYTES", "CDBG_VAR_SCALE", "CDBG_WALK_MAX" };
         for (const char* n : NAMES) if (const char* e = getenv(n)) kv.emplace_back(n, e);
     }
     const char* get(const char* name) const { for (const auto& p : kv) if (p.first == name) return p.second.c_str(); return nullptr; }
@@ -258,7 +258,7 @@ struct cdbg_ctx {
     DBuf<uint32_t> piece_n; DBuf<uint64_t> piece_kc, piece_boff; DBuf<uint8_t> piece_bases; DBuf<uint64_t> cursors;
     DBuf<uint64_t> glue_keys; DBuf<uint32_t> glue_a, glue_b, glue_conf; uint32_t glue_cap = 0;   // (fallback junction table)
     DBuf<uint32_t> retry_list2;                              // partitions that did not fit the second count tier either
-    DBuf<uint32_t> var_cap; DBuf<uint64_t> var_pairs, ovf_words, xp_slab;        // single-pass layout of skewed inputs: region capacities, begin / end of every partition's records
+    DBuf<uint32_t> var_cap; DBuf<uint64_t> var_pairs, ovf_words;        // single-pass layout of skewed inputs: region capacities, begin / end of every partition's records
     DBuf<uint64_t> split_keys, vseg_off, split_cur; DBuf<uint32_t> split_cnt, vseg_n, vlist_a, vlist_b;   // second-level bucket split (k_split.h)
     DBuf<uint64_t> repair_recs, repair_off, rp_idx; DBuf<uint32_t> repair_part, rp_flag, rp_size, rp_fill;   // capped-scan spill repair (kept: no allocation per step)
     DBuf<uint32_t> jfill; DBuf<uint64_t> jrecs;              // join buckets

@@ -37,9 +37,7 @@ constexpr uint32_t COUNT_MAX = 0x7FFFFFFFu, COUNT_SAT = COUNT_MAX - 4095u;
 #ifndef CDBG_COUNT_MAX_SUB
 #define CDBG_COUNT_MAX_SUB 1
 #endif
-constexpr uint32_t COUNT_MAX_SUB = CDBG_COUNT_MAX_SUB;
-                                                        // multi-pass kernel: passes that divide a partition by its records' sub-partition (1: by k-mer hash only, as in round 4)
-constexpr uint32_t COUNT_XP_MIN_PASSES = 4;             // multi-pass kernel: from this many passes on a partition's member k-mers are expanded once (CountParams::xp_buf)
+constexpr uint32_t COUNT_MAX_SUB = CDBG_COUNT_MAX_SUB;  // multi-pass kernel: passes that divide a partition by its records' sub-partition (1: by k-mer hash only, as in round 4)
 constexpr uint32_t COUNT_FAST_MAX_RECORDS = 1u << 23;   // 255 members x (2^23 - 1) records < COUNT_SAT
 CDBG_DEV void count_add_sat(uint32_t* p) {
     const uint32_t old = atomic_add_u32(p, 1u);
@@ -278,8 +276,6 @@ struct CountParams {
     uint32_t n_items;              // partitions (or part_list entries) to process
     uint32_t max_passes;           // LDS multi-pass limit before a partition is deferred to the HBM pass
     uint32_t max_sub;              // multi-pass kernel: passes that divide a partition by its records' sub-partition (a power of two <= 16; 0: COUNT_MAX_SUB)
-    uint64_t* xp_buf; uint64_t xp_cap;   // multi-pass kernel, EXPANDED passes (round 5): per workgroup a slab of (W + 1) * xp_cap words for the member k-mers of one partition
-                                   // (nullptr: every pass walks the records)
 };
 
 // ---------------------------------------------------------------------------
@@ -312,7 +308,7 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
     // instead of all TS slots, most of which are empty at the usual ~20-45 % load
     constexpr uint32_t LIST_CAP = GLOBAL ? 1 : TS / 2;
     CDBG_SHARED uint16_t l_used[LIST_CAP];
-    CDBG_SHARED uint32_t s_fill, s_over, s_nsolid, s_wr, s_members, s_xp;
+    CDBG_SHARED uint32_t s_fill, s_over, s_nsolid, s_wr, s_members;
     CDBG_SHARED uint64_t s_base;
     CDBG_SHARED uint32_t s_stat[4];
     CDBG_SHARED uint64_t s_occ;                          // home occurrences of the partition (64 bit: one k-mer may hold 2^31 - 1 of them)
@@ -347,7 +343,6 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
     // straight behind those of the passes before it, and the unused tail goes back to the chunk.  Only partitions
     // whose bound exceeds a chunk count first and write in a second round of passes.
     bool have_ub = false, onephase = false, reserved = false; uint32_t ub = 0;
-    bool expanded = false;                                       // the partition's member k-mers lie expanded in the workgroup's slab (see below)
     for (;;) {                                                    // attempts with npass, 2 npass, ...
         if (tid == 0) { s_nsolid = 0; s_wr = 0; s_over = 0; }
         if (tid < 4) s_stat[tid] = 0;
@@ -373,66 +368,6 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
             }
             reserved = true;
         }
-        // EXPANDED passes (round 5).  A partition that needs four passes and more -- a repeat's minimizer locus: 10^5 - 10^6 distinct k-mers at k = 127 --
-        // used to cut every member k-mer out of its record, reverse-complement and hash it in EVERY pass, to keep one hash class of them.  Its members are
-        // now expanded ONCE into a slab of the workgroup (key words + hash | traveller bit, one array per word: coalesced), and a pass streams the slab and
-        // inserts its class: the hostile generator's k = 127 share spent 1.6 of its 2.0 s in these passes.
-        if (!GLOBAL && !expanded && P.xp_buf != nullptr && npass >= COUNT_XP_MIN_PASSES && have_ub && (uint64_t)s_members <= P.xp_cap) {
-            uint64_t* const xb = P.xp_buf + (uint64_t)blockIdx.x * (uint64_t)(W + 1) * P.xp_cap;
-            if (tid == 0) s_xp = 0;
-            block_sync<GLOBAL>();
-            const uint64_t per_wave = (rec1 - rec0 + NW - 1) / NW;
-            const uint64_t w0 = rec0 + (uint64_t)wave * per_wave, w1 = (w0 + per_wave < rec1) ? w0 + per_wave : rec1;
-            for (uint64_t b0 = w0; b0 < w1; b0 += 64) {          // wave-uniform
-                const int nrec = (int)((w1 - b0) < 64 ? (w1 - b0) : 64);
-                RecView<W> R; int n = 0;
-#pragma unroll
-                for (int i = 0; i < RW; ++i) R.r[i] = 0;
-                if (lane < nrec) {
-#pragma unroll
-                    for (int i = 0; i < RW; ++i) R.r[i] = P.records[(b0 + lane) * RW + i];
-                    n = R.n();
-                }
-                int incl = n;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-                const int excl = incl - n;
-                const int total = __shfl(incl, 63);
-                uint32_t base = 0;
-                if (lane == 0 && total) base = atomic_add_u32(&s_xp, (uint32_t)total);
-                base = (uint32_t)__shfl((int)base, 0);
-                for (int g0 = 0; g0 < total; g0 += 64) {
-                    const int g = g0 + lane;
-                    int ri = 0, ex = 0;
-#pragma unroll
-                    for (int step = 32; step >= 1; step >>= 1) {
-                        const int cand = ri + step;
-                        const int e = __shfl(excl, cand & 63);
-                        if (e <= g) { ri = cand; ex = e; }
-                    }
-                    RecView<W> Q;
-#pragma unroll
-                    for (int i = 0; i < RW; ++i) Q.r[i] = __shfl(R.r[i], ri);
-                    if (g < total) {
-                        const int t = g - ex, qn = Q.n();
-                        const Kmer<W> fw = Q.kmer(t, k);
-                        const Kmer<W> rc = fw.rc(k);
-                        const bool rev = rc < fw;
-                        const Kmer<W>& can = rev ? rc : fw;
-                        Kmer<W> ck = can;
-                        ck.w[W - 1] |= key_flags(t == 0 && Q.first_foreign(), t == qn - 1 && Q.last_foreign(), rev);
-                        const bool trav = (t == 0 && Q.first_trav()) || (t == qn - 1 && Q.last_trav());
-                        const uint64_t idx = (uint64_t)base + (uint64_t)g;
-#pragma unroll
-                        for (int i = 0; i < W; ++i) xb[(uint64_t)i * P.xp_cap + idx] = ck.w[i];
-                        xb[(uint64_t)W * P.xp_cap + idx] = ((uint64_t)can.hash() << 32) | (trav ? 1ULL : 0ULL);
-                    }
-                }
-            }
-            block_sync<true>();                                   // (the slab is read back by the other waves of this workgroup: stores out, the CU's L1 dropped --
-            expanded = true;                                      //  it may hold lines of the partition that used the slab before)
-            if (tid == 0) atomic_add_u64(&P.stats[4], 1ULL);      // (partitions counted this way: CDBG_HOST_MARKS prints it)
-        }
         bool overflow = false;
         const uint32_t max_sub = P.max_sub ? P.max_sub : COUNT_MAX_SUB;
         const uint32_t nsub = npass < max_sub ? npass : max_sub, nhash = npass / nsub;   // passes = sub-partitions x hash classes
@@ -448,39 +383,10 @@ CDBG_DEV void count_partition(const CountParams& P, const uint32_t item, uint64_
                 clean = false;
                 block_sync<GLOBAL>();
                 CDBG_PH(1);
-                if (expanded) {
-                    // a pass over the expanded members: the slab's hash word picks the class, the key words are read for the lanes that insert
-                    const uint64_t* const xb = P.xp_buf + (uint64_t)blockIdx.x * (uint64_t)(W + 1) * P.xp_cap;
-                    const uint32_t M = s_members;
-                    for (uint32_t i0 = (uint32_t)wave * 64u; i0 < M; i0 += (uint32_t)NT) {   // wave-uniform
-                        if (__any((int)ld_volatile_u32(&s_over))) break;
-                        const uint32_t idx = i0 + (uint32_t)lane;
-                        if (idx < M) {
-                            const uint64_t mw = xb[(uint64_t)W * P.xp_cap + idx];
-                            if ((((uint32_t)(mw >> 32) >> 20) & (npass - 1)) == pass) {
-                                Kmer<W> ck;
-#pragma unroll
-                                for (int i = 0; i < W; ++i) ck.w[i] = xb[(uint64_t)i * P.xp_cap + idx];
-                                bool is_new;
-                                const uint32_t sl = ktable_insert<W, GLOBAL>(T, ck, is_new, 64u);
-                                if (sl == 0xFFFFFFFFu) s_over = 1;
-                                else {
-                                    if (is_new) {
-                                        const uint32_t fi = atomic_add_u32(&s_fill, 1u);
-                                        if (fi >= maxfill) s_over = 1;
-                                        if (!GLOBAL && fi < LIST_CAP) l_used[fi] = (uint16_t)sl;
-                                    }
-                                    count_add_sat(&cnt[sl]);
-                                    if (mw & 1ULL) atomic_or_u32(&cnt[sl], TRAV_FLAG);
-                                }
-                            }
-                        }
-                    }
-                }
                 // the partition's records are split evenly over the waves; a wave takes its share 64 records at a time
                 const uint64_t per_wave = (rec1 - rec0 + NW - 1) / NW;
                 const uint64_t w0 = rec0 + (uint64_t)wave * per_wave, w1 = (w0 + per_wave < rec1) ? w0 + per_wave : rec1;
-                for (uint64_t b0 = w0; b0 < w1 && !expanded; b0 += 64) {      // wave-uniform
+                for (uint64_t b0 = w0; b0 < w1; b0 += 64) {      // wave-uniform
                     if (__any((int)ld_volatile_u32(&s_over))) break;
                     const int nrec = (int)((w1 - b0) < 64 ? (w1 - b0) : 64);
                     RecView<W> R; int n = 0;

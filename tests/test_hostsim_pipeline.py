@@ -482,18 +482,3 @@ def test_second_wave_tier_one_word(oracle, sim, k, glen, log_np, tier2, monkeypa
     assert_parity(oracle, sim, text, k, 1, log2_partitions=log_np)
     gg = api.Graph(k, 1, lib=sim, log2_partitions=log_np)
     gg.push_text(text); gg.run(); assert_verified(gg); gg.close()
-
-
-@pytest.mark.parametrize("k,glen,expand", [(31, 30000, True), (31, 30000, False), (21, 28000, True), (55, 16000, True), (55, 16000, False), (96, 16000, True), (127, 14000, True), (31, 100000, True)])
-def test_multipass_count_expanded_passes(oracle, sim, k, glen, expand, monkeypatch):
-    """round 5: ONE partition (log2_partitions = 0) of tens of thousands of distinct k-mers at abundance-min 1: the multi-pass kernel needs four passes and
-    more, so the member k-mers are expanded once into the workgroup's slab and the passes stream the slab (k_count.h); CDBG_NO_EXPAND: every pass walks the
-    records, as before.  (100 K bases at k = 31: more members than the simulator's slab holds -- the records are walked.)  Same counts and unitigs"""
-    if not expand:
-        monkeypatch.setenv("CDBG_NO_EXPAND", "1")
-    rng = random.Random(glen + k)
-    comp = str.maketrans("ACGT", "TGCA")
-    g = "".join(rng.choice("ACGT") for _ in range(glen))
-    reads = [g[i:i + 400] for i in range(0, glen - 200, 250)] + [g[5000:5600][::-1].translate(comp), g[100:700]]
-    got = assert_parity(oracle, sim, "\n".join(reads) + "\n", k, 1, log2_partitions=0)
-    assert got["stats"]["n_multipass_partitions"] == 1, got["stats"]
