@@ -102,19 +102,29 @@ CDBG_DEV bool scan_all_valid(const uint32_t* vm, int q, int len) {
     return true;
 }
 
+struct alignas(16) RecPair { uint64_t lo, hi; };      // two words of a record, stored at once (global_store_dwordx4)
 // place one record: count it (HIST), write it at its exact offset (EMIT) or into the partition's
 // fixed-capacity region / the spill list (EMIT_CAPPED) -- one device atomic either way.
 // bitoff = bit offset of the record's first base in the tile's packed 2-bit stream.
+#ifndef CDBG_REC16_W1
+#define CDBG_REC16_W1 0                                  // (A/B: one 16-byte store for the record of a one-word k-mer as well)
+#endif
+// the placement atomic of a record (its raw return value: scan_finish_record turns it into the record's place)
+template <int MODE>
+CDBG_DEV uint32_t scan_reserve_record(const ScanParams& P, uint32_t lpart) {
+    if (MODE == SCAN_HIST) { atomic_add_u32(&P.part_count[lpart], 1u); return 0u; }
+    return atomic_add_u32(&P.part_fill[lpart], 1u);
+}
 template <int W, int MODE>
-CDBG_DEV void scan_emit_record(const ScanParams& P, const uint32_t* pk, int bitoff, uint32_t meta, uint32_t lpart) {
+CDBG_DEV void scan_finish_record(const ScanParams& P, const uint32_t* pk, int bitoff, uint32_t meta, uint32_t lpart, uint32_t j) {
     constexpr int RW = RecFmt<W>::RW;
-    if (MODE == SCAN_HIST) { atomic_add_u32(&P.part_count[lpart], 1u); return; }
+    if (MODE == SCAN_HIST) return;
     uint64_t* dst;
     bool fits;
     if (MODE == SCAN_EMIT) {
         // exact layout (var_limit == nullptr: the histogram pass sized every region), or ESTIMATED regions of their own size per
         // partition (var_limit[p] = end of p's region, sized from a sampled histogram: the single-pass layout of skewed inputs)
-        uint64_t pos = (uint64_t)atomic_add_u32(&P.part_fill[lpart], 1u);
+        uint64_t pos = (uint64_t)j;
         fits = true;
         if (P.part_off != nullptr) {                         // (nullptr: the counters were pre-loaded with the regions' offsets -- exact layout of fewer than 2^32 records)
             pos += P.part_off[lpart];
@@ -122,7 +132,6 @@ CDBG_DEV void scan_emit_record(const ScanParams& P, const uint32_t* pk, int bito
         }
         dst = P.records + pos * RW;
     } else {
-        const uint32_t j = atomic_add_u32(&P.part_fill[lpart], 1u);
         fits = j < P.part_cap;
         dst = P.records + ((uint64_t)lpart * P.part_cap + j) * RW;
         if (!fits && P.ovf != nullptr) {                     // skewed input: a partition the sample found heavy has an overflow region of its own
@@ -136,12 +145,33 @@ CDBG_DEV void scan_emit_record(const ScanParams& P, const uint32_t* pk, int bito
         P.spill_part[o] = lpart;
         dst = P.spill_recs + o * RW;
     }
+    // Records of 32 bytes and more leave as 16-byte stores (RW is even, a record is 16-byte aligned): config-4 share scan 53.8 -> 48.8 ms, config-5 share
+    // 19.0 -> 17.9.  The 16-byte record of a ONE-word k-mer stays TWO 8-byte stores: the L2 then counts 3.2 G write requests for 1.6 G records (4.95 G requests
+    // in all) -- and still runs the pass in 66 ms, while ONE 16-byte store per record (3.34 G requests) takes 132 - 150 ms: a lane's scattered 16-byte store
+    // behind its returning atomic runs at the 11 G/s of round 4's micro-benchmark (profiles/r04_micro_sector_store.log), two 8-byte stores -- the second
+    // one hits the sector the first opened -- at more than twice that (profiles/r05_scan_request_counters.log).
+    static_assert(RW % 2 == 0, "records are pairs of words");
+    if (RW == 2 && !CDBG_REC16_W1) {
 #pragma unroll
-    for (int wv = 0; wv < RW; ++wv) {
-        uint64_t x = scan_get64(pk, bitoff + 64 * wv);
-        if (wv == RW - 1) x = (x & ~0xFFFFULL) | meta;
-        dst[RW - 1 - wv] = x;
+        for (int wv = 0; wv < RW; ++wv) {
+            uint64_t x = scan_get64(pk, bitoff + 64 * wv);
+            if (wv == RW - 1) x = (x & ~0xFFFFULL) | meta;
+            dst[RW - 1 - wv] = x;
+        }
+        return;
     }
+#pragma unroll
+    for (int wv = 0; wv < RW; wv += 2) {
+        const uint64_t hi = scan_get64(pk, bitoff + 64 * wv);
+        uint64_t lo = scan_get64(pk, bitoff + 64 * (wv + 1));
+        if (wv + 1 == RW - 1) lo = (lo & ~0xFFFFULL) | meta;
+        RecPair v; v.lo = lo; v.hi = hi;
+        *reinterpret_cast<RecPair*>(&dst[RW - 2 - wv]) = v;
+    }
+}
+template <int W, int MODE>
+CDBG_DEV void scan_emit_record(const ScanParams& P, const uint32_t* pk, int bitoff, uint32_t meta, uint32_t lpart) {
+    scan_finish_record<W, MODE>(P, pk, bitoff, meta, lpart, scan_reserve_record<MODE>(P, lpart));
 }
 
 template <int W, int MODE>
