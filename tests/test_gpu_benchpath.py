@@ -266,6 +266,23 @@ def test_hostile_four_million_reads(oracle, hip):
     assert st["n_multipass_partitions"] + st["n_big_partitions"] + st["n_split_buckets"] > 0          # the hostile input did reach the fallback tiers
 
 
+@pytest.mark.parametrize("k,cfg,n_reads", [(55, 4, 4_000_000), (55, 4 | 0x100, 3_000_000), (40, 3 | 0x100, 2_000_000)])
+def test_millions_of_reads_two_word_kmers_against_the_multithreaded_restatement(oracle, hip, k, cfg, n_reads):
+    """round 5 (oracle/cpu_mt.cpp counts two-word k-mers): the same size class for k = 55 / 40 -- uniform and HOSTILE reads generated on the device against
+    the multithreaded CPU restatement on the same bytes: occurrences, distinct / solid / unitig counts, KC sum, unitig bases and the set digest"""
+    import bcalm_amd
+    g = bcalm_amd.Graph(k, 2, lib=hip)
+    g.generate_reads(n_reads, 150, cfg)
+    text = g.read_text(0, n_reads * 151)
+    cpu = oracle_lib.cpu_mt_run(text, k, 2, os.cpu_count() or 8)
+    g.run()
+    st = g.stats(); d = g.digest(); g.close()
+    assert st["n_occurrences"] == cpu["occurrences"] == n_reads * (150 - k + 1)
+    assert (st["n_distinct"], st["n_solid"], st["n_unitigs"]) == (cpu["distinct"], cpu["solid"], cpu["unitigs"])
+    assert d["kc_sum"] == cpu["kc_sum"] and d["set_digest"] == cpu["set_digest"]
+    assert st["unitig_bases"] == cpu["unitig_bases"]
+
+
 @pytest.mark.parametrize("k,cfg,n_reads,read_len", [(55, 4 | 0x100, 150_000, 150), (32, 3 | 0x100, 150_000, 150), (64, 4 | 0x100, 100_000, 150),
                                                     (96, 5 | 0x100, 20_000, 1000), (127, 5 | 0x100, 20_000, 1000)])
 def test_hostile_multiword_parity(oracle, hip, k, cfg, n_reads, read_len):
