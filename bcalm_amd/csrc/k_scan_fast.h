@@ -43,7 +43,7 @@ CDBG_DEV uint32_t scanf_enc4(uint32_t x, uint32_t& vbits) {
 #define CDBG_SCAN_WAVES0 3
 #endif
 template <int W, int MODE, int WNT>
-__global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : WNT == 15 ? 1 : WNT < 0 ? 2 : 4) k_scan_fast(ScanParams P) {
+__global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (WNT == 15 || WNT == 16) ? 1 : WNT < 0 ? 2 : 4) k_scan_fast(ScanParams P) {
     constexpr int RW = RecFmt<W>::RW;
     constexpr int CAPB = RecFmt<W>::CAPB;
     CDBG_SHARED uint32_t pk[SCANF_PKW];
@@ -156,6 +156,19 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : WN
             gq[0] = a[0]; gq[15] = a[29];
 #pragma unroll
             for (int j = 1; j < 15; ++j) gq[j] = a[j] < a[j + 14] ? a[j] : a[j + 14];
+        } else if (WNT == 16) {
+            // window of exactly 16 keys (k = 31, m = 15): the window of junction j is the tail a[j..15] of the lane's own block and
+            // the head a[16..j+15] of the next: suffix minima of one, prefix minima of the other, 44 min
+            uint32_t a[31];
+#pragma unroll
+            for (int i = 0; i < 31; ++i) a[i] = kg[17 * c + i + (i >> 4)];
+#pragma unroll
+            for (int i = 14; i >= 0; --i) a[i] = a[i] < a[i + 1] ? a[i] : a[i + 1];
+#pragma unroll
+            for (int i = 17; i < 31; ++i) a[i] = a[i] < a[i - 1] ? a[i] : a[i - 1];
+            gq[0] = a[0];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) gq[j] = a[j] < a[j + 15] ? a[j] : a[j + 15];
         } else if (WNT > 0) {
             // any other compile-time window (k = 55, m = 16: 39 keys): minima over 2, 4, ... 2^p <= WNT keys by doubling in
             // place, then g[j] = min of the two 2^p-blocks that cover [j, j + WNT): ~ (16 + WNT) log2(WNT) min instead of 16 WNT

@@ -6,7 +6,7 @@ lib = bcalm_amd.load(os.environ.get("CDBG_LIB"))
 n_reads = int(sys.argv[1]); k = int(sys.argv[2]); reps = int(sys.argv[3])
 cfg, L = (3, 150) if k <= 31 else (4, 150) if k <= 63 else (5, 1000)
 gen = int(sys.argv[4], 0) if len(sys.argv) > 4 else (cfg | 0x100)
-g = bcalm_amd.Graph(k, 2, lib=lib, log2_partitions=int(os.environ.get("CDBG_LOG_NP", -1)))
+g = bcalm_amd.Graph(k, 2, lib=lib, log2_partitions=int(os.environ.get("CDBG_LOG_NP", -1)), minimizer_size=int(os.environ.get("CDBG_M", 0)))
 g.generate_reads(n_reads, L, gen)
 for rep in range(reps):
     t1 = time.time(); g.run(); t2 = time.time()

@@ -80,6 +80,25 @@ def test_synthetic_parity(oracle, hip, k, amin, n_reads, read_len, cfg):
     assert canon == exp["unitigs"]
 
 
+@pytest.mark.parametrize("k,m", [(31, 16), (31, 15), (32, 16), (31, 12), (55, 16), (63, 8)])
+def test_scan_window_specialisations_gpu(oracle, hip, k, m):
+    """the compile-time minimizer windows of k_scan_fast (15 keys, 16 keys, the doubling window, 39 keys) and the run-time one,
+    with the minimizer length named by the caller"""
+    import bcalm_amd
+    cfg = 3 if k <= 32 else 4
+    text = oracle.synth_reads(30000, 150, cfg)
+    exp = oracle.run(text, k, 2)
+    g = bcalm_amd.Graph(k, 2, lib=hip, minimizer_size=m)
+    g.generate_reads(30000, 150, cfg)
+    g.run()
+    st = g.stats()
+    canon = oracle_lib.canonical_set(oracle, g.unitigs(), k)
+    g.close()
+    assert st["minimizer_size"] == m
+    assert st["n_distinct"] == exp["stats"]["distinct"] and st["n_solid"] == exp["stats"]["solid"]
+    assert canon == exp["unitigs"]
+
+
 def test_determinism(oracle, hip):
     """same input, repeated runs and different partitionings -> identical canonical set"""
     text = oracle.synth_reads(20000, 150, 3)

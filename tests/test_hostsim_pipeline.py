@@ -311,10 +311,10 @@ def test_second_level_bucket_split(oracle, sim, k, glen, log_np, split, monkeypa
     gg.push_text(text); gg.run(); assert_verified(gg); gg.close()
 
 
-@pytest.mark.parametrize("k,m", [(31, 16), (21, 6), (25, 10), (31, 10), (17, 16), (55, 16), (63, 16), (33, 15), (45, 12), (63, 8), (71, 16), (127, 16)])
+@pytest.mark.parametrize("k,m", [(31, 16), (31, 15), (32, 16), (21, 6), (25, 10), (31, 10), (17, 16), (55, 16), (63, 16), (33, 15), (45, 12), (63, 8), (71, 16), (127, 16)])
 def test_scan_window_variants(oracle, sim, k, m):
     """every (k, m) shape of the register-window scan: the 15-key specialisation (k-m == 15, with and without a
-    full 32-bit m-mer mask), shorter and longer windows, two-word k-mers; reads with N, lower case, reads
+    full 32-bit m-mer mask), the 16-key one (k-m == 16), shorter and longer windows, two-word k-mers; reads with N, lower case, reads
     shorter than k and shorter than m, runs of invalid bytes next to tile and 16-base chunk borders"""
     rng = random.Random(1000 * k + m)
     g = "".join(rng.choice("ACGT") for _ in range(2500))
