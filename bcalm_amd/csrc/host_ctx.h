@@ -65,8 +65,13 @@ struct DevPool {
         }
         (void)hipFree(p);
     }
-    // everything back to the driver (an allocation failed, or the caller asked)
+    // everything back to the driver (an allocation failed, or the caller asked).  One drain at a time, and a second caller waits for the
+    // first one's hipFree calls: contexts on several host threads run out of memory together, and the thread that found the pool already
+    // emptied retried its hipMalloc before the blocks were back with the driver -- "out of memory" with 150 GB about to be free (found by
+    // the round-5 fuzz of eight ranks on one device)
+    std::mutex drain_mu;
     void drain(int d) {
+        std::lock_guard<std::mutex> dg(drain_mu);
         std::vector<Block> bl;
         { std::lock_guard<std::mutex> g(mu); bl.swap(blocks[d]); held[d] = 0; }
         for (const Block& b : bl) (void)hipFree(b.p);

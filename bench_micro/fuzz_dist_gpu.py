@@ -5,13 +5,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib, bcalm_amd
 from loopback import hip_loopback
-orc = oracle_lib.load(); lib = bcalm_amd.load()
+orc = oracle_lib.load()
+HOSTSIM = bool(os.environ.get("FUZZ_HOSTSIM"))          # the same cases through the SIMT simulator build (CPU): FUZZ_HOSTSIM=1
+if HOSTSIM:
+    import ctypes, hostsim_lib
+    from loopback import Loopback
+    lib = hostsim_lib.load()
+    def hip_loopback(world):
+        mv = lambda dst, src, n: ctypes.memmove(dst, src, n)
+        hub = Loopback(world, mv); hub.memcpy_d2h = mv; hub.memcpy_h2d = mv
+        return hub
+else:
+    lib = bcalm_amd.load()
 budget = float(sys.argv[1]); seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else None      # fuzz_dist_gpu.py SECONDS SEED IT[,IT..]: just these iterations, errors in full
+LONG = bool(only) or bool(os.environ.get("FUZZ_LONGERR"))
 t_end = time.time() + budget
 comp = str.maketrans("ACGT", "TGCA")
 n_ok = 0; fails = []; it = 0
-while time.time() < t_end and len(fails) < 5:
+while time.time() < t_end and len(fails) < (1 if os.environ.get("FUZZ_LONGERR") else 5):
     it += 1
+    if only and it > max(only): break
+    if only and it not in only: continue
     rng = random.Random(seed0 * 7000003 + it)
     k = rng.choice([7, 15, 21, 31, 31, 33, 55, 63, 65, 97, 127])
     amin = rng.choice([1, 2, 2, 3])
@@ -50,7 +65,7 @@ while time.time() < t_end and len(fails) < 5:
         ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
         for t in ts: t.start()
         for t in ts: t.join(300)
-        bad = [repr(o)[:200] for o in out if isinstance(o, Exception) or o is None or o[2] is not None]
+        bad = [repr(o)[:2000 if LONG else 200] for o in out if isinstance(o, Exception) or o is None or o[2] is not None]
         if bad: raise RuntimeError("; ".join(bad))
         if kw["emit_replicated"]:
             ok = all(oracle_lib.canonical_set(orc, out[r][0], k) == exp["unitigs"] for r in range(world))
@@ -65,5 +80,5 @@ while time.time() < t_end and len(fails) < 5:
         if ok: n_ok += 1
         else: fails.append((it, k, amin, world, kw, len(text), "MISMATCH"))
     except Exception as e:                       # noqa: BLE001
-        fails.append((it, k, amin, world, kw, len(text), repr(e)[:300]))
+        fails.append((it, k, amin, world, kw, len(text), repr(e)[:20000 if LONG else 300]))
 print(json.dumps({"iterations": it, "ok": n_ok, "fails": fails}))
