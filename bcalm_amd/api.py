@@ -33,13 +33,14 @@ class Stats(C.Structure):
         "unitig_bases", "n_big_partitions", "n_cycles")] + [
         ("minimizer_size", C.c_int), ("log2_partitions", C.c_int), ("kmer_words", C.c_int)] + [
         (n, C.c_float) for n in ("ms_scan_hist", "ms_scan_emit", "ms_count", "ms_compact", "ms_glue", "ms_total", "ms_exchange")] + [
-        (n, C.c_uint64) for n in ("n_launch_scan", "n_launch_count", "n_launch_compact", "n_multipass_partitions", "n_tiles_overlapped", "n_split_buckets", "n_glue_rounds", "n_walked_unitigs")]
+        (n, C.c_uint64) for n in ("n_launch_scan", "n_launch_count", "n_launch_compact", "n_multipass_partitions", "n_tiles_overlapped", "n_split_buckets", "n_glue_rounds", "n_walked_unitigs", "n_deferred_records")] + [
+        ("ms_place", C.c_float), ("count_slices", C.c_int)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-ABI_VERSION = 6                                        # include/cdbg.h CDBG_ABI_VERSION this binding was written for
+ABI_VERSION = 7                                        # include/cdbg.h CDBG_ABI_VERSION this binding was written for
 EXPORTS = ["cdbg_abi_version", "cdbg_stats_sizeof", "cdbg_create", "cdbg_destroy", "cdbg_release_cached", "cdbg_last_error", "cdbg_push_reads", "cdbg_push_text",
            "cdbg_generate_reads", "cdbg_expect_input", "cdbg_stage_acquire", "cdbg_stage_commit", "cdbg_read_text", "cdbg_count", "cdbg_compact", "cdbg_glue", "cdbg_run", "cdbg_reset",
            "cdbg_num_solid", "cdbg_fetch_solid", "cdbg_num_unitigs", "cdbg_fetch_unitigs", "cdbg_stats", "cdbg_digest", "cdbg_verify",
@@ -279,13 +280,25 @@ class Graph:
         self._ck(self.lib.cdbg_digest(self._h, out))
         return {"kc_sum": out[0], "solid_count_sum": out[1], "set_digest": out[2], "kmers_in_unitigs": out[3]}
 
-    def verify(self):
+    def verify(self, edges=True):
         """the unitig definition checked on the device, without the oracle (cdbg_verify, bcalm_amd/csrc/k_verify.h):
         k-mer multiset of the unitigs == solid set (counts + two commutative sums), and no pair of unitig ends that are each
-        other's only link (maximality).  mergeable_ends is None on a rank that holds a share of the unitigs."""
+        other's only link (maximality).  mergeable_ends is None on a rank that holds a share of the unitigs.
+        edges: also run the edge-conservation pass (verify_edges: a 12-byte x pow2(3 x n_solid) table).  A graph too large for that
+        pass (or a card without room for its table) reports edges = None -- with the reason under "edges_error" -- instead of failing
+        the k-mer-set / maximality verdict; edges=False skips the pass."""
         out = (C.c_uint64 * 8)()
         self._ck(self.lib.cdbg_verify(self._h, out))
-        return self._verify_dict(out, self.verify_edges())
+        e, why = None, None
+        if edges:
+            try:
+                e = self.verify_edges()
+            except CdbgError as ex:
+                why = str(ex)
+        d = self._verify_dict(out, e)
+        if why is not None:
+            d["edges_error"] = why
+        return d
 
     @staticmethod
     def _verify_dict(out, edges):

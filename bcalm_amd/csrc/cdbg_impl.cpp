@@ -90,6 +90,9 @@ void cdbg_destroy(cdbg_ctx* c) {
     if (c->rccl) { c->rccl->destroy(); delete c->rccl; c->rccl = nullptr; }
 #endif
     (void)hipStreamSynchronize(c->stream);               // (the buffers go back to the process's pool: nothing may still be writing them)
+    if (c->place_stream) { (void)hipStreamSynchronize(c->place_stream); (void)hipStreamDestroy(c->place_stream); }
+    for (hipEvent_t& e : c->place_ev) if (e) (void)hipEventDestroy(e);
+    if (c->scan_ev) (void)hipEventDestroy(c->scan_ev);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -142,7 +145,8 @@ int cdbg_stage_commit(cdbg_ctx* c, char* buf, uint64_t nbytes) {
 }
 int cdbg_expect_input(cdbg_ctx* c, uint64_t text_bytes) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
-    if (c->stage != 0 || c->n_dev || c->pin_fill) return fail(CDBG_E_STATE, "cdbg_expect_input must precede the first push");
+    // (a text that is complete already -- cdbg_generate_reads -- must not be announced again: the pre-warm thread would swap the buffer that holds it)
+    if (c->stage != 0 || c->n_dev || c->pin_fill || c->reads_final) return fail(CDBG_E_STATE, "cdbg_expect_input must precede the first push");
     c->expect_bytes = text_bytes;
     // a large input on one GPU: obtain the text buffer, the record region and the solid arrays in the background (host_count.h prewarm_run)
     uint64_t min_bytes = 1ull << 30;
@@ -151,7 +155,8 @@ int cdbg_expect_input(cdbg_ctx* c, uint64_t text_bytes) {
         (void)hipSetDevice(c->prm.device_id);
         configure(c, text_bytes);                          // (what the streaming scan will choose from the same number)
         c->prewarm_reads = 1; c->prewarm_region = 1;
-        c->prewarm = std::thread(prewarm_run, c);
+        // (no exception may cross the C ABI, and the flags must not stay set without a thread behind them: ingest_reserve waits on them)
+        try { c->prewarm = std::thread(prewarm_run, c); } catch (...) { c->prewarm_reads = 0; c->prewarm_region = 0; }
     }
     return CDBG_OK;
 }
@@ -160,6 +165,7 @@ int cdbg_generate_reads(cdbg_ctx* c, uint64_t first_read, uint64_t n_reads, uint
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     if (c->stage != 0 || c->reads_final || c->n_dev || c->pin_fill) return fail(CDBG_E_STATE, "reads already present");
     if (!n_reads || !read_len || total_reads < n_reads) return fail(CDBG_E_PARAM, "bad synthetic read set");
+    prewarm_join(c);                                        // (an announced input that is generated after all: the pre-warm thread owns c->reads until it is done)
     const uint64_t n = n_reads * (read_len + 1);
     const uint64_t np = ((n + 15) / 16) * 16 + 256;
     CK(c->reads.alloc(np, false));
@@ -252,6 +258,7 @@ int cdbg_fetch_links(cdbg_ctx* c, uint64_t* end_off, uint32_t* link_to) {
 int cdbg_reset(cdbg_ctx* c) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
+    prewarm_join(c);
     c->stage = 0; c->st = cdbg_stats_t{};
     c->n_solid_entries = c->n_pieces = c->n_piece_bases = c->n_unitigs = c->unitig_total = 0; c->linked = false; c->n_links = 0; c->joined = false;
     c->xchg_done = false; c->xp_ab_ready = false; c->comm_bytes = 0; c->piece_lo = c->piece_hi = 0; c->ss_on = false; c->expect_bytes = 0;

@@ -118,6 +118,19 @@ CDBG_DEV uint32_t uni_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfi
 #define CDBG_LDS_FENCE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 #endif
 CDBG_DEV uint64_t uni_u64(uint64_t v) { return ((uint64_t)uni_u32((uint32_t)(v >> 32)) << 32) | uni_u32((uint32_t)v); }
+// One slot of an append-only list for every lane that calls this TOGETHER (divergent control flow allowed): the active lanes of the wave advance
+// the cursor (an LDS word of their workgroup) with ONE atomic and take consecutive slots in lane order, so that their 16-byte stores behind it coalesce.
+#ifdef CDBG_HOSTSIM
+CDBG_DEV uint32_t wave_append_slots(uint32_t* cursor) { return atomic_add_u32(cursor, 1u); }   // (the simulator's wave rendezvous needs every live lane: one atomic per lane there)
+#else
+CDBG_DEV uint32_t wave_append_slots(uint32_t* cursor) {
+    const uint64_t act = __ballot(1);                                                              // the lanes that are here (exec mask)
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+    uint32_t base = 0;
+    if (rank == 0) base = atomic_add_u32(cursor, (uint32_t)__popcll(act));
+    return uni_u32(base) + rank;                                                                   // (readfirstlane reads the first ACTIVE lane: the one of rank 0)
+}
+#endif
 // v in the lanes whose bit of a wave-uniform 64-bit mask (from uni_u64) is set, 0 in the others.  A mask in a scalar
 // register pair IS a lane predicate on CDNA: one v_cndmask, where (mask >> lane) & 1 costs a 64-bit shift per lane.
 #ifdef CDBG_HOSTSIM

@@ -15,27 +15,27 @@ inline bool scan_is_fast(const cdbg_ctx* c) {
 #define CDBG_SCAN_GEN 8                                   // workgroups per resident place of the register-window scan: 1 -> 4 / 16: scan 69.3 -> 66.0 / 65.6 ms at config 3 (profiles/r04_ab_cfg3_scan_grid.log)
 #endif
 // the scan kernel for this k / m / mode on the context's stream (persistent grid: resident workgroups)
+// (dry: nothing is launched; the return value is the number of workgroups the launch would have -- the segments of a deferred record stream)
 template <int W, int MODE>
-void launch_scan_mode(cdbg_ctx* c, ScanParams& sp, uint64_t grid) {
+uint64_t launch_scan_mode(cdbg_ctx* c, ScanParams& sp, uint64_t grid, bool dry = false) {
     hipStream_t s = c->stream;
     const bool fast_scan = scan_is_fast(c);
     sp.n_tiles = grid;
-    if (fast_scan && (c->k - c->m > SCANF_WNMAX || (c->k - c->m >= 17 && c->knobs.get("CDBG_SCAN_TWO_LEVEL")))) {   // the two-level window minimum (k_scan_fast.h, WNT = -1): k <= 127 with a long minimizer window (dev knob: any window of 17 keys and more)
-        if (grid == 0) return;
-        CDBG_LAUNCH((k_scan_fast<W, MODE, -1>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, -1>, SCAN_THREADS, SCANF_GRID) * CDBG_SCAN_GEN), SCAN_THREADS, s, sp);
-        return;
-    }
-    if (grid == 0) return;                                   // (a rank without reads)
+    if (grid == 0) return 0;                                 // (a rank without reads)
+#define CDBG_SCAN_GO(KERN, FALLBACK, GEN)                                                                                        \
+    { const uint64_t g_ = std::min<uint64_t>(grid, resident_grid(KERN, SCAN_THREADS, FALLBACK) * (GEN));                         \
+      if (!dry) CDBG_LAUNCH(KERN, g_, SCAN_THREADS, s, sp);                                                                      \
+      return g_; }
+    if (fast_scan && (c->k - c->m > SCANF_WNMAX || (c->k - c->m >= 17 && c->knobs.get("CDBG_SCAN_TWO_LEVEL"))))   // the two-level window minimum (k_scan_fast.h, WNT = -1): k <= 127 with a long minimizer window (dev knob: any window of 17 keys and more)
+        CDBG_SCAN_GO((k_scan_fast<W, MODE, -1>), SCANF_GRID, CDBG_SCAN_GEN)
     // compile-time minimizer windows (k - m): the k = 31 family m = 16 .. 12 and k = 55, m = 16 (config 4)
 #define CDBG_SCAN_WNT(WW, WNT_)                                                                                                  \
-    if (fast_scan && W == WW && c->k - c->m == WNT_) {                                                                           \
-        CDBG_LAUNCH((k_scan_fast<W, MODE, W == WW ? WNT_ : 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, W == WW ? WNT_ : 0>, SCAN_THREADS, SCANF_GRID) * CDBG_SCAN_GEN), SCAN_THREADS, s, sp); \
-        return;                                                                                                                  \
-    }
+    if (fast_scan && W == WW && c->k - c->m == WNT_) CDBG_SCAN_GO((k_scan_fast<W, MODE, W == WW ? WNT_ : 0>), SCANF_GRID, CDBG_SCAN_GEN)
     CDBG_SCAN_WNT(1, 15) CDBG_SCAN_WNT(1, 16) CDBG_SCAN_WNT(1, 17) CDBG_SCAN_WNT(1, 18) CDBG_SCAN_WNT(1, 19) CDBG_SCAN_WNT(2, 39)
 #undef CDBG_SCAN_WNT
-    if (fast_scan) CDBG_LAUNCH((k_scan_fast<W, MODE, 0>), std::min<uint64_t>(grid, resident_grid(k_scan_fast<W, MODE, 0>, SCAN_THREADS, SCANF_GRID) * CDBG_SCAN_GEN), SCAN_THREADS, s, sp);
-    else CDBG_LAUNCH((k_scan<W, MODE>), std::min<uint64_t>(grid, resident_grid(k_scan<W, MODE>, SCAN_THREADS, SCAN_GRID)), SCAN_THREADS, s, sp);
+    if (fast_scan) CDBG_SCAN_GO((k_scan_fast<W, MODE, 0>), SCANF_GRID, CDBG_SCAN_GEN)
+    CDBG_SCAN_GO((k_scan<W, MODE>), SCAN_GRID, 1)
+#undef CDBG_SCAN_GO
 }
 inline uint64_t scan_tile_bytes(const cdbg_ctx* c) { return scan_is_fast(c) ? (uint64_t)SCANF_TILE : (uint64_t)SCAN_TILE; }
 void scan_params_base(cdbg_ctx* c, ScanParams& sp) {
@@ -74,15 +74,15 @@ void capped_capacities(const cdbg_ctx* c, double mean, uint64_t NPL, uint32_t& p
 #endif
 constexpr uint64_t SIFT_GRID = CDBG_SIFT_GRID, T2_GRID = CDBG_T2_GRID, MP_GRID_W = CDBG_MP_GRID_W, MP_GRID_1 = CDBG_MP_GRID_1;
 // (launches of the stage: one-pass tier 1 of COUNT_GRID workgroups, tier 2 of at most SIFT_GRID, multi-pass retry, spill repair, HBM tables)
-inline uint64_t count_solid_slack(uint64_t NPL) {
+inline uint64_t count_solid_slack(uint64_t NPL, uint32_t slices = 1) {   // slices: launches of the one-pass tier (deferred placement: one per slice of the partition space)
     // (no launch has more workgroups than partitions: a small input -- a test, a shard of few partitions -- reserves megabytes, not the 3 - 15 GB
     //  that the grids' constants alone came to; fresh device memory costs 40 - 70 ms per GB)
     auto lim = [NPL](uint64_t grid) { return std::min<uint64_t>(NPL, grid); };
-    return 4096 + (lim(COUNT_GRID) + 3 * lim(PERSISTENT_GRID) + lim(SIFT_GRID) + lim(T2_GRID) + 2 * lim(MP_GRID_1 > MP_GRID_W ? MP_GRID_1 : MP_GRID_W) + lim(768) + 5) * (uint64_t)COUNT_CHUNK;
+    return 4096 + ((uint64_t)slices * std::min<uint64_t>(NPL / slices, COUNT_GRID) + 3 * lim(PERSISTENT_GRID) + lim(SIFT_GRID) + lim(T2_GRID) + 2 * lim(MP_GRID_1 > MP_GRID_W ? MP_GRID_1 : MP_GRID_W) + lim(768) + 5) * (uint64_t)COUNT_CHUNK;
 }
 // first attempt at the solid arrays' size (see count_impl): a third of the bound of one entry per abundance-min member k-mers
-inline uint64_t count_solid_first_cap(uint64_t members, int amin, uint64_t NPL) {
-    return std::max<uint64_t>(members / (uint64_t)std::max(1, amin) / 3, 1u << 16) + count_solid_slack(NPL);
+inline uint64_t count_solid_first_cap(uint64_t members, int amin, uint64_t NPL, uint32_t slices = 1) {
+    return std::max<uint64_t>(members / (uint64_t)std::max(1, amin) / 3, 1u << 16) + count_solid_slack(NPL, slices);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -151,9 +151,13 @@ int stream_scan_advance(cdbg_ctx* c) {
         uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPL, &sample_records));
         const double mean = (double)sample_records * (double)tiles_exp / (double)ns / (double)NPL;
         capped_capacities(c, mean, NPL, c->ss_part_cap, c->ss_spill_cap);
-        if ((double)c->ss_part_cap * (double)NPL * RW * 8.0 > 200e9) { c->expect_bytes = 0; return CDBG_OK; }   // would not fit: no streaming
-        CK(c->records.alloc((uint64_t)c->ss_part_cap * NPL * RW, false));
-        CK(c->spill_recs.alloc(c->ss_spill_cap * RW, false)); CK(c->spill_part.alloc(c->ss_spill_cap, false));
+        // (the same budget as count_impl -- what the card has free, what this context and the pool would hand back, less a reserve for the
+        //  stages that follow; a region that cannot be had switches streaming off instead of failing the push)
+        { size_t fr = 0, tot = 0;
+          const double budget = (hipMemGetInfo(&fr, &tot) == hipSuccess && tot) ? (double)fr + (double)c->records.cap * 8.0 + (double)dev_pool().held[DevPool::device()] - 0.15 * (double)tot : 200e9;
+          if ((double)c->ss_part_cap * (double)NPL * RW * 8.0 > budget) { c->expect_bytes = 0; return CDBG_OK; } }   // would not fit: no streaming
+        if (c->records.alloc((uint64_t)c->ss_part_cap * NPL * RW, false) != CDBG_OK || c->spill_recs.alloc(c->ss_spill_cap * RW, false) != CDBG_OK ||
+            c->spill_part.alloc(c->ss_spill_cap, false) != CDBG_OK) { c->expect_bytes = 0; return CDBG_OK; }
         HIPCK(hipMemsetAsync(c->part_count.p, 0, NPL * sizeof(uint32_t), s));
         HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
         c->ss_on = true; c->ss_done = 0;
@@ -181,6 +185,80 @@ int stream_scan_dispatch(cdbg_ctx* c) {
 #endif
         default: return fail(CDBG_E_PARAM, "k-mers of %d words: rebuild with CDBG_MAX_W", c->W);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Deferred record placement (round 6).  The scan is bound by its memory REQUESTS (two per record: 1.6 G returning atomics beside 1.6 G partial-sector
+// stores, 66 ms at config 3 with a third of the VALU busy), the one-pass count kernel by VALU issue (57 ms, little traffic) -- and the two ran one
+// after the other.  Now the partition space is cut into S slices: the scan places slice 0's records as before and APPENDS the others to S - 1 streams
+// (coalesced 16-byte stores, one device atomic per wave); k_place (k_scan.h) scatters stream q on a second HIP stream while k_count_fast counts slice
+// q - 1 on the first (events between them).  The placement kernel needs no LDS and 4 wave slots per CU: the count's three workgroups per CU leave 8.
+// Measured before it was built (profiles/r06_ab_overlap_place_vs_count.log): 0.8 G records placed beside the count cost the pair 70 ms against
+// 57 + 35 = 92 one after the other -- with ONE-WAVE workgroups, 4 per CU: larger workgroups or more of them land unevenly over the CUs once the count's
+// workgroups are on the chip, and a CU with 12 placement waves is the step's tail.
+// ---------------------------------------------------------------------------------------
+#ifndef CDBG_DEFER_SLICES
+#define CDBG_DEFER_SLICES 4
+#endif
+#ifndef CDBG_PLACE_GRID
+#define CDBG_PLACE_GRID (256 * 2)                          // (one-wave workgroups: two per CU.  256: too few requests in flight; 384, 768: land unevenly; 1024: fine for one launch on an idle chip, uneven for the launches behind it)
+#endif
+// The slices of this step and their record streams.  w[q]: sixteenths of the partition space in slice q (slice 0: placed by the scan); cap[q]: records a
+// SEGMENT of stream q holds (one segment per workgroup of the scan); base[q]: first slot of stream q.  n == 1: no deferral.
+struct DeferPlan { uint32_t n = 1; uint32_t w[16] = {}; uint32_t cap = 0; uint64_t slots = 0; uint64_t nseg = 0; };
+// Measured at config 3 (profiles/r06_ab_defer_slices.log; same box, no deferral: 170.5 ms with the scan at 71): two halves 154.5 ms (scan 46, count stage 66.5 with
+// the placement's 36 ms inside it); four quarters 155.6 (41 + 72.5: the placement of 1.2 G records, 58 ms, is what the last quarter's count waits for); patterns with a
+// shrinking tail ("4,4,4,2,1,1") lost: every further placement launch lands on a chip full of count workgroups, unevenly, and runs at half its rate.
+#ifndef CDBG_DEFER_PATTERN
+#define CDBG_DEFER_PATTERN "8,8"
+#endif
+inline DeferPlan defer_plan(cdbg_ctx* c, int W, double mean, uint64_t NPS, int RW, uint64_t nseg, double budget_left) {
+    DeferPlan d; d.nseg = nseg;
+    // one-word k-mers only: the scans of wider k-mers are bound by their instructions, not by their requests (config-4 / -5 shares: 232 -> 239 / 198 -> 204 ms with two slices)
+    const char* pat = c->knobs.get("CDBG_DEFER_SLICES");
+    if (pat == nullptr) pat = W == 1 ? CDBG_DEFER_PATTERN : "0";
+    if (c->defer_off_once) { c->defer_off_once = false; return d; }
+    uint32_t n = 0, sum = 0, w[16];
+    if (strchr(pat, ',') != nullptr) {                       // sixteenths per slice
+        for (const char* q = pat; *q && n < 16; ) { w[n] = (uint32_t)std::max(0, atoi(q)); sum += w[n]; ++n; while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+    } else {                                                 // a number: that many equal slices (2, 4, 8, 16)
+        uint32_t S = (uint32_t)std::max(0, atoi(pat)); while (S & (S - 1)) S &= S - 1;
+        if (S >= 2 && S <= 16) { n = S; for (uint32_t q = 0; q < S; ++q) w[q] = 16 / S; sum = 16; }
+    }
+    for (uint32_t q = 0; q < n; ++q) if (w[q] == 0) return d;
+    if (n < 2 || sum != 16 || NPS < 16 * 64 || nseg == 0) return d;
+    const double est = mean * (double)NPS;                   // records of the step
+    uint32_t wmax = 0; for (uint32_t q = 1; q < n; ++q) wmax = std::max(wmax, w[q]);
+    // (the persistent workgroups take equal shares of the tiles: a segment's share is est * w / 16 / nseg with a spread of a few sqrt;
+    //  a segment that fills up loses nothing -- the scan places the record itself)
+    const double share = est * (double)wmax / 16.0 / (double)nseg;
+    uint64_t cap = (uint64_t)(share * 1.05 + 8.0 * std::sqrt(share + 1.0)) + 64;
+    if (const char* e = c->knobs.get("CDBG_DEFER_CAP")) cap = (uint64_t)std::max(1, atoi(e));   // test knob: segments that fill up
+    cap = (cap + 3) & ~3ull;
+    if (cap >= (1ull << 31)) return d;
+    const uint64_t slots = (uint64_t)(n - 1) * nseg * cap;
+    if ((double)slots * (RW * 8.0 + 4.0) > budget_left) return d;
+    d.cap = (uint32_t)cap;
+    d.n = n; d.slots = slots; for (uint32_t q = 0; q < n; ++q) d.w[q] = w[q];
+    return d;
+}
+template <int W>
+int defer_launch_places(cdbg_ctx* c, const ScanParams& sp) {
+    hipStream_t s = c->stream;
+    if (!c->place_stream) HIPCK(hipStreamCreateWithFlags(&c->place_stream, hipStreamNonBlocking));   // (non-blocking: the host's reads behind the scan must not wait for the placement)
+    if (!c->scan_ev) HIPCK(hipEventCreate(&c->scan_ev));
+    for (uint32_t q = 0; q < sp.defer_slices; ++q) if (!c->place_ev[q]) HIPCK(hipEventCreate(&c->place_ev[q]));
+    HIPCK(hipEventRecord(c->scan_ev, s));
+    HIPCK(hipStreamWaitEvent(c->place_stream, c->scan_ev, 0));
+    HIPCK(hipEventRecord(c->place_ev[0], c->place_stream));
+    uint64_t grid = CDBG_PLACE_GRID;
+    if (const char* e = c->knobs.get("CDBG_PLACE_GRID")) grid = (uint64_t)std::max(1, atoi(e));
+    for (uint32_t q = 1; q < sp.defer_slices; ++q) {
+        PlaceParams pp{ sp, q };
+        CDBG_LAUNCH(k_place<W>, grid, 64, c->place_stream, pp);
+        HIPCK(hipEventRecord(c->place_ev[q], c->place_stream));
+    }
+    return CDBG_OK;
 }
 
 template <int W>
@@ -264,8 +342,33 @@ int count_impl(cdbg_ctx* c) {
     uint64_t n_spilled_parts = 0;                            // partitions whose region overflowed (capped mode): counted from gathered copies
     Timer t;
     uint64_t spill_cap = 0;
+    DeferPlan dp; uint32_t& defer_S = dp.n;                   // deferred placement: slices of the partition space (1: off) and their streams
+    bool deferred_open = false;                              // placement kernels of this step are (or may be) still running: the record count and the spill list are not final
     uint64_t sample_ns = 0, sample_stride = 0, sample_recs = 0;   // the capped path's sampled histogram, when it ran (still in part_count)
     if (c->ss_on) capped = true;                             // tiles [0, ss_done) were scanned while the input was arriving
+    // repair: gather region + spilled records of each spilled partition into one contiguous run (k_count.h); the one-pass count kernels
+    // leave such a partition alone (fill > capacity) and the repair launch of the count stage counts the gathered copy
+    auto repair_spills = [&](const uint64_t* ovf) -> int {
+        RepairParams rp{};
+        rp.records = c->records.p; rp.spill_recs = c->spill_recs.p; rp.spill_part = c->spill_part.p; rp.n_spill = n_spill;
+        rp.part_fill = c->part_count.p; rp.npl = NPL; rp.part_cap = part_cap; rp.RW = RW; rp.ovf = ovf;
+        CK(c->rp_flag.alloc(NPL, false)); CK(c->rp_idx.alloc(NPL + 1, false));
+        rp.flag = c->rp_flag.p; rp.ridx = c->rp_idx.p;
+        CDBG_LAUNCH(k_repair_flag, (NPL + 255) / 256, 256, s, rp);
+        CK(exscan_u32(c, c->rp_flag.p, c->rp_idx.p, NPL));
+        CK(read_u64(c->rp_idx.p + NPL, &n_spilled_parts));
+        const uint64_t nsp = n_spilled_parts;
+        CK(c->repair_part.alloc(nsp, false)); CK(c->rp_size.alloc(nsp, false)); CK(c->repair_off.alloc(nsp + 1, false)); CK(c->rp_fill.alloc(nsp, true));
+        rp.item_part = c->repair_part.p; rp.item_size = c->rp_size.p; rp.item_off = c->repair_off.p; rp.item_fill = c->rp_fill.p;
+        CDBG_LAUNCH(k_repair_list, (NPL + 255) / 256, 256, s, rp);
+        CK(exscan_u32(c, c->rp_size.p, c->repair_off.p, nsp));
+        uint64_t total = 0; CK(read_u64(c->repair_off.p + nsp, &total));
+        CK(c->repair_recs.alloc(total * RW, false));
+        rp.out = c->repair_recs.p;
+        CDBG_LAUNCH(k_repair_gather, nsp, 256, s, rp);
+        CDBG_LAUNCH(k_repair_scatter, std::min<uint64_t>((n_spill + 255) / 256, 1u << 16), 256, s, rp);
+        return CDBG_OK;
+    };
     if (capped) {
         bool fits = true;
         if (c->ss_on) { part_cap = c->ss_part_cap; spill_cap = c->ss_spill_cap; }
@@ -293,8 +396,18 @@ int count_impl(cdbg_ctx* c) {
             else if (sample_max >= 32 && (double)sample_max * (double)tiles / (double)ns > 8.0 * (double)part_cap && c->knobs.get("CDBG_SCAN_MODE") == nullptr) { fits = false; var = !multi; }
             if (fits) {
                 if (c->xrecs.cap > c->records.cap) c->records.swap(c->xrecs);   // (sharded reads: the previous step left the region buffer there)
+                // deferred placement (above): one GPU's own partitions, the whole text at hand
+                if (!multi) {
+                    sp.tile_stride = 1;
+                    const uint64_t nseg = launch_scan_mode<W, SCAN_EMIT_CAPPED>(c, sp, tiles, true);   // (dry run: the workgroups of the emit launch)
+                    dp = defer_plan(c, W, mean, NPS, RW, nseg, region_budget() - (double)part_cap * (double)NPS * RW * 8.0 + (double)(c->defer_recs.cap + c->defer_part.cap / 2) * 8.0);
+                }
                 CK(c->records.alloc((uint64_t)part_cap * NPS * RW, false));
                 CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
+                if (defer_S > 1) {
+                    if (c->defer_recs.alloc(dp.slots * RW, false) != CDBG_OK || c->defer_part.alloc(dp.slots, false) != CDBG_OK) defer_S = 1;   // (no room after all: every record placed by the scan)
+                    else { CK(c->defer_count.alloc((uint64_t)(defer_S - 1) * dp.nseg, false)); HIPCK(hipMemsetAsync(c->defer_count.p, 0, (uint64_t)(defer_S - 1) * dp.nseg * sizeof(uint32_t), s)); }
+                }
                 HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));
                 HIPCK(hipMemsetAsync(c->dstats.p, 0, 32 * sizeof(uint64_t), s));
             }
@@ -303,21 +416,33 @@ int count_impl(cdbg_ctx* c) {
         else {
             sp.tile_stride = 1; sp.records = c->records.p; sp.part_cap = part_cap; sp.part_fill = c->part_count.p;
             sp.spill_recs = c->spill_recs.p; sp.spill_part = c->spill_part.p; sp.spill_cursor = c->cursors.p + 6; sp.spill_cap = spill_cap;
+            if (defer_S > 1) {
+                uint32_t lg = 0; while ((1ull << lg) < NPS) ++lg;
+                sp.defer_slices = defer_S; sp.defer_shift = lg - 4; sp.defer_nseg = (uint32_t)dp.nseg; sp.defer_map = 0;
+                for (uint32_t q = 0, x = 0; q < defer_S; ++q) for (uint32_t i = 0; i < dp.w[q]; ++i, ++x) sp.defer_map |= (uint64_t)q << (4 * x);
+                sp.defer_seg_cap = dp.cap;
+                sp.defer_recs = c->defer_recs.p; sp.defer_part = c->defer_part.p; sp.defer_count = c->defer_count.p;
+            }
             CK(t.start(s));
             const uint64_t done = c->ss_on ? std::min<uint64_t>(c->ss_done, tiles) : 0;
             sp.tile_offset = (uint32_t)done;
-            if (tiles > done) LAUNCH_SCAN(SCAN_EMIT_CAPPED, tiles - done);
+            if (tiles > done) {
+                const uint64_t g = LAUNCH_SCAN(SCAN_EMIT_CAPPED, tiles - done);
+                if (defer_S > 1 && g != dp.nseg) return fail(CDBG_E_INTERNAL, "deferred placement: the scan ran with %llu workgroups, its streams have %llu segments", (unsigned long long)g, (unsigned long long)dp.nseg);
+            }
             sp.tile_offset = 0;
             c->st.n_tiles_overlapped = done;
-            CK(exscan(c->part_count.p));                     // only for the total number of records
+            if (defer_S > 1) { CK(defer_launch_places<W>(c, sp)); deferred_open = true; }   // (second stream, behind the scan; the count's slices wait for its events)
+            else CK(exscan(c->part_count.p));                // only for the total number of records
             CK(t.stop(&c->st.ms_scan_emit));
             hm.mark("count: sample + capped scan");
-            CK(read_u64(c->part_off.p + NPS, &n_records));
+            if (!deferred_open) CK(read_u64(c->part_off.p + NPS, &n_records));
             CK(read_u64(c->dstats.p, hs, 2));
-            CK(read_u64(c->cursors.p + 6, &n_spill));
+            CK(read_u64(c->cursors.p + 6, &n_spill));        // (deferred placement: what the scan itself spilled so far -- looked at again when the last stream is placed)
             uint32_t derr = 0; CK(read_u32(c->derr.p, &derr));
             c->ss_on = false;                                // (the streamed part is accounted for; a re-count scans everything)
             if (derr == 6 || n_spill > spill_cap) {          // estimate was off (very skewed input): exact layout instead
+                if (deferred_open) { HIPCK(hipStreamSynchronize(c->place_stream)); deferred_open = false; defer_S = 1; }   // (the placement kernels append to the same lists)
                 capped = false; HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t))); HIPCK(hipMemset(c->cursors.p + 6, 0, sizeof(uint64_t)));
             } else if (multi) {
                 // what travels is the exact owner-major layout: squeeze the regions (part_off = exclusive scan of the fills)
@@ -331,26 +456,8 @@ int count_impl(cdbg_ctx* c) {
                 }
                 c->records.swap(c->xrecs);
                 capped = false; packed_exact = true;
-            } else if (n_spill) {
-                // repair: gather region + spilled records of each spilled partition into one contiguous run (k_count.h)
-                RepairParams rp{};
-                rp.records = c->records.p; rp.spill_recs = c->spill_recs.p; rp.spill_part = c->spill_part.p; rp.n_spill = n_spill;
-                rp.part_fill = c->part_count.p; rp.npl = NPL; rp.part_cap = part_cap; rp.RW = RW; rp.ovf = nullptr;
-                CK(c->rp_flag.alloc(NPL, false)); CK(c->rp_idx.alloc(NPL + 1, false));
-                rp.flag = c->rp_flag.p; rp.ridx = c->rp_idx.p;
-                CDBG_LAUNCH(k_repair_flag, (NPL + 255) / 256, 256, s, rp);
-                CK(exscan_u32(c, c->rp_flag.p, c->rp_idx.p, NPL));
-                CK(read_u64(c->rp_idx.p + NPL, &n_spilled_parts));
-                const uint64_t nsp = n_spilled_parts;
-                CK(c->repair_part.alloc(nsp, false)); CK(c->rp_size.alloc(nsp, false)); CK(c->repair_off.alloc(nsp + 1, false)); CK(c->rp_fill.alloc(nsp, true));
-                rp.item_part = c->repair_part.p; rp.item_size = c->rp_size.p; rp.item_off = c->repair_off.p; rp.item_fill = c->rp_fill.p;
-                CDBG_LAUNCH(k_repair_list, (NPL + 255) / 256, 256, s, rp);
-                CK(exscan_u32(c, c->rp_size.p, c->repair_off.p, nsp));
-                uint64_t total = 0; CK(read_u64(c->repair_off.p + nsp, &total));
-                CK(c->repair_recs.alloc(total * RW, false));
-                rp.out = c->repair_recs.p;
-                CDBG_LAUNCH(k_repair_gather, nsp, 256, s, rp);
-                CDBG_LAUNCH(k_repair_scatter, std::min<uint64_t>((n_spill + 255) / 256, 1u << 16), 256, s, rp);
+            } else if (n_spill && !deferred_open) {
+                CK(repair_spills(nullptr));
             }
         }
     }
@@ -418,24 +525,7 @@ int count_impl(cdbg_ctx* c) {
             if (derr == 6 || n_spill > spill_cap) {          // the estimate was off by more than the spill list holds: exact layout
                 var = false; HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t))); HIPCK(hipMemset(c->cursors.p + 6, 0, sizeof(uint64_t)));
             } else if (n_spill) {
-                RepairParams rp{};
-                rp.records = c->records.p; rp.spill_recs = c->spill_recs.p; rp.spill_part = c->spill_part.p; rp.n_spill = n_spill;
-                rp.part_fill = c->part_count.p; rp.npl = NPL; rp.part_cap = part_cap; rp.RW = RW; rp.ovf = c->ovf_words.p;
-                CK(c->rp_flag.alloc(NPL, false)); CK(c->rp_idx.alloc(NPL + 1, false));
-                rp.flag = c->rp_flag.p; rp.ridx = c->rp_idx.p;
-                CDBG_LAUNCH(k_repair_flag, (NPL + 255) / 256, 256, s, rp);
-                CK(exscan_u32(c, c->rp_flag.p, c->rp_idx.p, NPL));
-                CK(read_u64(c->rp_idx.p + NPL, &n_spilled_parts));
-                const uint64_t nsp = n_spilled_parts;
-                CK(c->repair_part.alloc(nsp, false)); CK(c->rp_size.alloc(nsp, false)); CK(c->repair_off.alloc(nsp + 1, false)); CK(c->rp_fill.alloc(nsp, true));
-                rp.item_part = c->repair_part.p; rp.item_size = c->rp_size.p; rp.item_off = c->repair_off.p; rp.item_fill = c->rp_fill.p;
-                CDBG_LAUNCH(k_repair_list, (NPL + 255) / 256, 256, s, rp);
-                CK(exscan_u32(c, c->rp_size.p, c->repair_off.p, nsp));
-                uint64_t total = 0; CK(read_u64(c->repair_off.p + nsp, &total));
-                CK(c->repair_recs.alloc(total * RW, false));
-                rp.out = c->repair_recs.p;
-                CDBG_LAUNCH(k_repair_gather, nsp, 256, s, rp);
-                CDBG_LAUNCH(k_repair_scatter, std::min<uint64_t>((n_spill + 255) / 256, 1u << 16), 256, s, rp);
+                CK(repair_spills(c->ovf_words.p));
             }
         }
     }
@@ -507,16 +597,17 @@ int count_impl(cdbg_ctx* c) {
 #ifdef CDBG_PROFILE_PHASES
     { uint64_t ph[6]; CK(read_u64(c->dstats.p + 16, ph, 6)); fprintf(stderr, "k_scan phase ticks: load %llu keys %llu winmin %llu flags %llu collect %llu emit %llu\n", (unsigned long long)ph[0], (unsigned long long)ph[1], (unsigned long long)ph[2], (unsigned long long)ph[3], (unsigned long long)ph[4], (unsigned long long)ph[5]); }
 #endif
-    c->st.n_records = n_records; c->st.n_member_kmers = hs[0];
+    c->st.n_records = n_records; c->st.n_member_kmers = hs[0];   // (deferred placement: the record count follows when the last stream is placed)
+    c->st.count_slices = (int)defer_S;
     hm.mark("count: spill repair/exchange");
 
     // Solid entries: at most one per abundance-min member k-mers -- a bound that is 12 x the need at sequencing depth (config 3: 6.7 G
     // entries, 81 GB, for 0.65 G), and fresh device memory costs 40 - 70 ms per GB to obtain (profiles/r05_micro_alloc.log: the CLI's
     // first and only job paid seconds for it).  First attempt: a third of the bound; the kernels report an overflow (device error 1)
     // without writing out of bounds, and the stage then runs once more with the bound itself (an input of mostly distinct k-mers).
-    const uint64_t solid_slack = count_solid_slack(NPL);
+    const uint64_t solid_slack = count_solid_slack(NPL, defer_S);
     const uint64_t solid_bound = hs[0] / (uint64_t)std::max(1, c->prm.abundance_min) + solid_slack;
-    uint64_t solid_cap = std::min(solid_bound, count_solid_first_cap(hs[0], c->prm.abundance_min, NPL));
+    uint64_t solid_cap = std::min(solid_bound, count_solid_first_cap(hs[0], c->prm.abundance_min, NPL, defer_S));
     if (c->knobs.get("CDBG_SOLID_FIRST_TINY")) solid_cap = 1u << 15;   // (tests: force the second attempt; not below one partition's entries -- the kernels park an overflowing partition at offset 0)
     if (c->solid_keys.cap >= solid_bound * W && c->solid_cnt.cap >= solid_bound) solid_cap = solid_bound;   // (a context that was re-run keeps what it has)
     float ms_count_first = 0;
@@ -551,13 +642,42 @@ int count_impl(cdbg_ctx* c) {
         CountFastParams fp{ cp, c->retry_list.p, c->big_count.p + 1, count_fast_record_limit<W>(c->k), W == 1 ? 0u : W == 2 ? 177u : 200u };
         if (const char* e = c->knobs.get("CDBG_FAST_SKIP_Q8")) fp.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
         if (const char* e = c->knobs.get("CDBG_FAST_MAX_RECORDS")) fp.fast_max_records = std::min<uint32_t>(count_fast_record_limit<W>(c->k), (uint32_t)std::max(1, atoi(e)));   // dev knob
-        if (capped) CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, true>), std::min<uint64_t>(NPL, COUNT_GRID), Cfg<W>::NTC, s, fp);
+        if (capped && defer_S > 1) {
+            // deferred placement: the tier runs once per slice of the partition space, slice q as soon as its stream has been placed (stream q is
+            // placed on the second HIP stream while slice q - 1 is counted here; slice 0 was placed by the scan)
+            for (uint32_t q = 0, x = 0; q < defer_S; x += dp.w[q], ++q) {
+                if (q) HIPCK(hipStreamWaitEvent(s, c->place_ev[q], 0));
+                const uint64_t per = NPL / 16 * dp.w[q];
+                fp.c.item_base = (uint32_t)(NPL / 16 * x); fp.c.n_items = (uint32_t)per;
+                CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, true>), std::min<uint64_t>(per, COUNT_GRID), Cfg<W>::NTC, s, fp);
+            }
+        }
+        else if (capped) CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, true>), std::min<uint64_t>(NPL, COUNT_GRID), Cfg<W>::NTC, s, fp);
         else CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(NPL, COUNT_GRID), Cfg<W>::NTC, s, fp);
     }
     c->st.n_launch_count = NPL;
     uint32_t nretry = 0;
     HIPCK(hipStreamSynchronize(s));
     hm.mark("count: tier 1");
+    if (deferred_open) {
+        // every stream has been placed (the last slice's launch waited for it): the record count and the spill list are final now
+        deferred_open = false;
+        HIPCK(hipStreamSynchronize(c->place_stream));
+        CK(exscan(c->part_count.p)); CK(read_u64(c->part_off.p + NPS, &n_records)); c->st.n_records = n_records;
+        { std::vector<uint32_t> dc((size_t)(defer_S - 1) * dp.nseg); CK(read_u32(c->defer_count.p, dc.data(), dc.size())); uint64_t nd = 0;
+          for (uint32_t v : dc) nd += std::min(v, dp.cap);
+          c->st.n_deferred_records = nd; }
+        HIPCK(hipEventElapsedTime(&c->st.ms_place, c->place_ev[0], c->place_ev[defer_S - 1]));
+        CK(read_u64(c->cursors.p + 6, &n_spill));
+        if (n_spill > spill_cap) {
+            // the capacity estimate was off by more than the spill list holds (the scan alone had not shown it): this step once more, every record placed by
+            // the scan, which then falls back to the exact layout by itself
+            HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t))); HIPCK(hipMemset(c->cursors.p + 6, 0, sizeof(uint64_t)));
+            c->defer_off_once = true;
+            return count_impl<W>(c);
+        }
+        if (n_spill) CK(repair_spills(nullptr));             // (the tier above left the spilled partitions alone; their gathered copies are counted below)
+    }
     CK(read_u32(c->big_count.p + 1, &nretry));
     const uint32_t* retry_ptr = c->retry_list.p;
     // second tier, k-mers of three words and more under an abundance filter: the sifting tier (k_count_fast.h) -- fingerprints first,

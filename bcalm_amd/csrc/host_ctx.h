@@ -215,7 +215,7 @@ int glue_table_slots(uint64_t want, uint32_t* out) {
 struct Knobs {
     std::vector<std::pair<std::string, std::string>> kv;
     void snapshot() {
-        static const char* const NAMES[] = { "CDBG_MAX_PASSES", "CDBG_CW_TIER3", "CDBG_CW_TIER2", "CDBG_SCAN_TWO_LEVEL", "CDBG_COUNT_MAX_SUB", "CDBG_VAR_RESAMPLE", "CDBG_EXACT_NO_CUR32", "CDBG_SOLID_FIRST_TINY", "CDBG_PREWARM_MIN_BYTES", "CDBG_NO_PREWARM", "CDBG_DEBUG_SEGHIST", "CDBG_FAST_MAX_RECORDS", "CDBG_FAST_SKIP2_Q8", "CDBG_FAST_SKIP_Q8", "CDBG_FORCE_MULTI", "CDBG_GENERIC_SCAN", "CDBG_GLUE_LOG", "CDBG_GLUE_RANK", "CDBG_GLUE_REPLICATED", "CDBG_GLUE_TABLE", "CDBG_JOIN_LOG_JB", "CDBG_NO_COUNT_TIER2", "CDBG_NO_SIFT", "CDBG_NO_SPLIT", "CDBG_PART_CAP", "CDBG_REPAIR_MAX_PASSES", "CDBG_SCAN_MODE", "CDBG_STAGE_BYTES", "CDBG_STREAM_BATCH_TILES", "CDBG_STREAM_MIN_BYTES", "CDBG_VAR_SCALE", "CDBG_WALK_MAX" };
+        static const char* const NAMES[] = { "CDBG_MAX_PASSES", "CDBG_CW_TIER3", "CDBG_CW_TIER2", "CDBG_SCAN_TWO_LEVEL", "CDBG_COUNT_MAX_SUB", "CDBG_VAR_RESAMPLE", "CDBG_EXACT_NO_CUR32", "CDBG_SOLID_FIRST_TINY", "CDBG_PREWARM_MIN_BYTES", "CDBG_NO_PREWARM", "CDBG_DEBUG_SEGHIST", "CDBG_FAST_MAX_RECORDS", "CDBG_FAST_SKIP2_Q8", "CDBG_FAST_SKIP_Q8", "CDBG_FORCE_MULTI", "CDBG_GENERIC_SCAN", "CDBG_GLUE_LOG", "CDBG_GLUE_RANK", "CDBG_GLUE_REPLICATED", "CDBG_GLUE_TABLE", "CDBG_JOIN_LOG_JB", "CDBG_NO_COUNT_TIER2", "CDBG_NO_SIFT", "CDBG_NO_SPLIT", "CDBG_PART_CAP", "CDBG_REPAIR_MAX_PASSES", "CDBG_SCAN_MODE", "CDBG_STAGE_BYTES", "CDBG_STREAM_BATCH_TILES", "CDBG_STREAM_MIN_BYTES", "CDBG_VAR_SCALE", "CDBG_WALK_MAX", "CDBG_DEFER_SLICES", "CDBG_DEFER_CAP", "CDBG_PLACE_GRID" };
         for (const char* n : NAMES) if (const char* e = getenv(n)) kv.emplace_back(n, e);
     }
     const char* get(const char* name) const { for (const auto& p : kv) if (p.first == name) return p.second.c_str(); return nullptr; }
@@ -256,6 +256,10 @@ struct cdbg_ctx {
 
     DBuf<uint32_t> part_count, spill_part; DBuf<uint64_t> part_off, part_cursor, records, exscan_tmp, spill_recs;
     DBuf<uint64_t> dstats; DBuf<uint32_t> derr;
+    // deferred record placement (host_count.h): the record streams of the slices the scan does not place itself, their cursors, the stream the
+    // placement kernels run on beside the count stage, and one event per slice (+ [0]: where that stream's work of this step begins)
+    DBuf<uint64_t> defer_recs; DBuf<uint32_t> defer_part, defer_count;
+    hipStream_t place_stream{}; hipEvent_t place_ev[17] = {}; hipEvent_t scan_ev{}; bool defer_off_once = false;
     DBuf<uint64_t> solid_keys; DBuf<uint32_t> solid_cnt; DBuf<uint64_t> solid_cursor, seg_off; DBuf<uint32_t> seg_n;
     DBuf<uint32_t> big_list, big_count, big_list2, big_count2, retry_list;
     uint64_t n_solid_entries = 0;                // home + traveller solid entries
@@ -378,10 +382,13 @@ int stage_acquire(cdbg_ctx* c, char** buf, uint64_t* cap) {
             if (sg.state == 0) { sg.state = 1; *buf = (char*)sg.p; *cap = c->stage_bytes; return CDBG_OK; }
             if (sg.state == 2 && oldest < 0) oldest = i;
         }
-        if ((int)c->stages.size() < cdbg_ctx::MAX_STAGES) {                                 // every buffer is with a caller or on its way: one more
+        // (every buffer is with a caller or on its way.  Beyond 32 buffers -- 1 GB pinned, twice the CLI's parser threads -- a copy that is about to land is waited for
+        //  instead of pinning 32 MB more on the ingest path; a caller that HOLDS them all still gets more, up to MAX_STAGES)
+        if ((int)c->stages.size() >= 32 && oldest >= 0) { HIPCK(hipEventSynchronize(c->stages[oldest].ev)); continue; }
+        if ((int)c->stages.size() < cdbg_ctx::MAX_STAGES) {
             cdbg_ctx::Stage sg;
             if (hipHostMalloc((void**)&sg.p, cdbg_ctx::STAGE_BYTES) != hipSuccess) return fail(CDBG_E_NOMEM, "pinned staging buffer (%llu bytes)", (unsigned long long)cdbg_ctx::STAGE_BYTES);
-            HIPCK(hipEventCreate(&sg.ev));
+            if (hipEventCreate(&sg.ev) != hipSuccess) { (void)hipHostFree(sg.p); return fail(CDBG_E_NODEVICE, "hipEventCreate failed (staging buffer)"); }
             sg.state = 1; c->stages.push_back(sg);
             *buf = (char*)sg.p; *cap = c->stage_bytes; return CDBG_OK;
         }

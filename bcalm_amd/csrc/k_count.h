@@ -274,6 +274,8 @@ struct CountParams {
     // HBM scratch table (GLOBAL variant): slot i of the big pass uses [big_off[i], big_off[i+1]) slots
     uint64_t* g_keys; uint32_t* g_cnt; const uint64_t* big_off;
     uint32_t n_items;              // partitions (or part_list entries) to process
+    uint32_t item_base;            // one-pass tier without a list: work item i is partition item_base + i (the tier runs once per SLICE of the partition space
+                                   // while the records of the next slice are still being placed: host_count.h, deferred placement)
     uint32_t max_passes;           // LDS multi-pass limit before a partition is deferred to the HBM pass
     uint32_t max_sub;              // multi-pass kernel: passes that divide a partition by its records' sub-partition (a power of two <= 16; 0: COUNT_MAX_SUB)
 };

@@ -137,7 +137,7 @@ template <int CAPPED>
 CDBG_DEV CountRaw<CAPPED> count_raw_load(const CountParams& P, uint32_t item) {
     const uint32_t i = item < P.n_items ? item : P.n_items - 1u;
     CountRaw<CAPPED> r;
-    uint32_t p = i;
+    uint32_t p = i + P.item_base;
     if constexpr (CAPPED & 2) { p = P.part_list[i]; r.p = p; }
     if constexpr (CAPPED & 1) r.f = P.part_fill[p];
     else if (P.part_pairs) { r.a = P.part_off[2ull * p]; r.b = P.part_off[2ull * p + 1]; }
@@ -147,7 +147,7 @@ CDBG_DEV CountRaw<CAPPED> count_raw_load(const CountParams& P, uint32_t item) {
 struct CountRange { uint64_t rec0; uint32_t n; uint32_t p; };      // records [rec0, rec0 + n) of partition p (n == 0: nothing to do here); wave-uniform
 template <int CAPPED>
 CDBG_DEV CountRange count_raw_resolve(const CountParams& P, uint32_t item, const CountRaw<CAPPED>& w) {
-    CountRange r; r.p = item; r.rec0 = 0; r.n = 0;
+    CountRange r; r.p = item + P.item_base; r.rec0 = 0; r.n = 0;
     if (item >= P.n_items) return r;
     if constexpr (CAPPED & 2) r.p = uni_u32(w.p);
     if constexpr (CAPPED & 1) { const uint32_t f = uni_u32(w.f); r.rec0 = (uint64_t)r.p * P.part_stride; r.n = f > P.part_stride ? 0u : f; }   // spilled: counted by the repair launch

@@ -74,11 +74,25 @@ struct ScanParams {
                                  // may hold in all (record j >= part_cap goes to slot j of that region; its first part_cap slots receive the uniform region's records afterwards)
     const uint64_t* part_off;    // SCAN_EMIT: first record of partition p's region, added to the 32-BIT running index part_fill[p] (zeroed by the host);
                                  // nullptr: part_fill[p] was pre-loaded with the offset itself (exact layout of fewer than 2^32 records: no second access)
+    // SCAN_EMIT_CAPPED, DEFERRED PLACEMENT (round 6; host_count.h): the partition space is cut into defer_slices ranges of whole SIXTEENTHS (slice of partition
+    // p = nibble p >> defer_shift of defer_map: slices need not be equal -- the last ones are small, so that little counting is left when the last stream has
+    // been placed).  The scan places the records of slice 0 itself; a record of slice q > 0 is APPENDED to stream q -- coalesced 16-byte stores -- and k_place
+    // scatters stream q + 1 on a second HIP stream while the count stage counts slice q: the placement is bound by memory requests (two per record), the count
+    // by VALU issue.  A stream is one SEGMENT per workgroup of the scan (the persistent workgroups take equal shares of the tiles), so that appending needs no
+    // device atomic at all: the workgroup's cursors live in LDS and are written to defer_count[(q - 1) * defer_nseg + workgroup] when it is done (one
+    // cursor word for the whole chip admits 88 M atomics/s: 25 M wave-level reservations took the scan from 66 to 318 ms).  Segment g of stream q holds
+    // records [((q - 1) * defer_nseg + g) * defer_seg_cap, + defer_seg_cap) of defer_recs / defer_part (one capacity for all streams: that of the largest
+    // slice -- nothing but LDS cursors and registers in the scan's emit loop); a record that finds its segment full is placed directly (always correct).
+    // defer_slices <= 1: off.
+    uint32_t defer_slices, defer_shift, defer_nseg, defer_seg_cap;
+    uint64_t defer_map;
+    uint64_t* defer_recs; uint32_t* defer_part; uint32_t* defer_count;
 };
 // Round 5: placing a record is ONE returning 32-bit atomic and one store wherever the layout allows it.  The exact layout used to
 // advance a 64-bit cursor per partition: the same 1.6 G atomics on the same addresses took its emit pass from 66.8 to 89.1 ms at
 // config 3 (profiles/r05_ab_scan_atomic_width.log), and a 32-bit index plus a load of the region's offset costs the same 86 - 89 ms:
 // the pass pays per memory REQUEST of a record (capped layout: two), whatever its kind.
+constexpr int SCAN_DEFER_MAX = 16;                       // slices of the partition space at most
 constexpr int SCAN_HIST = 0, SCAN_EMIT = 1, SCAN_EMIT_CAPPED = 2;
 constexpr int OVF_CAP_BITS = 28;                         // (a partition of more than 2^28 records spills its excess, and the step then falls back to the exact layout)
 constexpr uint64_t OVF_CAP_MASK = (1ULL << OVF_CAP_BITS) - 1ULL;
@@ -115,10 +129,11 @@ CDBG_DEV uint32_t scan_reserve_record(const ScanParams& P, uint32_t lpart) {
     if (MODE == SCAN_HIST) { atomic_add_u32(&P.part_count[lpart], 1u); return 0u; }
     return atomic_add_u32(&P.part_fill[lpart], 1u);
 }
+// where record j of partition lpart goes (nullptr: nowhere -- HIST pass, or the spill list is full and the step falls back to the exact layout)
 template <int W, int MODE>
-CDBG_DEV void scan_finish_record(const ScanParams& P, const uint32_t* pk, int bitoff, uint32_t meta, uint32_t lpart, uint32_t j) {
+CDBG_DEV uint64_t* scan_record_dst(const ScanParams& P, uint32_t lpart, uint32_t j) {
     constexpr int RW = RecFmt<W>::RW;
-    if (MODE == SCAN_HIST) return;
+    if (MODE == SCAN_HIST) return nullptr;
     uint64_t* dst;
     bool fits;
     if (MODE == SCAN_EMIT) {
@@ -141,16 +156,52 @@ CDBG_DEV void scan_finish_record(const ScanParams& P, const uint32_t* pk, int bi
     }
     if (!fits) {
         const uint64_t o = atomic_add_u64(P.spill_cursor, 1ULL);
-        if (o >= P.spill_cap) { *P.error = 6; return; }
+        if (o >= P.spill_cap) { *P.error = 6; return nullptr; }
         P.spill_part[o] = lpart;
         dst = P.spill_recs + o * RW;
     }
-    // Records of 32 bytes and more leave as 16-byte stores (RW is even, a record is 16-byte aligned): config-4 share scan 53.8 -> 48.8 ms, config-5 share
-    // 19.0 -> 17.9.  The 16-byte record of a ONE-word k-mer stays TWO 8-byte stores: the L2 then counts 3.2 G write requests for 1.6 G records (4.95 G requests
-    // in all) -- and still runs the pass in 66 ms, while ONE 16-byte store per record (3.34 G requests) takes 132 - 150 ms: a lane's scattered 16-byte store
-    // behind its returning atomic runs at the 11 G/s of round 4's micro-benchmark (profiles/r04_micro_sector_store.log), two 8-byte stores -- the second
-    // one hits the sector the first opened -- at more than twice that (profiles/r05_scan_request_counters.log).
+    return dst;
+}
+// the RW words of a record (w[0] least significant: the meta word) to dst
+// Records of 32 bytes and more leave as 16-byte stores (RW is even, a record is 16-byte aligned): config-4 share scan 53.8 -> 48.8 ms, config-5 share
+// 19.0 -> 17.9.  The 16-byte record of a ONE-word k-mer stays TWO 8-byte stores: the L2 then counts 3.2 G write requests for 1.6 G records (4.95 G requests
+// in all) -- and still runs the pass in 66 ms, while ONE 16-byte store per record (3.34 G requests) takes 132 - 150 ms: a lane's scattered 16-byte store
+// behind its returning atomic runs at the 11 G/s of round 4's micro-benchmark (profiles/r04_micro_sector_store.log), two 8-byte stores -- the second
+// one hits the sector the first opened -- at more than twice that (profiles/r05_scan_request_counters.log).
+template <int W>
+CDBG_DEV void scan_store_words(uint64_t* dst, const uint64_t (&w)[RecFmt<W>::RW]) {
+    constexpr int RW = RecFmt<W>::RW;
     static_assert(RW % 2 == 0, "records are pairs of words");
+    if (RW == 2 && !CDBG_REC16_W1) {
+        // (the compiler barrier keeps the pair apart: with both words in registers at once it merges them into one global_store_dwordx4 -- round 6's first
+        //  placement kernel ran 0.8 G records in 53 ms that way, 35 ms with two stores: profiles/r06_ab_overlap_place_vs_count.log)
+        dst[1] = w[1]; CDBG_COMPILER_BARRIER(); dst[0] = w[0];
+        return;
+    }
+#pragma unroll
+    for (int i = RW - 2; i >= 0; i -= 2) {
+        RecPair v; v.lo = w[i]; v.hi = w[i + 1];
+        *reinterpret_cast<RecPair*>(&dst[i]) = v;
+    }
+}
+// the RW words of the record whose first base sits at bit offset bitoff of the tile's packed 2-bit stream
+template <int W>
+CDBG_DEV void scan_record_words(const uint32_t* pk, int bitoff, uint32_t meta, uint64_t (&w)[RecFmt<W>::RW]) {
+    constexpr int RW = RecFmt<W>::RW;
+#pragma unroll
+    for (int wv = 0; wv < RW; ++wv) {
+        uint64_t x = scan_get64(pk, bitoff + 64 * wv);
+        if (wv == RW - 1) x = (x & ~0xFFFFULL) | meta;
+        w[RW - 1 - wv] = x;
+    }
+}
+template <int W, int MODE>
+CDBG_DEV void scan_finish_record(const ScanParams& P, const uint32_t* pk, int bitoff, uint32_t meta, uint32_t lpart, uint32_t j) {
+    constexpr int RW = RecFmt<W>::RW;
+    if (MODE == SCAN_HIST) return;
+    uint64_t* dst = scan_record_dst<W, MODE>(P, lpart, j);
+    if (dst == nullptr) return;
+    // (words cut out of the tile's packed stream and stored one by one / pair by pair: for the 16-byte record the two 8-byte stores stay apart this way)
     if (RW == 2 && !CDBG_REC16_W1) {
 #pragma unroll
         for (int wv = 0; wv < RW; ++wv) {
@@ -169,9 +220,78 @@ CDBG_DEV void scan_finish_record(const ScanParams& P, const uint32_t* pk, int bi
         *reinterpret_cast<RecPair*>(&dst[RW - 2 - wv]) = v;
     }
 }
+// sdefer: the workgroup's stream cursors (LDS, SCAN_DEFER_MAX words, zeroed by the kernel when it starts)
 template <int W, int MODE>
-CDBG_DEV void scan_emit_record(const ScanParams& P, const uint32_t* pk, int bitoff, uint32_t meta, uint32_t lpart) {
+CDBG_DEV void scan_emit_record(const ScanParams& P, const uint32_t* pk, int bitoff, uint32_t meta, uint32_t lpart, uint32_t* sdefer) {
+    if (MODE == SCAN_EMIT_CAPPED && P.defer_slices > 1u) {
+        // deferred placement (ScanParams): a record of slice q > 0 joins the workgroup's segment of stream q.  The lanes of the wave that hold a record of
+        // the same slice take consecutive slots behind ONE LDS atomic (wave_append_slots, devrt.h) and write 16 bytes each side by side; divergent control flow
+        const uint32_t sl = (uint32_t)(P.defer_map >> (4u * (lpart >> P.defer_shift))) & 15u;
+        if (sl) {
+            constexpr int RW = RecFmt<W>::RW;
+            uint32_t slot = P.defer_seg_cap;
+            for (uint32_t q = 1; q < P.defer_slices; ++q)     // (uniform trip count; the body runs for the lanes of slice q)
+                if (sl == q) slot = wave_append_slots(&sdefer[q]);
+            if (slot < P.defer_seg_cap) {
+                const uint64_t at = ((uint64_t)(sl - 1u) * P.defer_nseg + blockIdx.x) * P.defer_seg_cap + slot;
+                uint64_t w[RW];
+                scan_record_words<W>(pk, bitoff, meta, w);
+                uint64_t* dst = P.defer_recs + at * RW;
+#pragma unroll
+                for (int i = 0; i < RW; i += 2) { RecPair v; v.lo = w[i]; v.hi = w[i + 1]; *reinterpret_cast<RecPair*>(&dst[i]) = v; }
+                P.defer_part[at] = lpart;
+                return;
+            }                                                // (segment full: placed here and now)
+        }
+    }
     scan_finish_record<W, MODE>(P, pk, bitoff, meta, lpart, scan_reserve_record<MODE>(P, lpart));
+}
+// the workgroup's stream cursors: cleared when the kernel starts, published when it ends (both behind / before a workgroup barrier of the caller)
+template <int MODE>
+CDBG_DEV void scan_defer_init(const ScanParams& P, uint32_t* sdefer) { if (MODE == SCAN_EMIT_CAPPED && P.defer_slices > 1u && threadIdx.x < (unsigned)SCAN_DEFER_MAX) sdefer[threadIdx.x] = 0; }
+template <int MODE>
+CDBG_DEV void scan_defer_publish(const ScanParams& P, const uint32_t* sdefer) {
+    if (MODE == SCAN_EMIT_CAPPED && P.defer_slices > 1u && threadIdx.x >= 1u && threadIdx.x < P.defer_slices)
+        P.defer_count[(uint64_t)(threadIdx.x - 1u) * P.defer_nseg + blockIdx.x] = sdefer[threadIdx.x];
+}
+
+// ---- deferred placement, second half: stream `slice` of a scan with ScanParams::defer_slices > 1 into the partition regions ----
+// One-wave workgroups, up to four records per lane and round: that many returning atomics in flight before the first store.  No LDS and few registers: the
+// waves fit beside the count stage's workgroups (which fill the CU's LDS but only 24 of its 32 wave slots), and 4 waves per CU saturate the memory side
+// (profiles/r06_ab_overlap_place_vs_count.log: 0.8 G records alone 35 ms; beside k_count_fast<1> 40 ms, and the count 57 -> 70 ms instead of 57 + 35).
+struct PlaceParams { ScanParams sp; uint32_t slice; };
+template <int W>
+__global__ void __launch_bounds__(64) k_place(PlaceParams Q) {
+    constexpr int RW = RecFmt<W>::RW;
+    constexpr int PLACE_U = RW <= 2 ? 4 : RW <= 4 ? 2 : 1;   // (records in flight per lane: bounded by registers for the wider records)
+    const ScanParams& P = Q.sp;
+    for (uint32_t seg = blockIdx.x; seg < P.defer_nseg; seg += gridDim.x) {
+        const uint64_t sidx = (uint64_t)(Q.slice - 1u) * P.defer_nseg + seg;
+        const uint32_t n0 = uni_u32(P.defer_count[sidx]);
+        const uint32_t n = n0 < P.defer_seg_cap ? n0 : P.defer_seg_cap;   // (appends beyond the capacity were placed by the scan)
+        const uint64_t base = sidx * P.defer_seg_cap;
+        for (uint32_t b = 0; b < n; b += 64u * PLACE_U) {
+            uint64_t w[PLACE_U][RW]; uint32_t p[PLACE_U], j[PLACE_U];
+#pragma unroll
+            for (int u = 0; u < PLACE_U; ++u) {
+                const uint32_t i = b + (uint32_t)u * 64u + threadIdx.x;
+                p[u] = 0xFFFFFFFFu;
+                if (i < n) {
+                    p[u] = P.defer_part[base + i];
+                    const uint64_t* src = P.defer_recs + (base + i) * RW;
+#pragma unroll
+                    for (int q = 0; q < RW; q += 2) { const RecPair v = *reinterpret_cast<const RecPair*>(&src[q]); w[u][q] = v.lo; w[u][q + 1] = v.hi; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PLACE_U; ++u) if (p[u] != 0xFFFFFFFFu) j[u] = scan_reserve_record<SCAN_EMIT_CAPPED>(P, p[u]);
+#pragma unroll
+            for (int u = 0; u < PLACE_U; ++u) if (p[u] != 0xFFFFFFFFu) {
+                uint64_t* dst = scan_record_dst<W, SCAN_EMIT_CAPPED>(P, p[u], j[u]);
+                if (dst != nullptr) scan_store_words<W>(dst, w[u]);
+            }
+        }
+    }
 }
 
 template <int W, int MODE>
@@ -185,6 +305,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     CDBG_SHARED uint64_t brk[SCAN_TILE / 64 + 2];
     CDBG_SHARED uint64_t stt[SCAN_TILE / 64 + 2];
     CDBG_SHARED uint32_t s_members, s_trav, s_nrec, s_nstart;
+    CDBG_SHARED uint32_t s_defer[SCAN_DEFER_MAX];            // deferred placement: this workgroup's stream cursors
     constexpr uint32_t LIST_CAP = (SCAN_NKEY - SCAN_TILE / 2) / 2;     // staged records (two words each) behind the run-start list
 
     const int tid = threadIdx.x;
@@ -194,6 +315,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
 #endif
     uint64_t n_members = 0, n_trav = 0;
     if (tid == 0) { s_members = 0; s_trav = 0; }
+    scan_defer_init<MODE>(P, s_defer);                       // (the first tile's barriers come before any record)
     // persistent workgroups stride over the tiles (a workgroup launch per ~30 us tile costs more than the tile)
     for (uint64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
     const int64_t t0 = ((int64_t)tile * P.tile_stride + P.tile_offset) * SCAN_TILE;
@@ -399,7 +521,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
                 // rounds of device-atomic latency instead of one per loop iteration
                 const uint32_t li = atomic_add_u32(&s_nrec, 1u);
                 if (li < LIST_CAP) { lst[2 * li] = (uint32_t)ms | (meta << 16); lst[2 * li + 1] = lpart; }
-                else scan_emit_record<W, MODE>(P, pk, 2 * (15 + ms), meta, lpart);   // list full (low-complexity tile)
+                else scan_emit_record<W, MODE>(P, pk, 2 * (15 + ms), meta, lpart, s_defer);   // list full (low-complexity tile)
                 n_members += (uint64_t)n;
                 n_trav += (ft ? 1 : 0) + (lt ? 1 : 0);
             }
@@ -412,7 +534,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
     {
         const uint32_t nl = s_nrec < LIST_CAP ? s_nrec : LIST_CAP;
         for (uint32_t i = tid; i < nl; i += SCAN_THREADS)
-            scan_emit_record<W, MODE>(P, pk, 2 * (15 + (int)(lst[2 * i] & 0xFFFFu)), lst[2 * i] >> 16, lst[2 * i + 1]);
+            scan_emit_record<W, MODE>(P, pk, 2 * (15 + (int)(lst[2 * i] & 0xFFFFu)), lst[2 * i] >> 16, lst[2 * i + 1], s_defer);
     }
     __syncthreads();                                    // the next tile reuses the LDS arrays
     CDBG_SPH(5);
@@ -420,6 +542,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan(ScanParams P) {
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
     if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) atomic_add_u64(&P.stats[16 + i], sph[i]);
 #endif
+    scan_defer_publish<MODE>(P, s_defer);                    // (behind the last tile's closing barrier)
     if (MODE != SCAN_EMIT || P.var_limit) {             // one device atomic per workgroup, not per lane (the exact layout's histogram pass counted already)
         uint32_t nm = (uint32_t)n_members, nt = (uint32_t)n_trav;
 #pragma unroll

@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (W
     CDBG_SHARED uint32_t stt[SCANF_NQ / 32 + 4];              // bit q: junction q starts a run
     CDBG_SHARED uint16_t sl[SCANF_TILE + 16];                 // compacted run starts
     CDBG_SHARED uint32_t s_wsum[SCAN_THREADS / 64], s_nstart, s_members, s_trav;
+    CDBG_SHARED uint32_t s_defer[SCAN_DEFER_MAX];            // deferred placement: this workgroup's stream cursors
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = P.k, m = P.m, WN = k - m;
@@ -62,6 +63,7 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (W
 #endif
     uint32_t n_members = 0, n_trav = 0;
     if (tid == 0) { s_members = 0; s_trav = 0; }
+    scan_defer_init<MODE>(P, s_defer);                       // (the first tile's barriers come before any record)
     // persistent workgroups: a tile lives ~30 us, far too short to pay a workgroup launch for each
     for (uint64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
     const int64_t t0 = ((int64_t)tile * P.tile_stride + P.tile_offset) * SCANF_TILE;
@@ -316,7 +318,7 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (W
                 if (lt) meta |= 0x200u;
                 if (firstchunk && first_incl && first_foreign) meta |= 0x400u;
                 if ((ce == e) && last_incl && last_foreign) meta |= 0x800u;
-                scan_emit_record<W, MODE>(P, pk, 2 * ms, meta, lpart);
+                scan_emit_record<W, MODE>(P, pk, 2 * ms, meta, lpart, s_defer);
                 n_members += (uint32_t)n;
                 n_trav += (ft ? 1u : 0u) + (lt ? 1u : 0u);
             }
@@ -330,6 +332,7 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (W
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
     if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) atomic_add_u64(&P.stats[16 + i], sph[i]);
 #endif
+    scan_defer_publish<MODE>(P, s_defer);                    // (behind the last tile's closing barrier)
     if (MODE != SCAN_EMIT || P.var_limit) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { n_members += __shfl_xor(n_members, d); n_trav += __shfl_xor(n_trav, d); }

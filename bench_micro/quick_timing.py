@@ -12,6 +12,6 @@ for n_reads in [int(x) for x in sys.argv[1].split(",")]:
     for rep in range(reps):
         t1 = time.time(); g.run(); t2 = time.time()
         st = g.stats(); g.reset()
-        keys = ("n_distinct", "n_big_partitions", "n_multipass_partitions", "minimizer_size", "log2_partitions", "ms_scan_hist", "ms_scan_emit", "ms_count", "ms_compact", "ms_glue")
+        keys = ("n_distinct", "n_big_partitions", "n_multipass_partitions", "minimizer_size", "log2_partitions", "ms_scan_hist", "ms_scan_emit", "ms_count", "ms_place", "count_slices", "ms_compact", "ms_glue")
         print(json.dumps({"n_reads": n_reads, "k": k, "run_wall_ms": round((t2 - t1) * 1e3, 1), "Gkmers_per_s": round(st["n_distinct"] / (t2 - t1) / 1e9, 3), **{x: (round(st[x], 2) if isinstance(st[x], float) else st[x]) for x in keys}}), flush=True)
     g.close()

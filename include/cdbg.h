@@ -73,12 +73,19 @@ typedef struct cdbg_stats_t {
                                         the replicated exchange -- emit_replicated, or closed chains across ranks) */
     uint64_t n_walked_unitigs;       /* unitigs written by walks from the chain heads (k_walk.h: one GPU, no chain beyond the step limit, no
                                         closed chain); 0: the list-ranking path of k_glue.h glued this run */
+    /* ABI 7 -- deferred record placement: the partition space is cut into count_slices ranges; the scan places the records
+     * of the first itself and appends the others to streams, which k_place scatters on a second HIP stream WHILE the count stage counts the
+     * slice before.  ms_scan_emit is then the scan kernel alone, ms_count the wall from the scan's end to the count stage's end (it contains
+     * the waits for the placement), ms_place the busy span of the placement stream (overlapped with ms_count, not a summand of the step). */
+    uint64_t n_deferred_records;     /* records that went through the streams (0: the scan placed every record itself) */
+    float ms_place;
+    int count_slices;                /* 1: no deferral */
 } cdbg_stats_t;
 
 /* ABI version: bumped whenever a struct of this header changes.  From version 5 on cdbg_stats_t only ever GROWS AT ITS END;
  * a binding checks cdbg_abi_version() against the header it was written for and sizeof(cdbg_stats_t) against
  * cdbg_stats_sizeof() when it loads the library (bcalm_amd/api.py does), instead of reading fields at stale offsets. */
-#define CDBG_ABI_VERSION 6
+#define CDBG_ABI_VERSION 7
 int cdbg_abi_version(void);
 uint64_t cdbg_stats_sizeof(void);
 

@@ -232,6 +232,8 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t = 0) { me
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = 0) { memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = 0; return hipSuccess; }
+enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = 1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hostsim_event{0}; return hipSuccess; }

@@ -297,6 +297,26 @@ def test_identical_multiword_keys_in_one_wave_gpu(oracle, hip, k):
         assert_parity(oracle, hip, "\n".join([r, rc] * 1000) + "\n", k, 2, log2_partitions=log_np)
 
 
+@pytest.mark.parametrize("k,cfg,n_reads,read_len,log_np", [(31, 3, 60000, 150, 12), (55, 4, 40000, 150, 11), (127, 5, 3000, 1000, 10), (255, 5, 1500, 1000, 10)])
+@pytest.mark.parametrize("slices,part_cap,defer_cap", [("2", None, None), ("4", None, None), ("16", None, None), ("4,4,4,2,1,1", None, None), ("8,4,2,1,1", None, None), ("4", "260", None), ("4", None, "16"), ("0", None, None)])
+def test_deferred_record_placement_gpu(oracle, hip, k, cfg, n_reads, read_len, log_np, slices, part_cap, defer_cap, monkeypatch):
+    """deferred placement on the device (host_count.h, k_scan.h k_place): the scan places the first slice of the partition space and appends the
+    records of the others to streams; k_place scatters stream q on a second HIP stream while k_count_fast counts slice q - 1 (events between
+    them).  Against the oracle: unitig set and (k-mer, count) set, for one-, two-, four- and eight-word k-mers; 2 / 4 / 16 slices; regions so
+    small that k_place spills (repair behind the last stream); streams so small that they fill up (the scan places the rest); 0 = off"""
+    monkeypatch.setenv("CDBG_SCAN_MODE", "capped"); monkeypatch.setenv("CDBG_DEFER_SLICES", slices)
+    if part_cap:
+        monkeypatch.setenv("CDBG_PART_CAP", part_cap)
+    if defer_cap:
+        monkeypatch.setenv("CDBG_DEFER_CAP", defer_cap)
+    text = oracle.synth_reads(n_reads, read_len, cfg)
+    st = assert_parity(oracle, hip, text, k, 2, log2_partitions=log_np)["stats"]
+    if slices == "0":
+        assert st["count_slices"] == 1 and st["n_deferred_records"] == 0
+    else:
+        assert st["count_slices"] == (len(slices.split(",")) if "," in slices else int(slices)) and st["n_deferred_records"] > 0
+
+
 @pytest.mark.parametrize("part_cap", [None, "64"])
 def test_capped_single_pass_scan_gpu(oracle, hip, part_cap, monkeypatch):
     """the large-input scan path (single pass, fixed-capacity partition regions, spill repair)"""

@@ -140,6 +140,34 @@ def test_capped_single_pass_scan(oracle, sim, key, part_cap, monkeypatch):
     assert_parity(oracle, sim, oracle_lib.read_input(name), k, amin, log2_partitions=4)
 
 
+@pytest.mark.parametrize("key", ["rand_a/15/2", "rand_b/31/2", "rand_w2/55/2", "rand_w4/127/1"])
+@pytest.mark.parametrize("slices,part_cap,defer_cap", [("2", None, None), ("4", None, None), ("16", None, None), ("4,4,4,2,1,1", None, None), ("8,4,2,1,1", None, None), ("4", "1", None), ("4", None, "3"), ("8", "2", "5")])
+def test_deferred_record_placement(oracle, sim, key, slices, part_cap, defer_cap, monkeypatch):
+    """deferred placement (host_count.h, k_scan.h k_place): the scan places the records of the first slice of the partition space and appends
+    the others to streams, which k_place scatters while the one-pass count tier runs slice by slice.  Same unitigs and the same (k-mer, count)
+    set as the oracle: with 2 / 4 / 16 slices; with regions so small that the placement kernel spills (repair after the last stream); with streams
+    so small that most records find them full and are placed by the scan after all"""
+    monkeypatch.setenv("CDBG_SCAN_MODE", "capped"); monkeypatch.setenv("CDBG_DEFER_SLICES", slices)
+    if part_cap:
+        monkeypatch.setenv("CDBG_PART_CAP", part_cap)
+    if defer_cap:
+        monkeypatch.setenv("CDBG_DEFER_CAP", defer_cap)
+    name, k, amin = _case(key)
+    text = oracle_lib.read_input(name)
+    text = text + oracle.synth_reads(60, 150, 3).decode() if isinstance(text, str) else text + oracle.synth_reads(60, 150, 3)
+    st = assert_parity(oracle, sim, text, k, amin, log2_partitions=10)["stats"]
+    assert st["count_slices"] == (len(slices.split(",")) if "," in slices else int(slices)) and st["n_deferred_records"] > 0
+    if not defer_cap and "," not in slices and st["n_records"] > 500:
+        assert st["n_deferred_records"] > st["n_records"] * (int(slices) - 1) // int(slices) * 3 // 4      # ~ (S - 1) / S of the records went through the streams
+
+
+def test_deferred_placement_off_for_few_partitions(oracle, sim, monkeypatch):
+    """fewer than 64 partitions per slice: every record placed by the scan, one launch of the count tier"""
+    monkeypatch.setenv("CDBG_SCAN_MODE", "capped")
+    st = assert_parity(oracle, sim, oracle_lib.read_input("rand_b"), 31, 2, log2_partitions=6)["stats"]
+    assert st["count_slices"] == 1 and st["n_deferred_records"] == 0
+
+
 @pytest.mark.parametrize("key", ["rand_a/15/2", "rand_w2/55/2", "rand_w4/127/1", "circ_test3/7/1"])
 @pytest.mark.parametrize("mode", ["log", "table", "overflow", "rank", "walkmax"])
 def test_glue_record_paths(oracle, sim, key, mode, monkeypatch):
