@@ -750,8 +750,9 @@ int count_impl(cdbg_ctx* c) {
         // Round 4 took records x the largest record of the format: 3 - 5 x too many slots, which one workgroup clears and sweeps
         HIPCK(hipMemcpy(c->big_list.p, bl.data(), nbig * sizeof(uint32_t), hipMemcpyHostToDevice));
         DBuf<uint64_t> d_members; CK(d_members.alloc(nbig, true));
+        DBuf<uint32_t> d_nrec; CK(d_nrec.alloc(nbig, false));
         { CountParams mp = cp; mp.part_list = c->big_list.p; mp.n_items = nbig;
-          BigMembersParams bm{ mp, RW, d_members.p };
+          BigMembersParams bm{ mp, RW, d_members.p, d_nrec.p };
           CDBG_LAUNCH(k_big_members, nbig, 256, s, bm); }
         std::vector<uint64_t> h_members(nbig); CK(read_u64(d_members.p, h_members.data(), nbig));
         for (uint32_t i = 0; i < nbig; ++i) offs[i + 1] = offs[i] + pow2_at_least(2 * h_members[i] + 4 * 256);
@@ -761,8 +762,31 @@ int count_impl(cdbg_ctx* c) {
         CountParams bp = cp;
         bp.part_list = c->big_list.p; bp.g_keys = g_keys.p; bp.g_cnt = g_cnt.p; bp.big_off = big_off.p;
         bp.n_items = nbig; bp.max_passes = 1;
-        // (grid bounded: every workgroup reserves whole output chunks, the slack is sized for PERSISTENT_GRID)
-        CDBG_LAUNCH((k_count<W, TS, 256, true>), std::min<uint64_t>(nbig, PERSISTENT_GRID), 256, s, bp);
+        if (c->knobs.get("CDBG_BIG_ONE_WG") != nullptr) {
+            // (dev knob: round 5's pass -- one 256-thread workgroup per listed partition; the grid bounded: every workgroup reserves whole output chunks, the slack is sized for PERSISTENT_GRID)
+            CDBG_LAUNCH((k_count<W, TS, 256, true>), std::min<uint64_t>(nbig, PERSISTENT_GRID), 256, s, bp);
+        } else {
+            // grid-wide (k_count.h): all workgroups share the listed partitions' records, clear and sweep the tables slot by slot; the segments of the
+            // solid arrays are reserved between the two sweeps -- every other launch of the stage has finished, the cursor is the host's to advance
+            DBuf<uint64_t> rec_pref, seg_pref; DBuf<uint32_t> nsolid, wr;
+            CK(rec_pref.alloc(nbig + 1, false)); CK(seg_pref.alloc(nbig + 1, false)); CK(nsolid.alloc(nbig, true)); CK(wr.alloc(nbig, true));
+            CK(exscan_u32(c, d_nrec.p, rec_pref.p, nbig));
+            BigGridParams bg{ bp, RW, rec_pref.p, nsolid.p, seg_pref.p, 0, wr.p };
+            const uint64_t grid = resident_grid(k_big_insert<W>, 256, 256 * 4);
+            CDBG_LAUNCH(k_big_clear<W>, std::min<uint64_t>((offs[nbig] + 255) / 256, 256 * 16), 256, s, bg);
+            CDBG_LAUNCH(k_big_insert<W>, grid, 256, s, bg);
+            CDBG_LAUNCH((k_big_sweep<W, 0>), std::min<uint64_t>((offs[nbig] + 255) / 256, 256 * 16), 256, s, bg);
+            CK(exscan_u32(c, nsolid.p, seg_pref.p, nbig));
+            uint64_t n_out = 0, cur = 0; CK(read_u64(seg_pref.p + nbig, &n_out)); CK(read_u64(c->solid_cursor.p, &cur));
+            if (cur + n_out > solid_cap) { const uint32_t one = 1; HIPCK(hipMemcpy(c->derr.p, &one, sizeof one, hipMemcpyHostToDevice)); n_out = 0; }   // (as the kernels report it: the attempt with the bound follows)
+            else {
+                const uint64_t upd = cur + n_out; HIPCK(hipMemcpy(c->solid_cursor.p, &upd, sizeof upd, hipMemcpyHostToDevice));
+                bg.seg_base = cur;
+                CDBG_LAUNCH(k_big_segments, (nbig + 255) / 256, 256, s, bg);
+                CDBG_LAUNCH((k_big_sweep<W, 1>), std::min<uint64_t>((offs[nbig] + 255) / 256, 256 * 16), 256, s, bg);
+            }
+            HIPCK(hipStreamSynchronize(s));                  // (the prefix arrays are this block's)
+        }
         c->st.n_big_partitions += nbig;
     }
     CK(t.stop(&c->st.ms_count)); c->st.ms_count += ms_count_first;

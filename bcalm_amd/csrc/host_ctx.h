@@ -215,7 +215,7 @@ int glue_table_slots(uint64_t want, uint32_t* out) {
 struct Knobs {
     std::vector<std::pair<std::string, std::string>> kv;
     void snapshot() {
-        static const char* const NAMES[] = { "CDBG_MAX_PASSES", "CDBG_CW_TIER3", "CDBG_CW_TIER2", "CDBG_SCAN_TWO_LEVEL", "CDBG_COUNT_MAX_SUB", "CDBG_VAR_RESAMPLE", "CDBG_EXACT_NO_CUR32", "CDBG_SOLID_FIRST_TINY", "CDBG_PREWARM_MIN_BYTES", "CDBG_NO_PREWARM", "CDBG_DEBUG_SEGHIST", "CDBG_FAST_MAX_RECORDS", "CDBG_FAST_SKIP2_Q8", "CDBG_FAST_SKIP_Q8", "CDBG_FORCE_MULTI", "CDBG_GENERIC_SCAN", "CDBG_GLUE_LOG", "CDBG_GLUE_RANK", "CDBG_GLUE_REPLICATED", "CDBG_GLUE_TABLE", "CDBG_JOIN_LOG_JB", "CDBG_NO_COUNT_TIER2", "CDBG_NO_SIFT", "CDBG_NO_SPLIT", "CDBG_PART_CAP", "CDBG_REPAIR_MAX_PASSES", "CDBG_SCAN_MODE", "CDBG_STAGE_BYTES", "CDBG_STREAM_BATCH_TILES", "CDBG_STREAM_MIN_BYTES", "CDBG_VAR_SCALE", "CDBG_WALK_MAX", "CDBG_DEFER_SLICES", "CDBG_DEFER_CAP", "CDBG_PLACE_GRID" };
+        static const char* const NAMES[] = { "CDBG_MAX_PASSES", "CDBG_CW_TIER3", "CDBG_CW_TIER2", "CDBG_SCAN_TWO_LEVEL", "CDBG_COUNT_MAX_SUB", "CDBG_VAR_RESAMPLE", "CDBG_EXACT_NO_CUR32", "CDBG_SOLID_FIRST_TINY", "CDBG_PREWARM_MIN_BYTES", "CDBG_NO_PREWARM", "CDBG_DEBUG_SEGHIST", "CDBG_FAST_MAX_RECORDS", "CDBG_FAST_SKIP2_Q8", "CDBG_FAST_SKIP_Q8", "CDBG_FORCE_MULTI", "CDBG_GENERIC_SCAN", "CDBG_GLUE_LOG", "CDBG_GLUE_RANK", "CDBG_GLUE_REPLICATED", "CDBG_GLUE_TABLE", "CDBG_JOIN_LOG_JB", "CDBG_NO_COUNT_TIER2", "CDBG_NO_SIFT", "CDBG_NO_SPLIT", "CDBG_PART_CAP", "CDBG_REPAIR_MAX_PASSES", "CDBG_SCAN_MODE", "CDBG_STAGE_BYTES", "CDBG_STREAM_BATCH_TILES", "CDBG_STREAM_MIN_BYTES", "CDBG_VAR_SCALE", "CDBG_WALK_MAX", "CDBG_DEFER_SLICES", "CDBG_DEFER_CAP", "CDBG_PLACE_GRID", "CDBG_BIG_ONE_WG" };
         for (const char* n : NAMES) if (const char* e = getenv(n)) kv.emplace_back(n, e);
     }
     const char* get(const char* name) const { for (const auto& p : kv) if (p.first == name) return p.second.c_str(); return nullptr; }

@@ -668,19 +668,167 @@ __global__ void __launch_bounds__(NT, lds_waves_per_simd(GLOBAL ? 1024 : (size_t
 
 // member k-mers of every LISTED partition (the HBM-table pass sizes its tables from them: round 5 -- records x the largest record a format
 // allows over-sized them 3 - 5 x, and one workgroup clears and sweeps a table: at k = 127 a partition of a repeat's locus had 600 MB of it)
-struct BigMembersParams { CountParams c; int RW; uint64_t* members; };   // RW: words per record
+struct BigMembersParams { CountParams c; int RW; uint64_t* members; uint32_t* nrec; };   // RW: words per record; nrec: records of every listed partition (the grid-wide pass below)
+// records [rec0, rec1) of partition p in the layout the stage runs with (capped regions, begin / end pairs, exact offsets)
+CDBG_DEV void count_part_range(const CountParams& P, uint32_t p, uint64_t& rec0, uint64_t& rec1) {
+    if (P.part_stride) { const uint32_t f = P.part_fill[p]; rec0 = (uint64_t)p * P.part_stride; rec1 = rec0 + (f > P.part_stride ? 0u : f); }
+    else if (P.part_pairs) { rec0 = P.part_off[2ull * p]; rec1 = P.part_off[2ull * p + 1]; }
+    else { rec0 = P.part_off[p]; rec1 = P.part_off[p + 1]; }
+}
 __global__ void k_big_members(BigMembersParams B) {
     const CountParams& P = B.c;
     const uint32_t item = blockIdx.x;
     const uint32_t p = P.part_list[item];
-    uint64_t rec0, rec1;
-    if (P.part_stride) { const uint32_t f = P.part_fill[p]; rec0 = (uint64_t)p * P.part_stride; rec1 = rec0 + (f > P.part_stride ? 0u : f); }
-    else if (P.part_pairs) { rec0 = P.part_off[2ull * p]; rec1 = P.part_off[2ull * p + 1]; }
-    else { rec0 = P.part_off[p]; rec1 = P.part_off[p + 1]; }
+    uint64_t rec0, rec1; count_part_range(P, p, rec0, rec1);
+    if (threadIdx.x == 0) B.nrec[item] = (uint32_t)(rec1 - rec0);
     uint64_t mine = 0;
     for (uint64_t i = rec0 + threadIdx.x; i < rec1; i += blockDim.x) mine += P.records[i * B.RW] & 0xFFu;
     mine = wave_sum_u64(mine);
     if ((threadIdx.x & 63) == 0 && mine) atomic_add_u64(&B.members[item], mine);
+}
+
+// ---------------------------------------------------------------------------
+// HBM-table pass, GRID-WIDE (round 6).  The partitions that no LDS tier takes -- a repeat's locus at long k brings 10^5 - 10^6 distinct
+// k-mers into one partition -- used to get ONE 256-thread workgroup each (count_partition<.., GLOBAL>): the largest partition was the
+// stage's tail, and sending more partitions here (fewer LDS passes) made it worse (hostile k = 127 share: 2.0 s at 16 LDS passes, 8.4 s
+// at 4; profiles/r05_hostile_long_k.log).  Now the listed partitions' records are ONE list that all workgroups share 64 records at a time
+// (k_big_insert: a lane finds its record's partition in the prefix of the record counts), the tables are cleared and swept slot by slot
+// by the whole grid (k_big_clear / k_big_sweep: a wave's 64 slots lie in one table -- every table is a power of two >= 1024), and a
+// partition's segment of the solid arrays is reserved between the two sweeps from the exact number of its solid entries.
+// ---------------------------------------------------------------------------
+struct BigGridParams {
+    CountParams c;                 // part_list: the listed partitions; big_off / g_keys / g_cnt: their tables; n_items
+    int RW;
+    const uint64_t* rec_pref;      // [n_items + 1] exclusive prefix of the partitions' record counts
+    uint32_t* nsolid;              // [n_items] solid entries of every partition (sweep 0; zeroed by the host)
+    const uint64_t* seg_pref;      // [n_items + 1] exclusive prefix of nsolid (sweep 1)
+    uint64_t seg_base;             // first entry of the listed partitions' segments in the solid arrays
+    uint32_t* wr;                  // [n_items] write cursors (sweep 1; zeroed by the host)
+};
+// largest i < n with pref[i] <= x (pref[0] = 0 <= x)
+CDBG_DEV uint32_t big_find(const uint64_t* pref, uint32_t n, uint64_t x) {
+    uint32_t lo = 0, hi = n;                               // invariant: pref[lo] <= x < pref[hi]
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (pref[mid] <= x) lo = mid; else hi = mid; }
+    return lo;
+}
+template <int W>
+__global__ void __launch_bounds__(256) k_big_clear(BigGridParams B) {
+    const CountParams& P = B.c;
+    const uint64_t total = P.big_off[P.n_items], stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) { P.g_keys[s * W + (W - 1)] = KEY_EMPTY; P.g_cnt[s] = 0; }
+}
+template <int W>
+__global__ void __launch_bounds__(256) k_big_insert(BigGridParams B) {
+    constexpr int RW = RecFmt<W>::RW;
+    const CountParams& P = B.c;
+    const int lane = threadIdx.x & 63;
+    const uint64_t total = B.rec_pref[P.n_items];
+    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6), gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int k = P.k;
+    for (uint64_t b0 = gw * 64; b0 < total; b0 += nwaves * 64) {   // wave-uniform
+        RecView<W> R; int n = 0; uint32_t item = 0;
+#pragma unroll
+        for (int i = 0; i < RW; ++i) R.r[i] = 0;
+        if (b0 + (uint64_t)lane < total) {
+            const uint64_t r = b0 + (uint64_t)lane;
+            item = big_find(B.rec_pref, P.n_items, r);
+            uint64_t rec0, rec1; count_part_range(P, P.part_list[item], rec0, rec1);
+            const uint64_t at = rec0 + (r - B.rec_pref[item]);
+#pragma unroll
+            for (int i = 0; i < RW; ++i) R.r[i] = P.records[at * RW + i];
+            n = R.n();
+        }
+        int incl = n;                                      // inclusive prefix sum over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+        const int excl = incl - n;
+        const int total_m = __shfl(incl, 63);
+        for (int g0 = 0; g0 < total_m; g0 += 64) {         // wave-uniform trip count: one member k-mer per lane and step (count_partition's scheme)
+            const int g = g0 + lane;
+            const bool active = g < total_m;
+            int ri = 0, ex = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int cand = ri + step;
+                const int e = __shfl(excl, cand & 63);
+                if (e <= g) { ri = cand; ex = e; }
+            }
+            RecView<W> Q;
+#pragma unroll
+            for (int i = 0; i < RW; ++i) Q.r[i] = __shfl(R.r[i], ri);
+            const uint32_t it = __shfl(item, ri);
+            if (active) {
+                const uint64_t o0 = P.big_off[it];
+                KTable<W> T; T.keys = P.g_keys + o0 * W; T.mask = (uint32_t)(P.big_off[it + 1] - o0) - 1u;
+                uint32_t* const cnt = P.g_cnt + o0;
+                const int t = g - ex, qn = Q.n();
+                const Kmer<W> fw = Q.kmer(t, k);
+                const Kmer<W> rc = fw.rc(k);
+                const bool rev = rc < fw;
+                Kmer<W> ck = rev ? rc : fw;
+                ck.w[W - 1] |= key_flags(t == 0 && Q.first_foreign(), t == qn - 1 && Q.last_foreign(), rev);
+                bool is_new;
+                const uint32_t s = ktable_insert<W, true>(T, ck, is_new, T.mask);   // (tables hold twice the partition's member k-mers: never full)
+                if (s == 0xFFFFFFFFu) *P.error = 2;
+                else {
+                    const bool trav = (t == 0 && Q.first_trav()) || (t == qn - 1 && Q.last_trav());
+                    count_add_sat(&cnt[s]);
+                    if (trav) atomic_or_u32(&cnt[s], TRAV_FLAG);
+                }
+            }
+        }
+    }
+}
+// PHASE 0: statistics and the number of solid entries of every partition; PHASE 1: the solid entries into the partitions' segments
+template <int W, int PHASE>
+__global__ void __launch_bounds__(256) k_big_sweep(BigGridParams B) {
+    const CountParams& P = B.c;
+    const int lane = threadIdx.x & 63;
+    const uint64_t total = P.big_off[P.n_items];
+    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x >> 6), gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint64_t st_dist = 0, st_occ = 0, st_sh = 0, st_st = 0;
+    for (uint64_t s0 = gw * 64; s0 < total; s0 += nwaves * 64) {   // wave-uniform; the 64 slots lie in one table
+        const uint32_t item = big_find(P.big_off, P.n_items, s0);
+        const uint64_t s = s0 + (uint64_t)lane;
+        const bool used = P.g_keys[s * W + (W - 1)] != KEY_EMPTY;
+        const uint32_t c = count_word_out(P.g_cnt[s]), n = c & ~TRAV_FLAG; const bool trav = c & TRAV_FLAG;
+        const bool solid = used && n >= P.amin;
+        if (PHASE == 0 && used) {
+            if (!trav) { ++st_dist; st_occ += n; }
+            if (solid) { if (trav) ++st_st; else ++st_sh; }
+        }
+        const uint64_t m = __ballot(solid);                // (every lane of the wave is here)
+        if (m == 0) continue;
+        const uint32_t cntm = (uint32_t)__popcll(m);
+        if (PHASE == 0) { if (lane == 0) atomic_add_u32(&B.nsolid[item], cntm); }
+        else {
+            uint32_t base = 0;
+            if (lane == 0) base = atomic_add_u32(&B.wr[item], cntm);
+            base = __shfl(base, 0);
+            if (solid) {
+                const uint64_t o = B.seg_base + B.seg_pref[item] + base + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+                for (int i = 0; i < W; ++i) P.solid_keys[o * W + i] = P.g_keys[s * W + i];
+                P.solid_cnt[o] = c;
+            }
+        }
+    }
+    if (PHASE == 0) {
+        st_dist = wave_sum_u64(st_dist); st_occ = wave_sum_u64(st_occ); st_sh = wave_sum_u64(st_sh); st_st = wave_sum_u64(st_st);
+        if (lane == 0) {
+            if (st_dist) atomic_add_u64(&P.stats[0], st_dist);
+            if (st_occ) atomic_add_u64(&P.stats[1], st_occ);
+            if (st_sh) atomic_add_u64(&P.stats[2], st_sh);
+            if (st_st) atomic_add_u64(&P.stats[3], st_st);
+        }
+    }
+}
+// the listed partitions' segments: [seg_base + seg_pref[i], + nsolid[i])
+__global__ void k_big_segments(BigGridParams B) {
+    const CountParams& P = B.c;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_items) return;
+    const uint32_t p = P.part_list[i];
+    P.seg_off[p] = B.seg_base + B.seg_pref[i]; P.seg_n[p] = B.nsolid[i];
 }
 
 // ---- capped-layout repair: gather a spilled partition's region + spill records contiguously ----
