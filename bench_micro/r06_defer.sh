@@ -10,8 +10,5 @@ for l in sys.stdin:
     print('  wall %.1f  scan %.1f  count %.1f  place %.1f  compact %.1f  glue %.1f  slices %d' % (d['run_wall_ms'], d['ms_scan_emit'], d['ms_count'], d['ms_place'], d['ms_compact'], d['ms_glue'], d['count_slices']))
 " >> $L; }
 N=100000000 K=31
-run CDBG_DEFER_SLICES=0
-for pat in 2 4 4,4,4,2,1,1 4,4,4,3,1 4,4,4,2,2 4,4,3,2,2,1 6,4,3,2,1 5,4,3,2,1,1 3,4,4,3,1,1 4,3,3,2,2,1,1 8,4,2,1,1 2,2,2,2,2,2,2,1,1; do run CDBG_DEFER_SLICES=$pat CDBG_PLACE_GRID=512; done
-run CDBG_DEFER_SLICES=4,4,4,2,1,1 CDBG_PLACE_GRID=1024
-run CDBG_DEFER_SLICES=4,4,4,2,1,1 CDBG_PLACE_GRID=256
+for pat in ${PATS:-0 8,8 4 6,10 10,6 12,4}; do run CDBG_DEFER_SLICES=$pat; done
 cat $L
