@@ -209,6 +209,9 @@ struct DeferPlan { uint32_t n = 1; uint32_t w[16] = {}; uint32_t cap = 0; uint64
 // Measured at config 3 (profiles/r06_ab_defer_slices.log; same box, no deferral: 170.5 ms with the scan at 71): two halves 154.5 ms (scan 46, count stage 66.5 with
 // the placement's 36 ms inside it); four quarters 155.6 (41 + 72.5: the placement of 1.2 G records, 58 ms, is what the last quarter's count waits for); patterns with a
 // shrinking tail ("4,4,4,2,1,1") lost: every further placement launch lands on a chip full of count workgroups, unevenly, and runs at half its rate.
+// With the scan's loads pipelined over the tiles (k_scan_fast.h; profiles/r06_ab_scan_pipelined.log) the scan of a quarter takes 36 ms instead of 41 and single
+// steps of "4" or "6,6,4" reach 150 ms -- but over the 25 steps of bench.py, in one process: "8,8" 150.0 ms, "4" 153.7, "6,6,4" 154.4: one placement launch,
+// onto a chip the scan has just left, lands evenly every time; a second and third one do not.
 #ifndef CDBG_DEFER_PATTERN
 #define CDBG_DEFER_PATTERN "8,8"
 #endif

@@ -42,12 +42,18 @@ CDBG_DEV uint32_t scanf_enc4(uint32_t x, uint32_t& vbits) {
 #ifndef CDBG_SCAN_WAVES0
 #define CDBG_SCAN_WAVES0 3
 #endif
+// (the 15- / 16-key windows: five workgroups per CU fit the LDS; with the next tile's 16-byte loads held across a tile the kernel takes 102 VGPRs when
+//  left alone -- four waves per SIMD -- and 96 when promised five)
+#ifndef CDBG_SCAN_WAVES15
+#define CDBG_SCAN_WAVES15 5
+#endif
 template <int W, int MODE, int WNT>
-__global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (WNT == 15 || WNT == 16) ? 1 : WNT < 0 ? 2 : 4) k_scan_fast(ScanParams P) {
+__global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (WNT == 15 || WNT == 16) ? CDBG_SCAN_WAVES15 : WNT < 0 ? 2 : 4) k_scan_fast(ScanParams P) {
     constexpr int RW = RecFmt<W>::RW;
     constexpr int CAPB = RecFmt<W>::CAPB;
-    CDBG_SHARED uint32_t pk[SCANF_PKW];
-    CDBG_SHARED uint32_t vm[SCANF_PKW / 2 + 4];
+    // packed bases + validity bits of TWO tiles: the one being scanned and the next one, whose bytes are loaded while this one is scanned (below)
+    CDBG_SHARED uint32_t pk2[2][SCANF_PKW];
+    CDBG_SHARED uint32_t vm2[2][SCANF_PKW / 2 + 4];
     CDBG_SHARED uint32_t kg[SCANF_NQ + SCANF_NQ / 16 + 32];   // keys, then g (padded layout)
     CDBG_SHARED uint32_t blk[WNT < 0 ? SCANF_NQ / 16 + 8 : 1];   // two-level window: minimum of every 16-key block
     CDBG_SHARED uint32_t brk[SCANF_NQ / 32 + 4];              // bit q: junction q does not continue a run
@@ -64,28 +70,66 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (W
     uint32_t n_members = 0, n_trav = 0;
     if (tid == 0) { s_members = 0; s_trav = 0; }
     scan_defer_init<MODE>(P, s_defer);                       // (the first tile's barriers come before any record)
+    // ---- A. load + encode, software-pipelined over the tiles (round 6) ----
+    // The bytes of tile t + 1 are REQUESTED when tile t starts and encoded into the other LDS buffer just before tile t's records leave (phase E2).  Every
+    // barrier inside a tile is LDS-only, so nothing waits for global memory except that encode -- and what it waits for, besides its own loads, are the
+    // stores of tile t - 1, a whole tile old.  Before, a tile ended with __syncthreads() (s_waitcnt vmcnt(0): every record store of the tile acknowledged
+    // before the next tile's loads were even issued) and began by waiting for its loads: two exposed round trips to memory per tile and workgroup.
+    static_assert(SCANF_PKW <= 2 * SCAN_THREADS, "two 16-byte loads per lane cover a tile");
+    uint4 pv0, pv1; bool pin0 = false, pin1 = false;
+    auto tile_request = [&](uint64_t tl) {
+        const int64_t b = (((int64_t)tl * P.tile_stride + P.tile_offset) * SCANF_TILE) - 16;
+        const int64_t o0 = b + 16 * (int64_t)tid, o1 = b + 16 * (int64_t)(tid + SCAN_THREADS);
+        pin0 = o0 >= 0 && o0 < (int64_t)P.nbytes_padded;
+        pin1 = tid + SCAN_THREADS < SCANF_PKW && o1 >= 0 && o1 < (int64_t)P.nbytes_padded;
+        if (pin0) pv0 = *reinterpret_cast<const uint4*>(P.reads + o0);
+        if (pin1) pv1 = *reinterpret_cast<const uint4*>(P.reads + o1);
+    };
+    auto tile_encode = [&](int buf) {
+        uint32_t* const pkd = pk2[buf]; uint16_t* const vmd = reinterpret_cast<uint16_t*>(vm2[buf]);
+        auto enc = [&](const uint4& v, bool in, int w) {
+            uint32_t packed = 0, vbits = 0;
+            if (in) {
+                uint32_t v0, v1, v2, v3;
+                packed = (scanf_enc4(v.x, v0) << 24) | (scanf_enc4(v.y, v1) << 16) | (scanf_enc4(v.z, v2) << 8) | scanf_enc4(v.w, v3);
+                vbits = v0 | (v1 << 4) | (v2 << 8) | (v3 << 12);
+            }
+            pkd[w] = packed; vmd[w] = (uint16_t)vbits;
+        };
+        enc(pv0, pin0, tid);
+        if (tid + SCAN_THREADS < SCANF_PKW) enc(pv1, pin1, tid + SCAN_THREADS);
+        if (tid < 4) vm2[buf][SCANF_PKW / 2 + tid] = 0;
+        if (SCANF_PKW & 1) { if (tid == 4) vmd[SCANF_PKW] = 0; }
+    };
+    // (not for the long compile-time windows -- k = 55, m = 16: 39 keys -- whose register window leaves no room for eight more registers: the kernel spilled
+    //  and the config-4 share's scan went from 49 to 58 ms; there a tile loads its own bytes when it starts, as before)
+    constexpr bool PIPE = !(WNT > 32);
+    int cur = 0;
+    if (PIPE && (uint64_t)blockIdx.x < P.n_tiles) { tile_request(blockIdx.x); tile_encode(0); }
+    if (PIPE) CDBG_LDS_BARRIER();
     // persistent workgroups: a tile lives ~30 us, far too short to pay a workgroup launch for each
     for (uint64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
-    const int64_t t0 = ((int64_t)tile * P.tile_stride + P.tile_offset) * SCANF_TILE;
-    const int64_t base = t0 - 16;
-
-    // ---- A. load + encode ----
-    for (int w = tid; w < SCANF_PKW; w += SCAN_THREADS) {
-        const int64_t off = base + 16 * (int64_t)w;
-        uint32_t packed = 0, vbits = 0;
-        if (off >= 0 && off < (int64_t)P.nbytes_padded) {
-            const uint4 v = *reinterpret_cast<const uint4*>(P.reads + off);
-            uint32_t v0, v1, v2, v3;
-            packed = (scanf_enc4(v.x, v0) << 24) | (scanf_enc4(v.y, v1) << 16) | (scanf_enc4(v.z, v2) << 8) | scanf_enc4(v.w, v3);
-            vbits = v0 | (v1 << 4) | (v2 << 8) | (v3 << 12);
+    const bool has_next = PIPE && tile + gridDim.x < P.n_tiles;
+    if (has_next) tile_request(tile + gridDim.x);
+    if (!PIPE) {                                            // one 16-byte load at a time, encoded at once (four registers instead of eight)
+        const int64_t b = (((int64_t)tile * P.tile_stride + P.tile_offset) * SCANF_TILE) - 16;
+        for (int w = tid; w < SCANF_PKW; w += SCAN_THREADS) {
+            const int64_t off = b + 16 * (int64_t)w;
+            uint32_t packed = 0, vbits = 0;
+            if (off >= 0 && off < (int64_t)P.nbytes_padded) {
+                const uint4 v = *reinterpret_cast<const uint4*>(P.reads + off);
+                uint32_t v0, v1, v2, v3;
+                packed = (scanf_enc4(v.x, v0) << 24) | (scanf_enc4(v.y, v1) << 16) | (scanf_enc4(v.z, v2) << 8) | scanf_enc4(v.w, v3);
+                vbits = v0 | (v1 << 4) | (v2 << 8) | (v3 << 12);
+            }
+            pk2[0][w] = packed;
+            reinterpret_cast<uint16_t*>(vm2[0])[w] = (uint16_t)vbits;
         }
-        pk[w] = packed;
-        reinterpret_cast<uint16_t*>(vm)[w] = (uint16_t)vbits;
+        if (tid < 4) vm2[0][SCANF_PKW / 2 + tid] = 0;
+        if (SCANF_PKW & 1) { if (tid == 4) reinterpret_cast<uint16_t*>(vm2[0])[SCANF_PKW] = 0; }
+        CDBG_LDS_BARRIER();
     }
-    if (tid < 4) vm[SCANF_PKW / 2 + tid] = 0;
-    if (SCANF_PKW & 1) { if (tid == 4) reinterpret_cast<uint16_t*>(vm)[SCANF_PKW] = 0; }
-    if (tid == 0) s_nstart = 0;
-    __syncthreads();
+    uint32_t* const pk = pk2[cur]; uint32_t* const vm = vm2[cur];
     CDBG_SPH(0);
 
     // ---- B. rolling m-mer keys: lane chunk c covers m-mer starts [16c, 16c+16) ----
@@ -114,7 +158,7 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (W
         if (WNT < 0) blk[c] = bmin;
     }
     if (WNT < 0) { for (int c = (nq_keys + 15) / 16 + tid; c < SCANF_NQ / 16 + 8; c += SCAN_THREADS) blk[c] = 0xFFFFFFFFu; }   // (blocks past the keys: never the minimum)
-    __syncthreads();
+    CDBG_LDS_BARRIER();
     CDBG_SPH(1);
 
     // ---- C. g[q] = min of keys[q .. q+WN-1], 16 junctions per lane from a register window ----
@@ -201,12 +245,12 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (W
             }
         }
     }
-    __syncthreads();                                        // every lane has read its keys
+    CDBG_LDS_BARRIER();                                        // every lane has read its keys
     if (tid < nchunk_g) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) kg[scanf_pad(16 * tid + j)] = gq[j];
     }
-    __syncthreads();
+    CDBG_LDS_BARRIER();
     CDBG_SPH(2);
     {
         // validity window: bit i <-> base 16*tid + i - 16 (i.e. starts one chunk earlier, for q-1 tests)
@@ -258,16 +302,17 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (W
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int x = __shfl_up(incl, d); if (lane >= d) incl += x; }
         if (lane == 63) s_wsum[wave] = (uint32_t)incl;
-        __syncthreads();
+        CDBG_LDS_BARRIER();
         int off = incl - cnt;
         for (int w = 0; w < wave; ++w) off += (int)s_wsum[w];
         uint32_t bits = stt16;
         while (bits) { const int j = __ffs((int)bits) - 1; bits &= bits - 1; sl[off++] = (uint16_t)(16 * c + j); }
         if (tid == SCAN_THREADS - 1) s_nstart = (uint32_t)off;
     }
-    __syncthreads();
+    CDBG_LDS_BARRIER();
     CDBG_SPH(3);
 
+    if (has_next) tile_encode(cur ^ 1);                     // (the only wait for global memory in a tile: its loads had phases B - E1 to arrive)
     // ---- E2. one lane per run ----
     const int NMAX = CAPB - k + 1;
     const uint32_t rank_mask = (1u << P.rank_bits) - 1u;
@@ -326,8 +371,9 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (W
             c = ce + 1;
         }
     }
-    __syncthreads();                                        // the next tile reuses the LDS arrays
+    CDBG_LDS_BARRIER();                                        // the next tile reuses the LDS arrays (the records' words were read from them before this barrier; their stores drain behind it)
     CDBG_SPH(4);
+    if (PIPE) cur ^= 1;
     }
 #if defined(CDBG_PROFILE_PHASES) && !defined(CDBG_HOSTSIM)
     if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) atomic_add_u64(&P.stats[16 + i], sph[i]);
