@@ -317,12 +317,8 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT,
                         for (int i = 0; i < W; ++i)
                             fw.w[i] = ((uint64_t)alignbit_u32(in[2 * i + 2], in[2 * i + 1], sh) << 32) | alignbit_u32(in[2 * i + 1], in[2 * i], sh);
                         fw.mask(k);
-#ifdef CDBG_AB_NO_RC
-                        const Kmer<W> rc = fw; const bool rev = false;   // (A/B only: the ceiling of a count stage without reverse complements -- WRONG results)
-#else
                         const Kmer<W> rc = fw.rc(k);
                         const bool rev = rc < fw;
-#endif
                         const Kmer<W>& can = rev ? rc : fw;
                         const uint64_t ktop = can.w[W - 1] | ((uint64_t)((rev ? facts << 2 : facts) & 0xC0000000u) << 32);
                         uint32_t s = can.hash_lds() >> (32 - LOG_TS);
@@ -437,12 +433,8 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT,
                         for (int i = 0; i < W; ++i)
                             fw.w[i] = ((uint64_t)alignbit_u32(in[2 * i + 2], in[2 * i + 1], sh) << 32) | alignbit_u32(in[2 * i + 1], in[2 * i], sh);
                         fw.mask(k);
-#ifdef CDBG_AB_NO_RC
-                        const Kmer<W> rc = fw; const bool rev = false;
-#else
                         const Kmer<W> rc = fw.rc(k);
                         const bool rev = rc < fw;
-#endif
                         const Kmer<W>& can = rev ? rc : fw;
                         const uint64_t ktop = can.w[W - 1] | ((uint64_t)((rev ? facts << 2 : facts) & 0xC0000000u) << 32);
                         const uint32_t hh = can.hash_lds();
@@ -561,12 +553,8 @@ CDBG_DEV bool count_partition_fast(const CountParams& P, CountFastLds<W, TS, NT,
                             fw.w[i] = ((uint64_t)alignbit_u32(in[2 * i + 2], in[2 * i + 1], sh) << 32) | alignbit_u32(in[2 * i + 1], in[2 * i], sh);
                         fw.mask(k);
                     }
-#ifdef CDBG_AB_NO_RC
-                    const Kmer<W> rc = fw; const bool rev = false;
-#else
                     const Kmer<W> rc = fw.rc(k);
                     const bool rev = rc < fw;
-#endif
                     const Kmer<W>& can = rev ? rc : fw;
                     // the key carries the foreign-junction flags (KEY_FOREIGN_*, k_count.h): the same for every occurrence
                     // (bits 31 / 30 of `facts`: right / left junction foreign in read orientation; bits 29 / 28: the same two swapped)

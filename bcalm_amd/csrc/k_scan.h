@@ -676,11 +676,7 @@ __global__ void k_gen_reads(GenParams P) {
     if (G < P.read_len) G = P.read_len;
     const uint64_t r = P.first_read + i;
     const uint64_t start = gen_read_start(mix64(SEED_R + 2 * r), G, P.read_len, hostile);
-#ifdef CDBG_AB_GEN_FWD
-    const int strand = 0;                                  // (A/B only: every read from the forward strand)
-#else
     const int strand = (int)(mix64(SEED_R + 2 * r + 1) & 1ULL);
-#endif
     const uint64_t gp = strand ? start + P.read_len - 1 - j : start + j;
     uint32_t b = gen_genome_base(gp, G, SEED_G, hostile);
     if (strand) b = 3u - b;
