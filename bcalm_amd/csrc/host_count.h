@@ -346,9 +346,17 @@ int count_impl(cdbg_ctx* c) {
     Timer t;
     uint64_t spill_cap = 0;
     DeferPlan dp; uint32_t& defer_S = dp.n;                   // deferred placement: slices of the partition space (1: off) and their streams
+    OvfParams var_op{};                                      // skewed inputs: the overflow-region layout (its finishing pass runs slice by slice under deferred placement)
     bool deferred_open = false;                              // placement kernels of this step are (or may be) still running: the record count and the spill list are not final
     uint64_t sample_ns = 0, sample_stride = 0, sample_recs = 0;   // the capped path's sampled histogram, when it ran (still in part_count)
     if (c->ss_on) capped = true;                             // tiles [0, ss_done) were scanned while the input was arriving
+    auto defer_fill_params = [&](ScanParams& q) {            // the slices and streams of dp as the kernels see them
+        uint32_t lg = 0; while ((1ull << lg) < NPS) ++lg;
+        q.defer_slices = defer_S; q.defer_shift = lg - 4; q.defer_nseg = (uint32_t)dp.nseg; q.defer_map = 0;
+        for (uint32_t sl = 0, x = 0; sl < defer_S; ++sl) for (uint32_t i = 0; i < dp.w[sl]; ++i, ++x) q.defer_map |= (uint64_t)sl << (4 * x);
+        q.defer_seg_cap = dp.cap;
+        q.defer_recs = c->defer_recs.p; q.defer_part = c->defer_part.p; q.defer_count = c->defer_count.p;
+    };
     // repair: gather region + spilled records of each spilled partition into one contiguous run (k_count.h); the one-pass count kernels
     // leave such a partition alone (fill > capacity) and the repair launch of the count stage counts the gathered copy
     auto repair_spills = [&](const uint64_t* ovf) -> int {
@@ -419,13 +427,7 @@ int count_impl(cdbg_ctx* c) {
         else {
             sp.tile_stride = 1; sp.records = c->records.p; sp.part_cap = part_cap; sp.part_fill = c->part_count.p;
             sp.spill_recs = c->spill_recs.p; sp.spill_part = c->spill_part.p; sp.spill_cursor = c->cursors.p + 6; sp.spill_cap = spill_cap;
-            if (defer_S > 1) {
-                uint32_t lg = 0; while ((1ull << lg) < NPS) ++lg;
-                sp.defer_slices = defer_S; sp.defer_shift = lg - 4; sp.defer_nseg = (uint32_t)dp.nseg; sp.defer_map = 0;
-                for (uint32_t q = 0, x = 0; q < defer_S; ++q) for (uint32_t i = 0; i < dp.w[q]; ++i, ++x) sp.defer_map |= (uint64_t)q << (4 * x);
-                sp.defer_seg_cap = dp.cap;
-                sp.defer_recs = c->defer_recs.p; sp.defer_part = c->defer_part.p; sp.defer_count = c->defer_count.p;
-            }
+            if (defer_S > 1) defer_fill_params(sp);
             CK(t.start(s));
             const uint64_t done = c->ss_on ? std::min<uint64_t>(c->ss_done, tiles) : 0;
             sp.tile_offset = (uint32_t)done;
@@ -492,8 +494,9 @@ int count_impl(cdbg_ctx* c) {
         // sampled records) fits with near certainty; the flagged ones get their overflow region from their own count + 4 sigma
         if (c->knobs.get("CDBG_PART_CAP") == nullptr) part_cap = std::max<uint32_t>(part_cap, ((uint32_t)(3.0 * mean) + 7u) & ~7u);
         const float heavy_min = c->knobs.get("CDBG_PART_CAP") ? 0.0f : (float)(2.0 * mean / scale + 2.0);
-        OvfParams op{ c->part_count.p, c->var_cap.p, NPS, (float)scale, heavy_min, part_cap, c->part_off.p, NPS * (uint64_t)part_cap, c->ovf_words.p,
-                      c->part_count.p, nullptr, RW, c->var_pairs.p, c->dstats.p + 28 };
+        OvfParams& op = var_op;
+        op = OvfParams{ c->part_count.p, c->var_cap.p, NPS, (float)scale, heavy_min, part_cap, c->part_off.p, NPS * (uint64_t)part_cap, c->ovf_words.p,
+                        c->part_count.p, nullptr, RW, c->var_pairs.p, c->dstats.p + 28, 0, NPS };
         if (const char* e = c->knobs.get("CDBG_VAR_SCALE")) op.scale = (float)atof(e);   // test knob (with CDBG_PART_CAP): overflow regions far too small, so that partitions spill
         CDBG_LAUNCH(k_ovf_caps, (NPS + 255) / 256, 256, s, op);
         CK(exscan_u32(c, c->var_cap.p, c->part_off.p, NPS));
@@ -503,11 +506,21 @@ int count_impl(cdbg_ctx* c) {
         // does it fit?  What the card has free, plus what this context (the region of the step before) and the process's pool would hand
         // back, less a reserve for the stages that follow; an allocation that fails all the same falls back to the exact layout as well
         if ((double)total_cap * RW * 8.0 > region_budget()) var = false;           // would not fit: the exact layout
-        else if (c->records.alloc(total_cap * RW, false) != CDBG_OK) var = false;
+        else {
+            // deferred placement (above) on this layout as well: k_place looks a heavy partition's overflow word up like the scan does
+            sp.tile_stride = 1; sp.tile_offset = 0;
+            const uint64_t nseg = launch_scan_mode<W, SCAN_EMIT_CAPPED>(c, sp, tiles, true);
+            dp = defer_plan(c, W, mean, NPS, RW, nseg, region_budget() - (double)total_cap * RW * 8.0 + (double)(c->defer_recs.cap + c->defer_part.cap / 2) * 8.0);
+            if (c->records.alloc(total_cap * RW, false) != CDBG_OK) var = false;
+        }
         if (var) {
             c->ss_on = false;                                // (as on the capped path: a re-count scans everything)
             spill_cap = std::max<uint64_t>(total_cap / 32, 65536);
             CK(c->spill_recs.alloc(spill_cap * RW, false)); CK(c->spill_part.alloc(spill_cap, false));
+            if (defer_S > 1) {
+                if (c->defer_recs.alloc(dp.slots * RW, false) != CDBG_OK || c->defer_part.alloc(dp.slots, false) != CDBG_OK) defer_S = 1;
+                else { CK(c->defer_count.alloc((uint64_t)(defer_S - 1) * dp.nseg, false)); HIPCK(hipMemsetAsync(c->defer_count.p, 0, (uint64_t)(defer_S - 1) * dp.nseg * sizeof(uint32_t), s)); }
+            }
             CK(t.start(s));
             CDBG_LAUNCH(k_ovf_words, (NPS + 255) / 256, 256, s, op);
             HIPCK(hipMemsetAsync(c->part_count.p, 0, NPS * sizeof(uint32_t), s));      // the sample is spent: fill counters
@@ -515,19 +528,23 @@ int count_impl(cdbg_ctx* c) {
             HIPCK(hipMemsetAsync(c->cursors.p + 6, 0, sizeof(uint64_t), s));
             sp.tile_stride = 1; sp.tile_offset = 0; sp.records = c->records.p; sp.part_cap = part_cap; sp.part_fill = c->part_count.p; sp.ovf = c->ovf_words.p;
             sp.spill_recs = c->spill_recs.p; sp.spill_part = c->spill_part.p; sp.spill_cursor = c->cursors.p + 6; sp.spill_cap = spill_cap;
-            LAUNCH_SCAN(SCAN_EMIT_CAPPED, tiles);
-            sp.ovf = nullptr;
+            if (defer_S > 1) defer_fill_params(sp);
+            const uint64_t g = LAUNCH_SCAN(SCAN_EMIT_CAPPED, tiles);
+            if (defer_S > 1 && g != dp.nseg) return fail(CDBG_E_INTERNAL, "deferred placement: the scan ran with %llu workgroups, its streams have %llu segments", (unsigned long long)g, (unsigned long long)dp.nseg);
             op.records = c->records.p;
-            CDBG_LAUNCH(k_ovf_finish, std::min<uint64_t>((NPS + 3) / 4, 256 * 16), 256, s, op);
+            if (defer_S > 1) { CK(defer_launch_places<W>(c, sp)); deferred_open = true; }   // (k_ovf_finish then runs slice by slice, in front of every slice's count)
+            else CDBG_LAUNCH(k_ovf_finish, std::min<uint64_t>((NPS + 3) / 4, 256 * 16), 256, s, op);
+            sp.ovf = nullptr;
             CK(t.stop(&c->st.ms_scan_emit));
             hm.mark("count: sample + single-pass scan into capped regions with overflow regions");
-            CK(read_u64(c->dstats.p + 28, &n_records));
+            if (!deferred_open) CK(read_u64(c->dstats.p + 28, &n_records));
             CK(read_u64(c->dstats.p, hs, 2));
             CK(read_u64(c->cursors.p + 6, &n_spill));
             uint32_t derr = 0; CK(read_u32(c->derr.p, &derr));
             if (derr == 6 || n_spill > spill_cap) {          // the estimate was off by more than the spill list holds: exact layout
+                if (deferred_open) { HIPCK(hipStreamSynchronize(c->place_stream)); deferred_open = false; defer_S = 1; }
                 var = false; HIPCK(hipMemset(c->derr.p, 0, 4 * sizeof(uint32_t))); HIPCK(hipMemset(c->cursors.p + 6, 0, sizeof(uint64_t)));
-            } else if (n_spill) {
+            } else if (n_spill && !deferred_open) {
                 CK(repair_spills(c->ovf_words.p));
             }
         }
@@ -645,13 +662,18 @@ int count_impl(cdbg_ctx* c) {
         CountFastParams fp{ cp, c->retry_list.p, c->big_count.p + 1, count_fast_record_limit<W>(c->k), W == 1 ? 0u : W == 2 ? 177u : 200u };
         if (const char* e = c->knobs.get("CDBG_FAST_SKIP_Q8")) fp.skip_fill_q8 = (uint32_t)std::max(0, atoi(e));   // dev knob
         if (const char* e = c->knobs.get("CDBG_FAST_MAX_RECORDS")) fp.fast_max_records = std::min<uint32_t>(count_fast_record_limit<W>(c->k), (uint32_t)std::max(1, atoi(e)));   // dev knob
-        if (capped && defer_S > 1) {
+        if (defer_S > 1) {
             // deferred placement: the tier runs once per slice of the partition space, slice q as soon as its stream has been placed (stream q is
             // placed on the second HIP stream while slice q - 1 is counted here; slice 0 was placed by the scan)
             for (uint32_t q = 0, x = 0; q < defer_S; x += dp.w[q], ++q) {
                 if (q) HIPCK(hipStreamWaitEvent(s, c->place_ev[q], 0));
                 const uint64_t per = NPL / 16 * dp.w[q];
                 fp.c.item_base = (uint32_t)(NPL / 16 * x); fp.c.n_items = (uint32_t)per;
+                if (var) {                                   // (skewed inputs: the slice's overflowed partitions become one run each, begin / end of every partition written)
+                    var_op.p0 = NPL / 16 * x; var_op.p1 = var_op.p0 + per;
+                    CDBG_LAUNCH(k_ovf_finish, std::min<uint64_t>((per + 3) / 4, 256 * 16), 256, s, var_op);
+                    CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, false>), std::min<uint64_t>(per, COUNT_GRID), Cfg<W>::NTC, s, fp);
+                } else
                 CDBG_LAUNCH((k_count_fast<W, TS, Cfg<W>::NTC, true>), std::min<uint64_t>(per, COUNT_GRID), Cfg<W>::NTC, s, fp);
             }
         }
@@ -666,7 +688,9 @@ int count_impl(cdbg_ctx* c) {
         // every stream has been placed (the last slice's launch waited for it): the record count and the spill list are final now
         deferred_open = false;
         HIPCK(hipStreamSynchronize(c->place_stream));
-        CK(exscan(c->part_count.p)); CK(read_u64(c->part_off.p + NPS, &n_records)); c->st.n_records = n_records;
+        if (var) CK(read_u64(c->dstats.p + 28, &n_records));   // (k_ovf_finish summed the fills of its slices; the count kernels leave that word alone)
+        else { CK(exscan(c->part_count.p)); CK(read_u64(c->part_off.p + NPS, &n_records)); }
+        c->st.n_records = n_records;
         { std::vector<uint32_t> dc((size_t)(defer_S - 1) * dp.nseg); CK(read_u32(c->defer_count.p, dc.data(), dc.size())); uint64_t nd = 0;
           for (uint32_t v : dc) nd += std::min(v, dp.cap);
           c->st.n_deferred_records = nd; }
@@ -679,7 +703,7 @@ int count_impl(cdbg_ctx* c) {
             c->defer_off_once = true;
             return count_impl<W>(c);
         }
-        if (n_spill) CK(repair_spills(nullptr));             // (the tier above left the spilled partitions alone; their gathered copies are counted below)
+        if (n_spill) CK(repair_spills(var ? c->ovf_words.p : nullptr));   // (the tier above left the spilled partitions alone; their gathered copies are counted below)
     }
     CK(read_u32(c->big_count.p + 1, &nretry));
     const uint32_t* retry_ptr = c->retry_list.p;

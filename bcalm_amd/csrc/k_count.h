@@ -899,6 +899,7 @@ struct OvfParams {
     const uint32_t* sample; uint32_t* tcap; uint64_t n; float scale; float heavy_min; uint32_t part_cap;
     const uint64_t* toff; uint64_t area0; uint64_t* words;
     const uint32_t* fill; uint64_t* records; int RW; uint64_t* pairs; uint64_t* stats;   // stats[0] += records offered, stats[1] += partitions that used their overflow region
+    uint64_t p0, p1;             // k_ovf_finish: the partitions [p0, p1) (deferred placement finishes a slice of the partition space when its stream has been placed)
 };
 __global__ void k_ovf_caps(OvfParams P) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -922,7 +923,7 @@ __global__ void k_ovf_finish(OvfParams P) {              // one wave per partiti
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     uint64_t offered = 0, used = 0;
-    for (uint64_t p = wave; p < P.n; p += n_waves) {
+    for (uint64_t p = P.p0 + wave; p < P.p1; p += n_waves) {
         const uint64_t f = P.fill[p], d = P.words[p], t = d & OVF_CAP_MASK, hb = d >> OVF_CAP_BITS, b = p * P.part_cap;
         offered += f;
         uint64_t r0 = b, r1 = b + f;

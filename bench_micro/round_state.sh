@@ -1,4 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; tag=${1:-r05h}; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; tag=${1:-r06z}; cd $R
 timeout 2000 python -m pytest tests -m gpu -x -q > $O/${tag}_gputest.log 2>&1; grep -E "passed|failed" $O/${tag}_gputest.log
 python bench.py --steps 20 --warmup 5 > $O/${tag}_bench_n1.json 2> $O/${tag}_bench_n1.err
 python bench.py --cfg 4 --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > $O/${tag}_bench_cfg4_n1.json 2> $O/${tag}_bench_cfg4.err

@@ -315,6 +315,21 @@ def test_single_pass_scan_into_estimated_regions(oracle, sim, k, cfg, n_reads, r
     assert_parity(oracle, sim, text, k, 1, log2_partitions=log_np)
 
 
+@pytest.mark.parametrize("k,cfg,n_reads,read_len,part_min,var_scale,slices", [
+    (31, 3 | 0x100, 1500, 150, None, None, "2"), (31, 3 | 0x100, 1500, 150, 4, None, "4"), (21, 3 | 0x100, 1500, 150, 1, "0.02", "2"), (55, 4 | 0x100, 700, 150, 4, "0.3", "4")])
+def test_deferred_placement_with_overflow_regions(oracle, sim, k, cfg, n_reads, read_len, part_min, var_scale, slices, monkeypatch):
+    """deferred placement on the layout of skewed inputs (CDBG_SCAN_MODE=var): k_place looks a heavy partition's overflow word up like the scan,
+    k_ovf_finish runs slice by slice in front of every slice's count, spills out of overflow regions are repaired behind the last stream"""
+    monkeypatch.setenv("CDBG_SCAN_MODE", "var"); monkeypatch.setenv("CDBG_DEFER_SLICES", slices)
+    if part_min:
+        monkeypatch.setenv("CDBG_PART_CAP", str(part_min))
+    if var_scale:
+        monkeypatch.setenv("CDBG_VAR_SCALE", var_scale)
+    text = oracle.synth_reads(n_reads, read_len, cfg)
+    st = assert_parity(oracle, sim, text, k, 2, log2_partitions=10)["stats"]
+    assert st["count_slices"] in ((1, int(slices)) if var_scale else (int(slices),))
+
+
 @pytest.mark.parametrize("k,glen,log_np", [(15, 6000, 0), (31, 9000, 1), (32, 6000, 0), (55, 5000, 0), (96, 4000, 1), (127, 4000, 0)])
 @pytest.mark.parametrize("split", [True, False])
 def test_second_level_bucket_split(oracle, sim, k, glen, log_np, split, monkeypatch):
