@@ -45,12 +45,15 @@ void scan_params_base(cdbg_ctx* c, ScanParams& sp) {
     sp.tile_stride = 1; sp.tile_offset = 0; sp.error = c->derr.p;
 }
 // capacity of a partition region from a sampled histogram (single-pass capped layout)
-void capped_capacities(const cdbg_ctx* c, double mean, uint64_t NPL, uint32_t& part_cap, uint64_t& spill_cap) {
+// (streaming: the scan that runs while a FILE is still being read -- the CLI's first and only job, whose region is fresh device memory at 40 - 70 ms per GB: there
+//  the capacity is mean + 12 sqrt(mean), + 2.2 sigma: 43 GB instead of 53 at config 3, and the 1.4 % of the partitions that spill are repaired and counted from
+//  their gathered copies -- a few ms of GPU time against half a second of hipMalloc)
+void capped_capacities(const cdbg_ctx* c, double mean, uint64_t NPL, uint32_t& part_cap, uint64_t& spill_cap, bool streaming = false) {
     // A partition's records are the sum over its minimizer loci (~ coverage records each): the spread is ~ 5.5 sqrt(mean), so
     // mean + 20 sqrt(mean) is + 3.6 sigma -- a few hundred of config 3's 4 M partitions spill and are repaired.  Round 5: was
     // 2.5 mean + 8 sqrt(mean) (75 GB at config 3, now 53 GB): the scan does not care (same-box A/B, CDBG_PART_CAP 1128 / 768 / 640:
     // scan 67.4 / 65.3 / 69.1 ms), and fresh device memory costs the CLI 40 ms per GB (profiles/r05_micro_alloc.log).
-    part_cap = (uint32_t)(mean + 20.0 * std::sqrt(mean + 1.0) + 16.0);
+    part_cap = (uint32_t)(mean + (streaming ? 12.0 : 20.0) * std::sqrt(mean + 1.0) + 16.0);
     part_cap = (part_cap + 7u) & ~7u;
     if (const char* e = c->knobs.get("CDBG_PART_CAP")) part_cap = (uint32_t)std::max(1, atoi(e));   // test knob: force spills
     spill_cap = std::max<uint64_t>((uint64_t)(mean * (double)NPL / 32.0), 65536);
@@ -98,8 +101,10 @@ void prewarm_run(cdbg_ctx* c) {
     const int RW = 2 * c->W;
     const uint64_t NPL = c->n_local_parts;
     {   // records: ~2 runs of junctions per window of k - m + 1 minimizer positions
-        const double rec = (double)bytes * 2.0 / (double)(c->k - c->m + 2) * 1.12;
-        uint32_t part_cap = 0; uint64_t spill_cap = 0; capped_capacities(c, rec / (double)NPL, NPL, part_cap, spill_cap);
+        // (the density of random minimizers, 2 per window + 1; sequencing reads stay ~10 % below it -- separators, records cut at read ends.  An input that
+        //  exceeds it makes the streaming scan obtain a larger region itself: slower, not wrong)
+        const double rec = (double)bytes * 2.0 / (double)(c->k - c->m + 2);
+        uint32_t part_cap = 0; uint64_t spill_cap = 0; capped_capacities(c, rec / (double)NPL, NPL, part_cap, spill_cap, true);
         DBuf<uint64_t> r;
         size_t fr = 0, tot = 0;
         const bool fits = hipMemGetInfo(&fr, &tot) == hipSuccess && (double)part_cap * (double)NPL * RW * 8.0 < 0.6 * (double)fr;
@@ -150,7 +155,7 @@ int stream_scan_advance(cdbg_ctx* c) {
         CK(exscan_u32(c, c->part_count.p, c->part_off.p, NPL));
         uint64_t sample_records = 0; CK(read_u64(c->part_off.p + NPL, &sample_records));
         const double mean = (double)sample_records * (double)tiles_exp / (double)ns / (double)NPL;
-        capped_capacities(c, mean, NPL, c->ss_part_cap, c->ss_spill_cap);
+        capped_capacities(c, mean, NPL, c->ss_part_cap, c->ss_spill_cap, true);
         // (the same budget as count_impl -- what the card has free, what this context and the pool would hand back, less a reserve for the
         //  stages that follow; a region that cannot be had switches streaming off instead of failing the push)
         { size_t fr = 0, tot = 0;

@@ -48,7 +48,8 @@ while time.time() < t_end:
     if len(text) > (60_000 if SIM else 6_000_000): continue
     if only and it not in only: continue
     if dump: open(os.path.join(dump, 'fuzz_%d_%d.txt' % (seed0, it)), 'w').write(text)
-    params = dict(k=k, amin=amin, log2_partitions=rng.choice([-1, -1, 0, 3, 8, 12]), minimizer_size=rng.choice([0, 0, 0, min(k - 1, rng.randrange(2, 17))]))
+    lnp = [int(x) for x in os.environ["FUZZ_LOG_NP"].split(",")] if os.environ.get("FUZZ_LOG_NP") else [-1, -1, 0, 3, 8, 12]   # (deferred placement needs >= 1024 partitions)
+    params = dict(k=k, amin=amin, log2_partitions=rng.choice(lnp), minimizer_size=rng.choice([0, 0, 0, min(k - 1, rng.randrange(2, 17))]))
     try:
         exp = orc.run(text, k, amin)
         gr = bcalm_amd.Graph(k, amin, lib=lib, log2_partitions=params["log2_partitions"], minimizer_size=params["minimizer_size"])
