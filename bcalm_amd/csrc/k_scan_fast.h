@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(SCAN_THREADS, WNT == 0 ? CDBG_SCAN_WAVES0 : (W
         if (SCANF_PKW & 1) { if (tid == 4) vmd[SCANF_PKW] = 0; }
     };
     // (not for the long compile-time windows -- k = 55, m = 16: 39 keys -- whose register window leaves no room for eight more registers: the kernel spilled
-    //  and the config-4 share's scan went from 49 to 58 ms; there a tile loads its own bytes when it starts, as before)
+    //  and the config-4 share's scan went from 49 to 58 ms; promised three waves instead of four it does not spill and takes 57.5 ms, with 24 bytes of
+    //  scratch at four waves 59.3: there a tile loads its own bytes when it starts, as before)
     constexpr bool PIPE = !(WNT > 32);
     int cur = 0;
     if (PIPE && (uint64_t)blockIdx.x < P.n_tiles) { tile_request(blockIdx.x); tile_encode(0); }
