@@ -180,7 +180,10 @@ def test_multi_gpu_path_single_rank_rccl(oracle, hip, monkeypatch):
     (2, 31, 2, 200000, 150, 3, {"reads_replicated": True}), (4, 32, 2, 60000, 150, 4, {"reads_replicated": True}),
     (2, 31, 2, 300000, 150, 3, {"scan_mode": "capped"}), (4, 77, 2, 6000, 1000, 5, {"scan_mode": "capped"}),
     (2, 31, 2, 300000, 150, 3, {"scan_mode": "capped", "part_cap": "12"}), (4, 55, 2, 60000, 150, 4, {"scan_mode": "capped", "part_cap": "2"}),
-    (2, 31, 1, 40, 5000, "circular", {}), (4, 55, 1, 25, 3000, "circular", {})])
+    (2, 31, 1, 40, 5000, "circular", {}), (4, 55, 1, 25, 3000, "circular", {}),
+    # reads replicated (X0) through the capped scan: every rank defers half of ITS partitions' records (k_place beside the count of the other half)
+    (2, 31, 2, 300000, 150, 3, {"reads_replicated": True, "scan_mode": "capped", "log2_partitions": 13, "deferred": 2}),
+    (4, 31, 2, 200000, 150, 3, {"reads_replicated": True, "scan_mode": "capped", "log2_partitions": 13, "part_cap": "380", "deferred": 2})])
 def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, read_len, cfg, kw, monkeypatch):
     """the complete N-rank data path on the real device: N contexts on GPU 0 driven by N host threads, reads sharded,
     records / pieces / junction log / partner ids moved by an in-process loop-back transport (tests/loopback.py: RCCL
@@ -194,6 +197,7 @@ def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, rea
     if kw.get("part_cap"):                       # regions far too small: the spilled records are packed behind their regions (k_pack_spills)
         monkeypatch.setenv("CDBG_PART_CAP", kw.pop("part_cap"))
     want_links = kw.pop("links", False)           # cdbg_link on the sharded set: job-wide ids, the union of the ranks' links == brute force
+    want_slices = kw.pop("deferred", None)        # deferred record placement must have run on every rank
     if cfg == "circular":
         # isolated circular unitigs (plasmids) among the ranks: closed chains, cut in place by the sharded glue (k_dglue.h)
         rng = random.Random(n_reads + read_len)
@@ -236,6 +240,8 @@ def test_multi_rank_flow_on_one_device(oracle, hip, world, k, amin, n_reads, rea
     assert sum(out[r][1]["n_distinct"] for r in range(world)) == exp["stats"]["distinct"]
     assert sum(out[r][1]["n_solid"] for r in range(world)) == exp["stats"]["solid"]
     assert all(out[r][2] > 0 for r in range(world))
+    if want_slices:
+        assert all(out[r][1]["count_slices"] == want_slices and out[r][1]["n_deferred_records"] > 0 for r in range(world)), [out[r][1]["count_slices"] for r in range(world)]
     if want_links:
         sys.path.insert(0, os.path.join(oracle_lib.ROOT, "oracle"))
         import oracle_py as op
