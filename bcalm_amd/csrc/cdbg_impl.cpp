@@ -259,6 +259,7 @@ int cdbg_reset(cdbg_ctx* c) {
     if (!c) return fail(CDBG_E_PARAM, "null context");
     (void)hipSetDevice(c->prm.device_id);                 // (the caller may be any host thread: one thread per GPU in the CLI)
     prewarm_join(c);
+    if (c->place_stream) (void)hipStreamSynchronize(c->place_stream);   // (a count stage that returned with an error may have left its placement stream busy)
     c->stage = 0; c->st = cdbg_stats_t{};
     c->n_solid_entries = c->n_pieces = c->n_piece_bases = c->n_unitigs = c->unitig_total = 0; c->linked = false; c->n_links = 0; c->joined = false;
     c->xchg_done = false; c->xp_ab_ready = false; c->comm_bytes = 0; c->piece_lo = c->piece_hi = 0; c->ss_on = false; c->expect_bytes = 0;

@@ -196,15 +196,13 @@ int stream_scan_dispatch(cdbg_ctx* c) {
 // Deferred record placement (round 6).  The scan is bound by its memory REQUESTS (two per record: 1.6 G returning atomics beside 1.6 G partial-sector
 // stores, 66 ms at config 3 with a third of the VALU busy), the one-pass count kernel by VALU issue (57 ms, little traffic) -- and the two ran one
 // after the other.  Now the partition space is cut into S slices: the scan places slice 0's records as before and APPENDS the others to S - 1 streams
-// (coalesced 16-byte stores, one device atomic per wave); k_place (k_scan.h) scatters stream q on a second HIP stream while k_count_fast counts slice
-// q - 1 on the first (events between them).  The placement kernel needs no LDS and 4 wave slots per CU: the count's three workgroups per CU leave 8.
+// (coalesced 16-byte stores into one segment per scan workgroup, cursors in LDS: no device atomic); k_place (k_scan.h) scatters stream q on a second HIP
+// stream while k_count_fast counts slice q - 1 on the first (events between them).  The placement kernel needs no LDS and two wave slots per CU: the
+// count's three workgroups per CU leave eight.
 // Measured before it was built (profiles/r06_ab_overlap_place_vs_count.log): 0.8 G records placed beside the count cost the pair 70 ms against
-// 57 + 35 = 92 one after the other -- with ONE-WAVE workgroups, 4 per CU: larger workgroups or more of them land unevenly over the CUs once the count's
+// 57 + 35 = 92 one after the other -- with ONE-WAVE workgroups spread evenly over the CUs: larger workgroups or more of them land unevenly once the count's
 // workgroups are on the chip, and a CU with 12 placement waves is the step's tail.
 // ---------------------------------------------------------------------------------------
-#ifndef CDBG_DEFER_SLICES
-#define CDBG_DEFER_SLICES 4
-#endif
 #ifndef CDBG_PLACE_GRID
 #define CDBG_PLACE_GRID (256 * 2)                          // (one-wave workgroups: two per CU.  256: too few requests in flight; 384, 768: land unevenly; 1024: fine for one launch on an idle chip, uneven for the launches behind it)
 #endif
