@@ -14,6 +14,10 @@ roofline = the dominant kernel's ALGORITHMIC bytes (SURVEY.md section 8d stage-i
           model, evaluated with the measured n_occ / S / P / U) / its launch duration,
           measured with HIP events on the library's own stream (cdbg_stats ms_*), against
           the 8 TB/s HBM3E peak.  `pipeline` inside it is the same for the whole step.
+          With deferred record placement (one-word k-mers: half of the records are scattered by
+          k_place on a second HIP stream WHILE k_count_fast counts the other half) the scan kernel
+          and the count stage are rated as ONE entry -- the bytes of both over the wall of both,
+          the placement stream's busy span listed beside it, not added -- see `roofline.kernels`.
 cpu_baseline = on the GPU box's host cores, a bounded sample of the same workload (10 M reads
           at k <= 31): a real BCALM 2 binary when one is reachable ($BCALM_BIN / `bcalm` on PATH;
           kind "reference", its unitig set is then diffed against the GPU's), otherwise the
