@@ -159,6 +159,9 @@ def test_two_rank_gloo():
                 (31, 2, 300, 150, 3, {"reads_replicated": True}), (31, 2, 300, 150, 3, {"scan_mode": "capped", "log2_partitions": 6}),
                 (31, 2, 300, 150, 3, {"scan_mode": "capped", "log2_partitions": 6, "part_cap": "3"}), (55, 2, 150, 150, 4, {"scan_mode": "capped", "part_cap": "1"}),
                 (55, 2, 200, 150, 4, {"scan_mode": "capped", "reads_replicated": True}), (31, 2, 200, 150, 3, {"empty_rank": 1}),
+                # reads replicated through the capped scan with 2^11 partitions per rank: every rank defers half of its partitions' records (k_place, two count slices)
+                (31, 2, 300, 150, 3, {"scan_mode": "capped", "reads_replicated": True, "log2_partitions": 12}),
+                (31, 2, 300, 150, 3, {"scan_mode": "capped", "reads_replicated": True, "log2_partitions": 12, "part_cap": "2"}),
                 (30, 2, 250, 150, 3, {"links": True}), (64, 1, 100, 300, 5, {"log2_partitions": 4, "links": True}),
                 (31, 2, 300, 150, 3, {"links": True}), (9, 1, 0, 0, "pufferize_refs", {"log2_partitions": 4, "minimizer_size": 4, "links": True}),
                 (8, 1, 0, 0, "even_k8", {"log2_partitions": 3, "minimizer_size": 4, "links": True}),
@@ -172,7 +175,8 @@ def test_four_rank_gloo():
     _launch(4, [(31, 2, 400, 150, 3, {"links": True}), (55, 1, 160, 150, 4, {"log2_partitions": 7, "links": True}), (127, 2, 80, 500, 5, {"log2_partitions": 5}),
                 # three plasmid-like circles of 1500 bp next to ordinary reads' worth of chains: cut in place, ranking restarted
                 (31, 1, 3, 1500, "@circular", {"log2_partitions": 6}), (55, 1, 2, 900, "@circular", {"log2_partitions": 5}),
-                (31, 2, 400, 150, 3, {"reads_replicated": True}), (31, 2, 300, 150, 3, {"scan_mode": "capped", "empty_rank": 3})], 31500, 300)
+                (31, 2, 400, 150, 3, {"reads_replicated": True}), (31, 2, 300, 150, 3, {"scan_mode": "capped", "empty_rank": 3}),
+                (31, 2, 400, 150, 3, {"scan_mode": "capped", "reads_replicated": True, "log2_partitions": 12})], 31500, 300)
 
 
 def test_eight_rank_gloo():
