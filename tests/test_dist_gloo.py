@@ -160,7 +160,6 @@ def test_two_rank_gloo():
                 (31, 2, 300, 150, 3, {"scan_mode": "capped", "log2_partitions": 6, "part_cap": "3"}), (55, 2, 150, 150, 4, {"scan_mode": "capped", "part_cap": "1"}),
                 (55, 2, 200, 150, 4, {"scan_mode": "capped", "reads_replicated": True}), (31, 2, 200, 150, 3, {"empty_rank": 1}),
                 # reads replicated through the capped scan with 2^11 partitions per rank: every rank defers half of its partitions' records (k_place, two count slices)
-                (31, 2, 300, 150, 3, {"scan_mode": "capped", "reads_replicated": True, "log2_partitions": 12}),
                 (31, 2, 300, 150, 3, {"scan_mode": "capped", "reads_replicated": True, "log2_partitions": 12, "part_cap": "2"}),
                 (30, 2, 250, 150, 3, {"links": True}), (64, 1, 100, 300, 5, {"log2_partitions": 4, "links": True}),
                 (31, 2, 300, 150, 3, {"links": True}), (9, 1, 0, 0, "pufferize_refs", {"log2_partitions": 4, "minimizer_size": 4, "links": True}),
