@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "cdbg.h"
+#include "pgz.h"
 
 #ifndef CDBG_VERSION
 #define CDBG_VERSION "cdbg-mi355x r1 (CLI-compatible with BCALM 2 v2.2.3)"
@@ -91,8 +92,9 @@ std::string base_name(const std::string& path) {          // strip directory and
 // N parser threads write sequence text STRAIGHT INTO the library's pinned staging buffers (cdbg_stage_acquire / _commit: no
 // intermediate copy; the H2D copies and -- with cdbg_expect_input -- the read scan itself run behind the parsing).  A plain
 // file is memory-mapped and cut into record-aligned slices (FASTA: at "\n>", strict four-line FASTQ: at an '@' line whose
-// second successor starts with '+'), one task per slice; a gzip file, or a FASTQ whose records wrap, is one task (inflate is
-// sequential): a file list keeps as many of those in flight as there are threads.
+// second successor starts with '+'), one task per slice; a FASTQ whose records wrap is one task.  A gzip file is inflated by ALL
+// threads when there are few of them (pgz.h: block starts searched, chunks decoded with the window unknown, resolved in order) and
+// its text parsed in slices like a plain file; a list of many gzip files keeps one zlib stream per thread in flight instead.
 struct Ingest {
     std::vector<cdbg_ctx*> ctxs; int k = 31;
     std::atomic<size_t> next_ctx{0};
@@ -213,6 +215,8 @@ void parse_stream(const std::string& path, Sink& out) {
             else if (!(starts_line && n && line[0] == ';')) out.bases(line.data(), n);
         }
     }
+    int zerr = Z_OK; const char* zmsg = gzerror(f, &zerr);
+    if (zerr != Z_OK && zerr != Z_STREAM_END) { const std::string m = zmsg ? zmsg : "read error"; gzclose(f); usage_error(path + ": " + m); }
     gzclose(f);
     out.end_seq();
 }
@@ -292,10 +296,19 @@ void plan_file(const std::string& path, int threads, std::vector<Task>& tasks) {
     }
     tasks.push_back(Task{ 0, path, nullptr, 0, 0 });
 }
+bool ingest_gz_parallel(Ingest& I, const std::string& path, int threads);
 // parse every file with `threads` workers; false: a FASTQ file was not as regular as its first record promised (nothing usable was pushed)
 bool ingest_files(Ingest& I, const std::vector<std::string>& files, int threads, bool allow_slices) {
     std::vector<Task> tasks;
-    for (const auto& f : files) { if (allow_slices) plan_file(f, threads, tasks); else tasks.push_back(Task{ 0, f, nullptr, 0, 0 }); }
+    // few gzip files and many threads: each is inflated by all threads, one after the other (pgz.h); many gzip files: one thread each, as before
+    std::vector<std::string> gz_parallel;
+    size_t n_gz = 0; for (const auto& f : files) n_gz += is_gzip(f);
+    const bool pgz_on = allow_slices && threads >= 2 && n_gz * 2 <= (size_t)threads && getenv("BCALM_GZ_SERIAL") == nullptr;
+    for (const auto& f : files) {
+        if (pgz_on && is_gzip(f)) gz_parallel.push_back(f);
+        else if (allow_slices) plan_file(f, threads, tasks);
+        else tasks.push_back(Task{ 0, f, nullptr, 0, 0 });
+    }
     std::atomic<size_t> next{0};
     auto worker = [&]() {
         try {
@@ -317,7 +330,90 @@ bool ingest_files(Ingest& I, const std::vector<std::string>& files, int threads,
     worker();
     for (auto& t : th) t.join();
     if (I.failed) usage_error(I.error);
+    for (const auto& f : gz_parallel) {
+        if (I.irregular) break;
+        if (!ingest_gz_parallel(I, f, threads)) { Sink out(I); parse_stream(f, out); out.finish(); }
+    }
     return !I.irregular;
+}
+
+// ---- one gzip file inflated by all threads (pgz.h): real read sets ship as one or two .fastq.gz, and zlib inflates a file with one thread ----
+// start of the last record of [p, p + n) that may be incomplete (n: every record is complete); 0: no record start known
+size_t last_fasta_start(const char* p, size_t n) {
+    for (size_t e = n; e > 1;) {
+        const char* q = (const char*)memrchr(p, '>', e); if (!q) return 0;
+        const size_t i = (size_t)(q - p);
+        if (i == 0 || p[i - 1] == '\n') return i;
+        e = i;
+    }
+    return 0;
+}
+size_t last_fastq4_start(const char* p, size_t n) {
+    for (size_t back = (size_t)1 << 20;; back *= 16) {
+        const size_t from = n > back ? n - back : 0;
+        size_t r = from ? next_fastq4_record(p, n, from) : 0;
+        if (r < n) {
+            for (;;) {                                              // whole records from r on: four lines each
+                while (r < n && (p[r] == '\n' || p[r] == '\r')) ++r;
+                size_t e = r; int lines = 0;
+                while (lines < 4) { const char* nl = (const char*)memchr(p + e, '\n', n - e); if (!nl) break; e = (size_t)(nl - p) + 1; ++lines; }
+                if (lines < 4) return r;
+                r = e;
+            }
+        }
+        if (!from) return 0;
+    }
+}
+struct IrregularInput {};
+// false: not handled, nothing was pushed (the caller parses the file with zlib)
+bool ingest_gz_parallel(Ingest& I, const std::string& path, int threads) {
+    Mapped mp; if (!mp.open(path)) return false;
+    size_t chunk = (size_t)4 << 20;
+    if (const char* e = getenv("BCALM_GZ_CHUNK")) chunk = std::max<size_t>(1024, strtoull(e, nullptr, 10));   // (tests: many chunks of a small file)
+    std::vector<std::unique_ptr<Sink>> sinks;
+    for (int t = 0; t < threads; ++t) sinks.emplace_back(new Sink(I));
+    int fmt = 0;                                                    // 1 FASTA, 2 strict four-line FASTQ
+    auto on_wave = [&](char* p, size_t n, bool last) -> size_t {
+        if (!fmt) {
+            size_t f0 = 0; while (f0 < n && (p[f0] == '\n' || p[f0] == '\r')) ++f0;
+            if (f0 < n && (p[f0] == '>' || p[f0] == ';')) fmt = 1;
+            else if (f0 < n && p[f0] == '@') {                     // (plan_file's test of the first record)
+                const size_t l0 = line_len(p + f0, p + n), s1 = f0 + l0 + 1;
+                if (s1 < n) { const size_t l1 = line_len(p + s1, p + n), s2 = s1 + l1 + 1;
+                    if (s2 < n && p[s2] == '+') { const size_t l2 = line_len(p + s2, p + n), s3 = s2 + l2 + 1;
+                        if (s3 <= n && rstrip_cr(p + s3, s3 < n ? line_len(p + s3, p + n) : 0) == rstrip_cr(p + s1, l1)) fmt = 2; } }
+            }
+            if (!fmt) return pgz::ABORT;
+        }
+        const size_t cut = last ? n : (fmt == 1 ? last_fasta_start(p, n) : last_fastq4_start(p, n));
+        if (!cut) return n;                                         // not one complete record yet: all of it again, with more behind
+        std::vector<size_t> b((size_t)threads + 1, cut); b[0] = 0;
+        for (int t = 1; t < threads; ++t) {
+            const size_t pos = cut / (size_t)threads * (size_t)t;
+            const size_t x = pos ? (fmt == 1 ? next_fasta_record(p, cut, pos) : next_fastq4_record(p, cut, pos)) : 0;
+            b[t] = std::min(cut, std::max(x, b[t - 1]));
+        }
+        std::atomic<bool> irregular{false};
+        pgz::parallel_for((size_t)threads, threads, [&](size_t t) {
+            if (b[t] >= b[t + 1] || I.failed) return;
+            try {
+                if (fmt == 1) parse_fasta_slice(p + b[t], p + b[t + 1], *sinks[t]);
+                else if (!parse_fastq4_slice(p + b[t], p + b[t + 1], *sinks[t])) irregular = true;
+            } catch (const std::exception& e) { I.fail(e.what()); }
+        });
+        if (I.failed) throw std::runtime_error(I.error);
+        if (irregular) throw IrregularInput{};
+        return n - cut;
+    };
+    pgz::Stats st; int rc = 0;
+    try { rc = pgz::inflate_parallel((const uint8_t*)mp.p, mp.n, threads, chunk, on_wave, &st); }
+    catch (const IrregularInput&) { I.irregular = true; return true; }         // (records that are not four lines: the caller starts over)
+    catch (const std::exception& e) { usage_error(path + ": " + e.what()); }
+    if (rc != 0) return false;
+    for (auto& sk : sinks) sk->finish();
+    if (getenv("BCALM_GZ_VERBOSE")) fprintf(stderr, "[bcalm] %s: inflated by %d threads, %zu chunks (%zu block starts found), %zu waves, %zu members, %.2f GB of text; find %.2f s, decode %.2f s, resolve %.2f s, parse %.2f s\n",
+                                            path.c_str(), threads, st.chunks, st.starts_found, st.waves, st.members, st.out_bytes * 1e-9, st.s_find, st.s_decode, st.s_resolve, st.s_caller);
+    return true;
 }
 
 // approximate number of sequence bytes a file will deliver (cdbg_expect_input): gzip ~4x, FASTQ carries as many quality bytes
