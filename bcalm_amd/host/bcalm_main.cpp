@@ -368,7 +368,8 @@ struct IrregularInput {};
 // false: not handled, nothing was pushed (the caller parses the file with zlib)
 bool ingest_gz_parallel(Ingest& I, const std::string& path, int threads) {
     Mapped mp; if (!mp.open(path)) return false;
-    size_t chunk = (size_t)4 << 20;
+    // 4 MB of compressed bytes per chunk (its text is held as 16-bit symbols until the wave is resolved); smaller for a small file, so that every thread gets some
+    size_t chunk = std::min<size_t>((size_t)4 << 20, std::max<size_t>((size_t)1 << 20, mp.n / ((size_t)threads * 4) + 1));
     if (const char* e = getenv("BCALM_GZ_CHUNK")) chunk = std::max<size_t>(1024, strtoull(e, nullptr, 10));   // (tests: many chunks of a small file)
     std::vector<std::unique_ptr<Sink>> sinks;
     for (int t = 0; t < threads; ++t) sinks.emplace_back(new Sink(I));
@@ -411,8 +412,8 @@ bool ingest_gz_parallel(Ingest& I, const std::string& path, int threads) {
     catch (const std::exception& e) { usage_error(path + ": " + e.what()); }
     if (rc != 0) return false;
     for (auto& sk : sinks) sk->finish();
-    if (getenv("BCALM_GZ_VERBOSE")) fprintf(stderr, "[bcalm] %s: inflated by %d threads, %zu chunks (%zu block starts found), %zu waves, %zu members, %.2f GB of text; find %.2f s, decode %.2f s, resolve %.2f s, parse %.2f s\n",
-                                            path.c_str(), threads, st.chunks, st.starts_found, st.waves, st.members, st.out_bytes * 1e-9, st.s_find, st.s_decode, st.s_resolve, st.s_caller);
+    if (getenv("BCALM_GZ_VERBOSE")) fprintf(stderr, "[bcalm] %s: inflated by %d threads, %zu chunks (%zu block starts found), %zu waves, %zu members, %.2f GB of text; find %.2f s, decode %.2f s, resolve %.2f s; parse %.2f s beside the decoding, %.2f s of it waited for\n",
+                                            path.c_str(), threads, st.chunks, st.starts_found, st.waves, st.members, st.out_bytes * 1e-9, st.s_find, st.s_decode, st.s_resolve, st.s_caller, st.s_wait);
     return true;
 }
 

@@ -14,7 +14,8 @@
 //   D  all chunks of the wave are resolved to bytes in parallel, CRC32 per gzip member segment; the segments are combined (crc32_combine)
 //      and checked against every member's trailer (CRC32, ISIZE).
 // The file is processed in WAVES of `threads` chunks; the text of a wave is handed to the caller as one contiguous buffer (it answers with
-// the number of trailing bytes it wants to see again in front of the next wave: an unfinished record).
+// the number of trailing bytes it wants to see again in front of the next wave: an unfinished record).  The caller works on a wave while
+// the next one is being decoded.
 // Anything this code cannot do BEFORE the first wave was delivered (no block starts found: stored / fixed blocks only; a tiny file) is
 // reported as "not handled" and the caller inflates with zlib; after that an inconsistency is an error (corrupt file).
 #pragma once
@@ -26,6 +27,7 @@
 #include <cstring>
 #include <algorithm>
 #include <functional>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -300,7 +302,7 @@ inline void parallel_for(size_t n, int threads, Fn&& fn) {
     for (auto& t : th) t.join();
 }
 
-struct Stats { size_t chunks = 0, starts_found = 0, chunks_on_chain = 0, waves = 0, members = 0; uint64_t out_bytes = 0; double s_find = 0, s_decode = 0, s_resolve = 0, s_caller = 0; };
+struct Stats { size_t chunks = 0, starts_found = 0, chunks_on_chain = 0, waves = 0, members = 0; uint64_t out_bytes = 0; double s_find = 0, s_decode = 0, s_resolve = 0, s_caller = 0, s_wait = 0; };
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // on_wave(char* text, size_t n, bool last) -> bytes at the end of `text` to put in front of the next wave (ABORT: see above).
@@ -326,11 +328,27 @@ inline int inflate_parallel(const uint8_t* d, size_t n, int threads, size_t chun
     struct Chunk { std::unique_ptr<Inflater> inf; size_t reached = 0; bool ok = false; std::string err; size_t out_at = 0; std::vector<uint32_t> seg_crc; };
     std::vector<uint8_t> window(WIN, 0);
     BufPool pool;
-    struct Text { char* p = nullptr; size_t cap = 0; ~Text() { free(p); } } tx;     // the wave's text (not zero-filled, kept over the waves)
+    struct Text { char* p = nullptr; size_t cap = 0; ~Text() { free(p); } } txs[2];  // the text of a wave (not zero-filled, kept over the waves); two: see `pending`
+    int cur_tx = 0;
     std::vector<char> carry;
     uint32_t crc_run = (uint32_t)crc32(0L, Z_NULL, 0); uint64_t len_run = 0;
     bool delivered = false;
     auto bad = [&](const std::string& what) -> int { if (!delivered) return 1; throw std::runtime_error("corrupt gzip input: " + what); };
+    // The caller works on wave w (parsing it) WHILE wave w + 1 is decoded; its answer -- the carry -- is needed when the text of wave w + 1 is laid out.
+    struct Pending { std::future<size_t> f; char* text = nullptr; size_t total = 0; bool on = false; } pending;
+    bool aborted = false;
+    auto settle = [&]() {                                              // wait for the caller; false: it refused the first wave
+        if (!pending.on) return true;
+        const double tw = now_s();
+        const size_t keep = pending.f.get(); pending.on = false;
+        st.s_wait += now_s() - tw;
+        if (keep == ABORT) { if (!delivered) { aborted = true; return false; } throw std::runtime_error("input text changed its format"); }
+        delivered = true;
+        if (keep > pending.total) throw std::runtime_error("pgz: bad carry");
+        carry.assign(pending.text + (pending.total - keep), pending.text + pending.total);
+        return true;
+    };
+    struct Settle { Pending& p; ~Settle() { if (p.on) { try { p.f.get(); } catch (...) {} } } } settle_on_exit{pending};   // (an exception on the way: the caller's threads are joined first)
     size_t cursor = 0;
     while (cursor < nchunks) {
         std::vector<size_t> wave{cursor};
@@ -352,7 +370,9 @@ inline int inflate_parallel(const uint8_t* d, size_t n, int threads, size_t chun
                 ++k; if (++passed > 8) { c.err = "block boundaries do not meet"; return; }      // (ran past starts[k]: that was not a block start)
             }
         });
-        st.s_decode += now_s() - t0; t0 = now_s();
+        st.s_decode += now_s() - t0;
+        if (!settle()) return 1;
+        t0 = now_s();
         // the chain from this wave's first chunk
         std::vector<size_t> chain; size_t c = cursor;
         for (;;) {
@@ -377,6 +397,7 @@ inline int inflate_parallel(const uint8_t* d, size_t n, int threads, size_t chun
             }
             window.swap(nw);
         }
+        Text& tx = txs[cur_tx]; cur_tx ^= 1;
         if (total + 1 > tx.cap) { free(tx.p); tx.cap = (total + 1) * 5 / 4; tx.p = (char*)malloc(tx.cap); if (!tx.p) throw std::runtime_error("pgz: out of memory"); }
         char* const text = tx.p;
         if (!carry.empty()) memcpy(text, carry.data(), carry.size());
@@ -409,14 +430,11 @@ inline int inflate_parallel(const uint8_t* d, size_t n, int threads, size_t chun
         st.s_resolve += now_s() - t0; t0 = now_s();
         for (auto& k : ch) if (k.inf) { pool.put(k.inf->o, k.inf->cap); k.inf->o = nullptr; }        // (chunks that were not on the chain)
         ch.clear();
-        const size_t keep = on_wave(text, total, last);
-        st.s_caller += now_s() - t0;
-        if (keep == ABORT) { if (!delivered) return 1; throw std::runtime_error("input text changed its format"); }
-        delivered = true;
-        if (keep > total) throw std::runtime_error("pgz: bad carry");
-        carry.assign(text + (total - keep), text + total);
+        pending.text = text; pending.total = total; pending.on = true;
+        pending.f = std::async(std::launch::async, [&on_wave, &st, text, total, last]() { const double tc = now_s(); const size_t k = on_wave(text, total, last); st.s_caller += now_s() - tc; return k; });
         cursor = c;
     }
+    if (!settle()) return 1;
     if (stats) *stats = st;
     return 0;
 }

@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
     } catch (const std::exception& e) { fprintf(stderr, "pgz_cat: %s\n", e.what()); return 1; }
     if (rc != 0) { fprintf(stderr, "pgz_cat: not handled\n"); return 2; }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    fprintf(stderr, "{\"threads\": %d, \"chunks\": %zu, \"starts_found\": %zu, \"chunks_on_chain\": %zu, \"waves\": %zu, \"members\": %zu, \"in_bytes\": %zu, \"out_bytes\": %llu, \"seconds\": %.3f, \"out_GB_per_s\": %.3f, \"s_find\": %.3f, \"s_decode\": %.3f, \"s_resolve\": %.3f, \"s_caller\": %.3f}\n",
-            threads, s.chunks, s.starts_found, s.chunks_on_chain, s.waves, s.members, (size_t)st.st_size, (unsigned long long)s.out_bytes, sec, s.out_bytes / sec * 1e-9, s.s_find, s.s_decode, s.s_resolve, s.s_caller);
+    fprintf(stderr, "{\"threads\": %d, \"chunks\": %zu, \"starts_found\": %zu, \"chunks_on_chain\": %zu, \"waves\": %zu, \"members\": %zu, \"in_bytes\": %zu, \"out_bytes\": %llu, \"seconds\": %.3f, \"out_GB_per_s\": %.3f, \"s_find\": %.3f, \"s_decode\": %.3f, \"s_resolve\": %.3f, \"s_caller\": %.3f, \"s_wait_for_caller\": %.3f}\n",
+            threads, s.chunks, s.starts_found, s.chunks_on_chain, s.waves, s.members, (size_t)st.st_size, (unsigned long long)s.out_bytes, sec, s.out_bytes / sec * 1e-9, s.s_find, s.s_decode, s.s_resolve, s.s_caller, s.s_wait);
     return 0;
 }

@@ -11,6 +11,7 @@ the HIP output, and of the real `bcalm` CLI binary (HIP build).
     src/bcalm_1.cpp:49-97) on FASTA, FASTQ.gz and file-list inputs.
 """
 import gzip
+import random
 import os
 import re
 import subprocess
@@ -211,6 +212,34 @@ def test_real_cli_binary_on_gpu(oracle, tmp_path):
     assert r.returncode == 1 and "EXCEPTION: Specifiy -in" in r.stdout
     r = subprocess.run([BCALM, "-in", "/nonexistent.fa"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "EXCEPTION:" in r.stdout
+
+
+def test_real_cli_binary_gzip_inflated_by_all_threads(oracle, tmp_path):
+    """one FASTQ.gz (single member, then 7 members) cut into 64 KB chunks and inflated by 8 threads (bcalm_amd/host/pgz.h), against the oracle and
+    against the one-thread zlib path; a damaged file is an error"""
+    assert os.path.exists(BCALM)
+    k = 31
+    reads = [r for r in oracle.synth_reads(40000, 150, 5).decode().split("\n") if r]
+    exp = oracle.run("\n".join(reads) + "\n", k, 2)
+    rng = random.Random(2)
+    fq = "".join("@SRR1.%d\n%s\n+\n%s\n" % (i, r, "".join(chr(33 + rng.randrange(20, 41)) for _ in r)) for i, r in enumerate(reads)).encode()
+    (tmp_path / "one.fastq.gz").write_bytes(gzip.compress(fq, 6))
+    step = len(fq) // 7 + 1
+    (tmp_path / "seven.fastq.gz").write_bytes(b"".join(gzip.compress(fq[i:i + step], 6) for i in range(0, len(fq), step)))
+    env = dict(os.environ, BCALM_GZ_CHUNK="65536", BCALM_GZ_VERBOSE="1")
+    for name in ("one", "seven"):
+        r = subprocess.run([BCALM, "-in", name + ".fastq.gz", "-kmer-size", str(k), "-abundance-min", "2", "-nb-cores", "8"], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "inflated by 8 threads" in r.stderr and "input: 40000 sequences, 6000000 bases" in r.stdout, r.stdout + r.stderr
+        assert oracle_lib.canonical_set(oracle, _parse_fa(tmp_path / (name + ".unitigs.fa"), k), k) == exp["unitigs"]
+    r = subprocess.run([BCALM, "-in", "one.fastq.gz", "-kmer-size", str(k), "-abundance-min", "2", "-out", "serial"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
+                       env=dict(env, BCALM_GZ_SERIAL="1"))
+    assert r.returncode == 0 and "inflated by" not in r.stderr
+    assert oracle_lib.canonical_set(oracle, _parse_fa(tmp_path / "serial.unitigs.fa", k), k) == exp["unitigs"]
+    blob = bytearray((tmp_path / "one.fastq.gz").read_bytes()); blob[len(blob) * 3 // 4] ^= 0x20
+    (tmp_path / "bad.fastq.gz").write_bytes(bytes(blob))
+    r = subprocess.run([BCALM, "-in", "bad.fastq.gz", "-kmer-size", str(k), "-abundance-min", "2", "-nb-cores", "8"], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "EXCEPTION" in r.stdout, r.stdout + r.stderr
 
 
 def test_result_digest_on_gpu(oracle, oracle_1m, hip):
