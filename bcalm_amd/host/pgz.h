@@ -11,8 +11,8 @@
 //      starts; if it runs past that position the next start was not a block start and the chunk carries on to the one after.
 //   C  the chain of chunks is walked from chunk 0 (whose start is known): each resolves its last 32 KB against the window handed to it and
 //      hands the result on -- 32 K look-ups per chunk, the only sequential work.
-//   D  all chunks of the wave are resolved to bytes in parallel, CRC32 per gzip member segment; the segments are combined (crc32_combine)
-//      and checked against every member's trailer (CRC32, ISIZE).
+//   D  all chunks of the wave are resolved to bytes in parallel; CRC32 per piece between member ends (parallel), combined (crc32_combine) and
+//      checked against every member's trailer (CRC32, ISIZE) before the caller sees the text.
 // The file is processed in WAVES of `threads` chunks; the text of a wave is handed to the caller as one contiguous buffer (it answers with
 // the number of trailing bytes it wants to see again in front of the next wave: an unfinished record).  The caller works on a wave while
 // the next one is being decoded.
@@ -38,6 +38,7 @@
 namespace pgz {
 
 constexpr uint64_t NONE = ~0ull;
+constexpr size_t DAMAGED = ~(size_t)0 - 1;     // (internal: a member's CRC32 / ISIZE did not match)
 constexpr size_t ABORT = ~(size_t)0;            // on_wave: "I cannot use this text" (only honoured for the first wave)
 constexpr uint32_t WIN = 32768;
 
@@ -325,7 +326,8 @@ inline int inflate_parallel(const uint8_t* d, size_t n, int threads, size_t chun
     if (found * 2 < nchunks - 1) return 1;
     Stats st; st.chunks = nchunks; st.starts_found = found; st.s_find = now_s() - t0;
 
-    struct Chunk { std::unique_ptr<Inflater> inf; size_t reached = 0; bool ok = false; std::string err; size_t out_at = 0; std::vector<uint32_t> seg_crc; };
+    struct Chunk { std::unique_ptr<Inflater> inf; size_t reached = 0; bool ok = false; std::string err; size_t out_at = 0; };
+    struct Seg { size_t off, len; bool ends_member; uint32_t crc, isize, got = 0; };
     std::vector<uint8_t> window(WIN, 0);
     BufPool pool;
     struct Text { char* p = nullptr; size_t cap = 0; ~Text() { free(p); } } txs[2];  // the text of a wave (not zero-filled, kept over the waves); two: see `pending`
@@ -342,6 +344,7 @@ inline int inflate_parallel(const uint8_t* d, size_t n, int threads, size_t chun
         const double tw = now_s();
         const size_t keep = pending.f.get(); pending.on = false;
         st.s_wait += now_s() - tw;
+        if (keep == DAMAGED) { if (!delivered) { aborted = true; return false; } throw std::runtime_error("corrupt gzip input: CRC32 / length of a member do not match its trailer"); }
         if (keep == ABORT) { if (!delivered) { aborted = true; return false; } throw std::runtime_error("input text changed its format"); }
         delivered = true;
         if (keep > pending.total) throw std::runtime_error("pgz: bad carry");
@@ -406,32 +409,35 @@ inline int inflate_parallel(const uint8_t* d, size_t n, int threads, size_t chun
             uint8_t* out = (uint8_t*)text + k.out_at;
             for (size_t j = 0; j < f.pos; ++j) { const uint16_t s = f.o[j]; out[j] = s < 256 ? (uint8_t)s : wv[s - 256]; }
             pool.put(f.o, f.cap); f.o = nullptr; f.cap = 0;
-            size_t a = 0;
-            for (size_t m = 0; m <= f.members.size(); ++m) {
-                const size_t b = m < f.members.size() ? f.members[m].out_off : f.pos;
-                k.seg_crc.push_back((uint32_t)crc32(crc32(0L, Z_NULL, 0), out + a, (uInt)(b - a)));
-                a = b;
-            }
         });
+        // the pieces of this wave's text between member ends, in order: their CRC32s are taken and checked beside the next wave's decoding, before the caller sees the text
+        std::vector<Seg> segs;
         for (size_t q = 0; q < chain.size(); ++q) {
             Chunk& k = ch[chain[q]]; Inflater& f = *k.inf; size_t a = 0;
             for (size_t m = 0; m <= f.members.size(); ++m) {
                 const size_t b = m < f.members.size() ? f.members[m].out_off : f.pos;
-                crc_run = (uint32_t)crc32_combine(crc_run, k.seg_crc[m], (z_off_t)(b - a)); len_run += b - a; a = b;
-                if (m < f.members.size()) {
-                    if (crc_run != f.members[m].crc || (uint32_t)len_run != f.members[m].isize) return bad("CRC32 / length of a member do not match its trailer");
-                    crc_run = (uint32_t)crc32(0L, Z_NULL, 0); len_run = 0; ++st.members;
-                }
+                Seg g; g.off = k.out_at + a; g.len = b - a; g.ends_member = m < f.members.size(); g.crc = g.ends_member ? f.members[m].crc : 0; g.isize = g.ends_member ? f.members[m].isize : 0;
+                segs.push_back(g); a = b;
             }
             st.out_bytes += f.pos;
         }
-        if (last && len_run) return bad("the last member has no trailer");
         st.chunks_on_chain += chain.size(); ++st.waves;
         st.s_resolve += now_s() - t0; t0 = now_s();
         for (auto& k : ch) if (k.inf) { pool.put(k.inf->o, k.inf->cap); k.inf->o = nullptr; }        // (chunks that were not on the chain)
         ch.clear();
         pending.text = text; pending.total = total; pending.on = true;
-        pending.f = std::async(std::launch::async, [&on_wave, &st, text, total, last]() { const double tc = now_s(); const size_t k = on_wave(text, total, last); st.s_caller += now_s() - tc; return k; });
+        pending.f = std::async(std::launch::async, [&on_wave, &st, &crc_run, &len_run, threads, text, total, last, segs]() mutable -> size_t {
+            parallel_for(segs.size(), threads, [&](size_t i) { segs[i].got = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef*)text + segs[i].off, (uInt)segs[i].len); });
+            for (const Seg& g : segs) {
+                crc_run = (uint32_t)crc32_combine(crc_run, g.got, (z_off_t)g.len); len_run += g.len;
+                if (g.ends_member) {
+                    if (crc_run != g.crc || (uint32_t)len_run != g.isize) return DAMAGED;
+                    crc_run = (uint32_t)crc32(0L, Z_NULL, 0); len_run = 0; ++st.members;
+                }
+            }
+            if (last && len_run) return DAMAGED;
+            const double tc = now_s(); const size_t k = on_wave(text, total, last); st.s_caller += now_s() - tc; return k;
+        });
         cursor = c;
     }
     if (!settle()) return 1;

@@ -228,7 +228,7 @@ def test_real_cli_binary_gzip_inflated_by_all_threads(oracle, tmp_path):
     (tmp_path / "seven.fastq.gz").write_bytes(b"".join(gzip.compress(fq[i:i + step], 6) for i in range(0, len(fq), step)))
     env = dict(os.environ, BCALM_GZ_CHUNK="65536", BCALM_GZ_VERBOSE="1")
     for name in ("one", "seven"):
-        r = subprocess.run([BCALM, "-in", name + ".fastq.gz", "-kmer-size", str(k), "-abundance-min", "2", "-nb-cores", "8"], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+        r = subprocess.run([BCALM, "-in", name + ".fastq.gz", "-kmer-size", str(k), "-abundance-min", "2", "-nb-cores", "8", "-out", name], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "inflated by 8 threads" in r.stderr and "input: 40000 sequences, 6000000 bases" in r.stdout, r.stdout + r.stderr
         assert oracle_lib.canonical_set(oracle, _parse_fa(tmp_path / (name + ".unitigs.fa"), k), k) == exp["unitigs"]
