@@ -66,6 +66,7 @@ def test_levels_strategies_members(pgz_cat, text, tmp_path):
         "bgzf_sized_members": b"".join(gzip.compress(text[i:i + 65280], 6) for i in range(0, len(text), 65280)),
         "members_zero_padded": gzip.compress(text[:1000000]) + b"\0" * 37 + gzip.compress(text[1000000:]),
         "trailing_garbage": _deflate(text, 6) + b"not a gzip member at all",
+        "bgzf_with_its_eof_marker": b"".join(gzip.compress(text[i:i + 65280], 6) for i in range(0, len(text), 65280)) + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"),
     }
     for name, blob in cases.items():
         p = tmp_path / (name + ".gz"); p.write_bytes(blob)
