@@ -31,7 +31,7 @@ echo "# 64 members, gzip -6 in parallel: $(ls -l reads.fq.gz | awk '{print $5}')
 echo "== bcalm, plain FASTQ, -nb-cores 32"; run $B -in reads.fq -kmer-size 31 -abundance-min 2 -nb-cores 32 -out p 2>&1 | grep "input:\|host:\|wall\|EXCEPTION"
 echo "== bcalm, FASTQ.gz, ONE zlib thread (BCALM_GZ_SERIAL=1)"; BCALM_GZ_SERIAL=1 run $B -in reads.fq.gz -kmer-size 31 -abundance-min 2 -nb-cores 32 -out s 2>&1 | grep "input:\|host:\|wall\|EXCEPTION"
 for t in 16 32 60; do
-  echo "== bcalm, FASTQ.gz, -nb-cores $t (all threads inflate)"; BCALM_GZ_VERBOSE=1 /usr/bin/time -f "max RSS %M KB" $B -in reads.fq.gz -kmer-size 31 -abundance-min 2 -nb-cores $t -out z$t 2>&1 | grep "input:\|host:\|EXCEPTION\|inflated\|max RSS"
+  echo "== bcalm, FASTQ.gz, -nb-cores $t (all threads inflate)"; BCALM_GZ_VERBOSE=1 python -c "import resource, subprocess, sys; rc = subprocess.call(sys.argv[1:]); print('max RSS %.1f GB (exit %d)' % (resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1048576.0, rc))" $B -in reads.fq.gz -kmer-size 31 -abundance-min 2 -nb-cores $t -out z$t 2>&1 | grep "input:\|host:\|EXCEPTION\|inflated\|max RSS"
 done
 python - <<PY
 import hashlib
