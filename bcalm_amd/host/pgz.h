@@ -41,6 +41,7 @@ constexpr uint64_t NONE = ~0ull;
 constexpr size_t DAMAGED = ~(size_t)0 - 1;     // (internal: a member's CRC32 / ISIZE did not match)
 constexpr size_t ABORT = ~(size_t)0;            // on_wave: "I cannot use this text" (only honoured for the first wave)
 constexpr uint32_t WIN = 32768;
+constexpr size_t MAX_CHUNK_SYMBOLS = (size_t)1 << 31;   // per chunk of compressed bytes: deflate reaches 1032 : 1 on constant input, and a wave holds `threads` chunks as 16-bit symbols
 
 inline uint64_t peek_bits(const uint8_t* d, size_t n, uint64_t bit) {          // >= 56 valid bits (zeros beyond the end)
     const size_t b = (size_t)(bit >> 3);
@@ -123,6 +124,7 @@ struct Inflater {
     bool fail(const char* e) { err = e; return false; }
     bool room(size_t more) {
         if (pos + more <= cap) return true;
+        if (pos + more > MAX_CHUNK_SYMBOLS) return fail("a chunk inflates to more than 2 GB (not sequence text; BCALM_GZ_SERIAL=1 reads it with zlib)");
         size_t nc = cap ? cap * 2 : (size_t)1 << 20; while (nc < pos + more) nc *= 2;
         void* p = realloc(o, nc * sizeof(uint16_t)); if (!p) return fail("out of memory");
         o = (uint16_t*)p; cap = nc; return true;
