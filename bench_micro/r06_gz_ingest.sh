@@ -35,6 +35,8 @@ echo "== bcalm, FASTQ.gz, ONE zlib thread (BCALM_GZ_SERIAL=1)"; BCALM_GZ_SERIAL=
 for t in 8 16 32; do
   echo "== bcalm, FASTQ.gz, -nb-cores $t (all threads inflate)"; BCALM_GZ_VERBOSE=1 run $B -in reads.fq.gz -kmer-size 31 -abundance-min 2 -nb-cores $t -out z$t 2>&1 | grep "input:\|host:\|wall\|EXCEPTION\|inflated"
 done
+echo "== bcalm, FASTQ.gz, default threads (min(32, CPUs the container grants))"; BCALM_GZ_VERBOSE=1 run $B -in reads.fq.gz -kmer-size 31 -abundance-min 2 -out zd 2>&1 | grep "input:\|host:\|wall\|EXCEPTION\|inflated"
+echo "== bcalm, plain FASTQ, default threads"; run $B -in reads.fq -kmer-size 31 -abundance-min 2 -out pd 2>&1 | grep "input:\|host:\|wall\|EXCEPTION"
 python - <<PY
 import hashlib
 comp = bytes.maketrans(b"ACGT", b"TGCA")
