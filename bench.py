@@ -124,6 +124,27 @@ def _reference_binary():
     return None
 
 
+
+def _cpus_granted():
+    """CPUs this process may use: affinity mask and the container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) -- a 256-thread host may grant 16"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
 def cpu_baseline(k, amin, read_len, cfg, sample_reads):
     """CPU baseline on the host cores of this box (reported, not the target).
     Preferred: the reference's own binary ($BCALM_BIN / `which bcalm`) on a FASTA dump of the sample, all cores.
@@ -177,13 +198,14 @@ def cpu_baseline(k, amin, read_len, cfg, sample_reads):
         import oracle_lib
         orc = oracle_lib.load()
         cores = os.cpu_count() or 1
+        granted = _cpus_granted()
         text = orc.synth_reads(sample_reads, read_len, cfg)
         r = oracle_lib.cpu_mt_run(text, k, amin, cores)
-        return {"value": r["distinct"] / r["s_total"], "unit": "kmers/s", "cores": cores, "kind": "port",
+        return {"value": r["distinct"] / r["s_total"], "unit": "kmers/s", "cores": cores, "cpus_granted": granted, "kind": "port",
                 "seconds": {"count": r["s_count"], "solid_table": r["s_solid"], "unitigs": r["s_unitigs"], "total": r["s_total"]},
                 "set_digest": "%016x" % r["set_digest"], "distinct": r["distinct"], "solid": r["solid"], "unitigs": r["unitigs"],
                 "sample": f"{sample_reads} x {read_len} bp synthetic reads (same generator, its own 30x genome), {r['distinct']} distinct k-mers, "
-                          f"{cores} threads on one shared lock-free table, reads -> unitigs in {r['s_total']:.2f} s; multithreaded CPU restatement "
+                          f"{cores} threads (the container grants {granted} CPUs) on one shared lock-free table, reads -> unitigs in {r['s_total']:.2f} s; multithreaded CPU restatement "
                           f"of the spec (oracle/cpu_mt.cpp), NOT BCALM 2 (its gatb-core sources are absent)"}
     cores = max(1, min(os.cpu_count() or 1, 32))
     t0 = time.time()
