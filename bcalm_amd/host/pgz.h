@@ -169,36 +169,48 @@ struct Inflater {
         fixed_dist.build(dl, 32);                                      // (symbols 30 / 31 have codes and no meaning: rejected where a distance is decoded)
         have_fixed = true;
     }
+    // the symbols of one block (tables L / D) from `bit` on.  The input is read through a 64-bit buffer that is topped up once per symbol (56+ bits: a
+    // length + its extra bits + a distance + its extra bits need 48); beyond the end of the input it is fed zero bytes, and `bit` says so afterwards.
     bool codes(const Huff& L, const Huff& D) {
         const uint32_t lmask = (1u << L.bits) - 1, dmask = D.bits ? (1u << D.bits) - 1 : 0;
-        const uint16_t* lt = L.tab.data(); const uint16_t* dt = D.tab.data();
-        const uint64_t end_bit = (uint64_t)n * 8;
+        const uint16_t* lt = L.tab.data(); const uint16_t* dt = D.tab.data(); const uint16_t* lf = L.fast;
+        const uint8_t* in = d + (size_t)(bit >> 3); const uint8_t* const in_end = d + n;
+        uint64_t bb = 0; unsigned bc = 0, zeros = 0;
         const size_t start = pos;
+#define PGZ_REFILL() do { \
+            if ((size_t)(in_end - in) >= 8) { uint64_t w; memcpy(&w, in, 8); bb |= w << bc; in += (63 - bc) >> 3; bc |= 56; } \
+            else { while (bc <= 56) { if (in < in_end) bb |= (uint64_t)*in++ << bc; else ++zeros; bc += 8; } if (zeros > 16) { store_bit(in, zeros, bc); return fail("truncated"); } } } while (0)
+#define PGZ_DROP(k) do { bb >>= (k); bc -= (k); } while (0)
+        if (in > in_end) return fail("truncated");
+        PGZ_REFILL();
+        PGZ_DROP((unsigned)(bit & 7));
         for (;;) {
             if (pos + 300 > cap && !room(1 << 16)) return false;
-            uint64_t v = peek_bits(d, n, bit);
-            uint32_t e = L.fast[v & 1023]; if (!e) e = lt[v & lmask];
+            PGZ_REFILL();
+            uint32_t e = lf[bb & 1023]; if (!e) e = lt[bb & lmask];
             uint32_t l = e & 15, s = e >> 4;
-            if (!l) return fail("bad literal/length code");
-            bit += l;
+            if (!l) { store_bit(in, zeros, bc); return fail("bad literal/length code"); }
+            PGZ_DROP(l);
             if (s < 256) {
                 if (text_only && !(s >= 32 ? s < 127 : (s == '\n' || s == '\r' || s == '\t'))) return fail("not text");
                 o[pos++] = (uint16_t)s;
-                // a second literal from the same peek (most symbols of text are literals)
-                v >>= l; e = L.fast[v & 1023]; l = e & 15; s = e >> 4;
-                if (l && s < 256 && !text_only) { bit += l; o[pos++] = (uint16_t)s; }
+                // a second and a third literal from the same buffer (most symbols of text are literals; 3 x 15 bits fit)
+                e = lf[bb & 1023]; l = e & 15; s = e >> 4;
+                if (l && s < 256 && !text_only) {
+                    PGZ_DROP(l); o[pos++] = (uint16_t)s;
+                    e = lf[bb & 1023]; l = e & 15; s = e >> 4;
+                    if (l && s < 256) { PGZ_DROP(l); o[pos++] = (uint16_t)s; }
+                }
                 continue;
             }
             if (s == 256) break;
             s -= 257; if (s >= 29) return fail("bad length symbol");
-            v >>= l;
-            uint32_t len = LEN_BASE[s] + (uint32_t)(v & ((1u << LEN_EXTRA[s]) - 1)); bit += LEN_EXTRA[s]; v >>= LEN_EXTRA[s];
+            const uint32_t len = LEN_BASE[s] + (uint32_t)(bb & ((1u << LEN_EXTRA[s]) - 1)); PGZ_DROP(LEN_EXTRA[s]);
             if (!D.bits) return fail("match without a distance code");
-            e = dt[v & dmask]; l = e & 15; s = e >> 4;
+            e = dt[bb & dmask]; l = e & 15; s = e >> 4;
             if (!l || s >= 30) return fail("bad distance code");
-            v >>= l; bit += l;
-            const uint32_t dd = DIST_BASE[s] + (uint32_t)(v & ((1u << DIST_EXTRA[s]) - 1)); bit += DIST_EXTRA[s];
-            if (bit > end_bit) return fail("truncated");
+            PGZ_DROP(l);
+            const uint32_t dd = DIST_BASE[s] + (uint32_t)(bb & ((1u << DIST_EXTRA[s]) - 1)); PGZ_DROP(DIST_EXTRA[s]);
             if (dd > pos) {
                 if (!placeholders || dd - pos > WIN) return fail("distance too far back");
                 for (uint32_t i = 0; i < len; ++i) {
@@ -214,9 +226,13 @@ struct Inflater {
             }
             if (pos - start > limit) return fail("block too long");
         }
-        if (bit > end_bit) return fail("truncated");
+#undef PGZ_REFILL
+#undef PGZ_DROP
+        store_bit(in, zeros, bc);
+        if (bit > (uint64_t)n * 8) return fail("truncated");
         return true;
     }
+    void store_bit(const uint8_t* in, unsigned zeros, unsigned bc) { bit = ((uint64_t)(in - d) + zeros) * 8 - bc; }
     // one block at `bit`
     bool block() {
         if (bit + 3 > (uint64_t)n * 8) return fail("truncated");
