@@ -197,8 +197,10 @@ def cpu_baseline(k, amin, read_len, cfg, sample_reads):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
         orc = oracle_lib.load()
-        cores = os.cpu_count() or 1
         granted = _cpus_granted()
+        # threads: all hardware threads -- unless the container grants fewer CPUs than the host shows: 256 threads on a 16-CPU grant run the restatement 1.5 x
+        # slower than 32 (bench_micro/cpu_baseline_threads.py on the GPU box: 8.1 M vs 12.4 M distinct k-mers/s; 16 threads: 10.9 M), so: twice the grant
+        cores = min(os.cpu_count() or 1, 2 * granted)
         text = orc.synth_reads(sample_reads, read_len, cfg)
         r = oracle_lib.cpu_mt_run(text, k, amin, cores)
         return {"value": r["distinct"] / r["s_total"], "unit": "kmers/s", "cores": cores, "cpus_granted": granted, "kind": "port",
