@@ -209,7 +209,7 @@ def cpu_baseline(k, amin, read_len, cfg, sample_reads):
                 "sample": f"{sample_reads} x {read_len} bp synthetic reads (same generator, its own 30x genome), {r['distinct']} distinct k-mers, "
                           f"{cores} threads (the container grants {granted} CPUs) on one shared lock-free table, reads -> unitigs in {r['s_total']:.2f} s; multithreaded CPU restatement "
                           f"of the spec (oracle/cpu_mt.cpp), NOT BCALM 2 (its gatb-core sources are absent)"}
-    cores = max(1, min(os.cpu_count() or 1, 32))
+    cores = max(1, min(os.cpu_count() or 1, 32, 2 * _cpus_granted()))
     t0 = time.time()
     res = []
     if cores > 1:                                            # one child process per core (never a Pool: a bench must not hang)
